@@ -1,0 +1,199 @@
+/* wayverb_amd.h -- C ABI of the MI355X-native waveguide engine.
+ *
+ * Drop-in boundary for wayverb's `waveguide::run` hot path.  Every entry point below names
+ * the reference interface it replaces (paths relative to the reference repository root).
+ * The C++ mirror of `waveguide::run<pre,post>` (include/wayverb_amd/waveguide.h) and the
+ * ctypes binding (wayverb_amd/engine.py) sit on top of exactly this ABI.
+ *
+ * Conventions
+ *   - every function returns WV_OK (0) or a negative WV_E_* status; no exception crosses the ABI;
+ *   - wv_last_error() returns the message for the calling thread's most recent failure;
+ *   - plain pointers + sizes only; host pointers unless a parameter says "device";
+ *   - node index = x + y*nx + z*nx*ny  (src/waveguide/src/cl/utils.cpp:33-36);
+ *   - an engine handle is used from one thread at a time (as `run` is,
+ *     src/waveguide/include/waveguide/waveguide.h:36-41).
+ */
+#ifndef WAYVERB_AMD_H
+#define WAYVERB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+    WV_OK = 0,
+    WV_E_INVALID_ARGUMENT = -1,
+    WV_E_INVALID_MESH = -2, /* node types / indices inconsistent with the data contract */
+    WV_E_HIP = -3,          /* a HIP runtime call failed (message has the HIP error string) */
+    WV_E_NO_DEVICE = -4,    /* no gfx950-class device visible: there is NO CPU fallback */
+    WV_E_COMM = -5,         /* RCCL failure in the halo exchange */
+    WV_E_STATE = -6         /* call not valid in the engine's current state */
+};
+
+/* ---- data contract: the reference's device structs, byte for byte -------------------------- */
+
+/* boundary_type bits -- src/waveguide/include/waveguide/cl/utils.h:11-21 */
+enum {
+    WV_ID_NONE = 0,
+    WV_ID_INSIDE = 1 << 0,
+    WV_ID_NX = 1 << 1,
+    WV_ID_PX = 1 << 2,
+    WV_ID_NY = 1 << 3,
+    WV_ID_PY = 1 << 4,
+    WV_ID_NZ = 1 << 5,
+    WV_ID_PZ = 1 << 6,
+    WV_ID_REENTRANT = 1 << 7
+};
+
+/* error_code bits -- src/waveguide/include/waveguide/cl/structs.h:8-15 */
+enum {
+    WV_FLAG_SUCCESS = 0,
+    WV_FLAG_INF = 1 << 0,
+    WV_FLAG_NAN = 1 << 1,
+    WV_FLAG_OUTSIDE_RANGE = 1 << 2,
+    WV_FLAG_OUTSIDE_MESH = 1 << 3,
+    WV_FLAG_SUSPICIOUS_BOUNDARY = 1 << 4
+};
+
+/* condensed_node -- cl/structs.h:19-22 (8 bytes) */
+typedef struct wv_condensed_node {
+    int32_t boundary_type;
+    uint32_t boundary_index;
+} wv_condensed_node;
+
+/* coefficients_canonical -- cl/filter_structs.h:39-44,65-66 (112 bytes) */
+typedef struct wv_coefficients_canonical {
+    double b[7];
+    double a[7];
+} wv_coefficients_canonical;
+
+/* boundary_data -- cl/structs.h:38-41 (56 bytes); boundary_data_array<D> is D of these */
+typedef struct wv_boundary_data {
+    double filter_memory[6];
+    uint32_t coefficient_index;
+    uint32_t reserved_;
+} wv_boundary_data;
+
+/* `waveguide::mesh` as `run` reads it (mesh.h:12-26, setup.h:27-48,
+ * cl/boundary_index_array.h:8-11).  All arrays are borrowed for the duration of wv_create. */
+typedef struct wv_mesh {
+    int32_t nx, ny, nz;                            /* mesh_descriptor::dimensions */
+    const wv_condensed_node* nodes;                /* [nx*ny*nz] */
+    const wv_coefficients_canonical* coefficients; /* [num_coefficients] */
+    uint32_t num_coefficients;
+    const uint32_t* boundary_indices_1; /* [num_boundary_1][1] surface index per filter */
+    const uint32_t* boundary_indices_2; /* [num_boundary_2][2] */
+    const uint32_t* boundary_indices_3; /* [num_boundary_3][3] */
+    uint64_t num_boundary_1, num_boundary_2, num_boundary_3;
+} wv_mesh;
+
+/* ---- engine options -------------------------------------------------------------------------- */
+enum { WV_PRECISION_F32 = 0, /* pressures as the reference stores them (cl_float) */
+       WV_PRECISION_F64 = 1  /* pressures in double: BASELINE.json north star */ };
+
+typedef struct wv_options {
+    int32_t struct_size; /* = sizeof(wv_options); lets the struct grow */
+    int32_t precision;   /* WV_PRECISION_* */
+    int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device */
+    /* z-slab decomposition: plane z=0 (ghost_lo) / z=nz-1 (ghost_hi) of this mesh is a ghost
+     * copy of the neighbouring rank's face plane; it is read, never updated, by this engine. */
+    int32_t ghost_lo, ghost_hi;
+    /* the error flag is brought to the host every `flag_interval` steps of wv_run
+     * (1 = after every step, like waveguide.h:100-101; 0 = once per wv_run call) */
+    int32_t flag_interval;
+    int32_t stream_variant; /* 0 = default kernel; other values select tuning variants */
+    int32_t reserved_[9];
+} wv_options;
+
+typedef struct wv_engine wv_engine;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+
+/* Replaces the set-up half of `run` (waveguide.h:43-76): zeroed previous/current fields, node,
+ * coefficient and boundary-state buffers (get_boundary_data<N>, setup.h:68-85). */
+int wv_create(const wv_mesh* mesh, const wv_options* options, wv_engine** out);
+void wv_destroy(wv_engine* e);
+const char* wv_last_error(void);
+/* Fills `options` with defaults (F64, current device, no ghosts, flag_interval 1). */
+void wv_default_options(wv_options* options);
+
+/* ---- buffer access used by step pre/post-processors ----------------------------------------- */
+enum { WV_BUF_CURRENT = 0, WV_BUF_PREVIOUS = 1 };
+
+/* core::read_value / core::write_value on the pressure buffer
+ * (src/core/include/core/cl/common.h:42-57); value converted to/from the engine precision. */
+int wv_read_value(wv_engine* e, int buffer, uint64_t index, double* value);
+int wv_write_value(wv_engine* e, int buffer, uint64_t index, double value);
+/* core::read_from_buffer / cl::copy of the whole field (common.h:34-40;
+ * preprocessor/gaussian.cpp:50).  elem_size 4 -> float[n], 8 -> double[n]. */
+int wv_read_field(wv_engine* e, int buffer, void* dst, int elem_size);
+int wv_write_field(wv_engine* e, int buffer, const void* src, int elem_size);
+/* Read back / restore boundary filter state in the reference layout boundary_data_array<D>[n_D]. */
+int wv_read_boundary_data(wv_engine* e, int dimensionality, wv_boundary_data* dst);
+int wv_write_boundary_data(wv_engine* e, int dimensionality, const wv_boundary_data* src);
+/* mesh::set_coefficients (src/waveguide/src/setup.cpp:38-50): n must equal num_coefficients */
+int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32_t n);
+/* Device addresses of the fields (element type per precision), for zero-copy wrappers. */
+int wv_device_buffer(wv_engine* e, int buffer, void** device_ptr);
+
+/* ---- stepping: the generic path ------------------------------------------------------------- */
+
+/* One loop body of waveguide.h:82-119 without the callbacks: clear flag, launch the update
+ * (previous <- next in place), read the flag back.  *flag receives the error_code bits. */
+int wv_step(wv_engine* e, int32_t* flag);
+/* std::swap(previous, current), waveguide.h:123 */
+int wv_swap(wv_engine* e);
+
+/* ---- stepping: the device-resident fast path ------------------------------------------------- */
+enum { WV_SOURCE_NONE = 0,
+       WV_SOURCE_HARD = 1, /* preprocessor::hard_source, preprocessor/hard_source.h:17-23 */
+       WV_SOURCE_SOFT = 2  /* preprocessor::soft_source, preprocessor/soft_source.h:17-25 */ };
+
+/* Signal injected at `node`, one sample per step, starting at the engine's current step. */
+int wv_set_source(wv_engine* e, int kind, uint64_t node, const double* signal, uint64_t n);
+/* Nodes whose pre-update `current` pressure is recorded every step
+ * (postprocessor::node, src/postprocessor/node.cpp:14-18; the 7 reads of
+ * directional_receiver.cpp:33-47).  node == UINT64_MAX records 0. */
+int wv_set_receivers(wv_engine* e, const uint64_t* nodes, uint32_t n);
+/* Run up to n_steps loop iterations on the device.  Stops early at the first step whose flag
+ * is non-zero: *steps_done = completed steps (that step excluded), *flag = its error bits. */
+int wv_run(wv_engine* e, uint64_t n_steps, uint64_t* steps_done, int32_t* flag);
+/* Receiver samples of steps [first, first+n) as double[n][num_receivers]. */
+int wv_fetch_receivers(wv_engine* e, uint64_t first, uint64_t n, double* dst);
+/* Number of loop iterations completed since creation. */
+int wv_step_count(wv_engine* e, uint64_t* steps);
+
+/* ---- timing hooks (bench.py) ------------------------------------------------------------------ */
+/* Mean duration in ms of the dominant (pressure update) kernel over the launches since the
+ * last call, measured with HIP events on the engine's own stream; 0 launches -> 0. */
+int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches);
+int wv_enable_kernel_timing(wv_engine* e, int enable);
+/* hipStreamSynchronize on every engine stream. */
+int wv_synchronize(wv_engine* e);
+
+/* ---- z-slab halo exchange over RCCL (multi-GPU) ---------------------------- */
+#define WV_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id; the caller distributes the bytes (e.g. torch.distributed broadcast) */
+int wv_comm_unique_id(void* id_bytes /* [WV_UNIQUE_ID_BYTES] */);
+/* Joins a communicator: this engine is slab `rank` of `nranks`, neighbours rank-1 / rank+1. */
+int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks);
+int wv_comm_destroy(wv_engine* e);
+
+/* ---- host helpers ------------------------------------------------------------------------------ */
+/* Synthetic box mesh of SURVEY.md 8(d): planes [z_begin, z_begin+z_count) of a global
+ * nx*ny*nz_global box; boundary_index numbered per dimensionality in increasing node index
+ * over planes [number_from, number_to) (set_boundary_index,
+ * src/waveguide/src/boundary_coefficient_finder.cpp:11-19); nodes outside that range get index 0.
+ * counts[3] receives the number of 1D/2D/3D boundary nodes numbered. */
+int wv_make_box_nodes(int32_t nx, int32_t ny, int32_t nz_global, int32_t z_begin, int32_t z_count,
+                      int32_t number_from, int32_t number_to, wv_condensed_node* nodes,
+                      uint64_t counts[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAYVERB_AMD_H */

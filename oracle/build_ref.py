@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Build oracle/_ref: the reference's OWN OpenCL C waveguide kernel, compiled for the host.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under wayverb_amd/ may import, link or call this.
+
+What this does (recipe from SURVEY.md section 8(c) / Appendix F):
+
+  1. reads the OpenCL C program text where it lies under /root/reference (the raw string
+     literals that `waveguide::program` concatenates at run time,
+     src/waveguide/src/program.cpp:534-556) -- the text is assembled in a temporary
+     directory and never written into this repository;
+  2. compiles it UNMODIFIED with `clang -x cl -cl-std=CL1.2 -ffp-contract=off` for
+     x86-64 (fp32 reference), and a second time with the pressure type promoted
+     float->double in the program.cpp part only (the "fp64-promoted reference" that
+     BASELINE.json's <=1e-12 target is defined against);
+  3. links each object with oracle/ref_shim.cpp, which supplies the handful of OpenCL
+     *language builtins* the kernel calls (get_global_id, popcount, isnan, ...; OpenCL
+     1.2 spec semantics) and a serial driver loop;
+  4. leaves only oracle/_ref/libwvref_f32.so and oracle/_ref/libwvref_f64.so behind
+     (git-ignored; they travel to the GPU box like any built .so).
+
+If /root/reference is absent (GPU box) this script is a no-op: the prebuilt .so files are used.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("WAYVERB_REFERENCE", "/root/reference")
+WG = os.path.join(REF, "src", "waveguide")
+OUT = os.path.join(HERE, "_ref")
+CLANG = os.environ.get("WV_CLANG", "/opt/rocm/lib/llvm/bin/clang")
+CLANGXX = os.environ.get("WV_CLANGXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+RAW = re.compile(r'R"\((.*?)\)"', re.S)
+
+
+def raw_strings(path):
+    with open(path) as f:
+        return RAW.findall(f.read())
+
+
+def representation(path, type_name):
+    """The OpenCL text registered as cl_representation<waveguide::type_name> in a header."""
+    with open(path) as f:
+        text = f.read()
+    m = re.search(
+        r"cl_representation<waveguide::" + re.escape(type_name) + r">\s*final\s*\{(.*?)\};",
+        text, re.S)
+    if not m:
+        raise RuntimeError("no cl_representation for %s in %s" % (type_name, path))
+    body = RAW.findall(m.group(1))
+    if not body:
+        raise RuntimeError("cl_representation<%s> has no inline text" % type_name)
+    return body[0]
+
+
+def int_constant(path, name):
+    with open(path) as f:
+        m = re.search(r"constexpr\s+size_t\s+" + name + r"\{(\d+)\}", f.read())
+    return int(m.group(1))
+
+
+def assemble(promote):
+    inc = os.path.join(WG, "include", "waveguide")
+    fs_h = os.path.join(inc, "cl", "filter_structs.h")
+    st_h = os.path.join(inc, "cl", "structs.h")
+    ut_h = os.path.join(inc, "cl", "utils.h")
+    md_h = os.path.join(inc, "mesh_descriptor.h")
+    biquad_order = int_constant(fs_h, "biquad_order")
+    biquad_sections = int_constant(fs_h, "biquad_sections")
+    canonical = biquad_order * biquad_sections
+
+    # the four typedef blocks the reference builds with std::to_string
+    # (src/waveguide/src/cl/filter_structs.cpp:5-64): same text, numbers substituted.
+    def memory_t(order, alias):
+        return ("\ntypedef struct {\n    filt_real array[%d];\n} memory_%d;\n\n"
+                "typedef memory_%d %s;\n" % (order, order, order, alias))
+
+    def coeffs_t(order, alias):
+        return ("\ntypedef struct {\n    filt_real b[%d];\n    filt_real a[%d];\n} coefficients_%d;\n\n"
+                "typedef coefficients_%d %s;\n" % (order + 1, order + 1, order, order, alias))
+
+    filter_constants = ("#define BIQUAD_SECTIONS %d\n#define BIQUAD_ORDER %d\n"
+                        "#define CANONICAL_FILTER_ORDER %d" %
+                        (biquad_sections, biquad_order, canonical))
+
+    filters = raw_strings(os.path.join(WG, "src", "cl", "filters.cpp"))[0]
+    utils = raw_strings(os.path.join(WG, "src", "cl", "utils.cpp"))[0]
+    source = raw_strings(os.path.join(WG, "src", "program.cpp"))[0]
+    if promote:
+        # promote ONLY the program.cpp part
+        source = re.sub(r"\bfloat\b", "double", source)
+        source = re.sub(r"([0-9]\.[0-9]+)f\b", r"\1", source)
+
+    # order of src/waveguide/src/program.cpp:537-556
+    parts = [
+        filter_constants,
+        representation(fs_h, "filt_real"),
+        memory_t(biquad_order, "memory_biquad"),
+        coeffs_t(biquad_order, "coefficients_biquad"),
+        memory_t(canonical, "memory_canonical"),
+        coeffs_t(canonical, "coefficients_canonical"),
+        representation(fs_h, "biquad_memory_array"),
+        representation(fs_h, "biquad_coefficients_array"),
+        representation(md_h, "mesh_descriptor"),
+        representation(st_h, "error_code"),
+        representation(st_h, "condensed_node"),
+        representation(st_h, "boundary_data"),
+        representation(st_h, "boundary_data_array_1"),
+        representation(st_h, "boundary_data_array_2"),
+        representation(st_h, "boundary_data_array_3"),
+        representation(ut_h, "boundary_type"),
+        filters,
+        utils,
+        source,
+    ]
+    return "\n".join(parts)
+
+
+def build(verbose=True):
+    if not os.path.isdir(WG):
+        if verbose:
+            print("[build_ref] %s absent: keeping prebuilt oracle/_ref (if any)" % WG)
+        return False
+    os.makedirs(OUT, exist_ok=True)
+    shim = os.path.join(HERE, "ref_shim.cpp")
+    with tempfile.TemporaryDirectory(prefix="wvref_") as tmp:
+        for tag, promote in (("f32", False), ("f64", True)):
+            cl = os.path.join(tmp, "program_%s.cl" % tag)
+            with open(cl, "w") as f:
+                f.write(assemble(promote))
+            obj = os.path.join(tmp, "program_%s.o" % tag)
+            subprocess.check_call([
+                CLANG, "-x", "cl", "-cl-std=CL1.2", "-target", "x86_64-unknown-linux-gnu",
+                "-Xclang", "-finclude-default-header", "-O2", "-ffp-contract=off",
+                "-fPIC", "-Werror", "-c", cl, "-o", obj])
+            so = os.path.join(OUT, "libwvref_%s.so" % tag)
+            subprocess.check_call([
+                CLANGXX, "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=c++14",
+                "-DWVREF_REAL=%s" % ("double" if promote else "float"),
+                "-DWVREF_TAG=%s" % tag,
+                shim, obj, "-o", so, "-lpthread"])
+            if verbose:
+                print("[build_ref] built", so)
+    return True
+
+
+if __name__ == "__main__":
+    sys.exit(0 if build() or True else 1)

@@ -1,0 +1,154 @@
+"""ctypes bindings for the TEST-ONLY checkers in oracle/.
+
+  Oracle()          -> liboracle.so   (the repo's C restatement, oracle/waveguide_oracle.c)
+  Reference("f32")  -> _ref/libwvref_f32.so  (reference kernel text compiled for the host)
+  Reference("f64")  -> _ref/libwvref_f64.so  (same, pressure type promoted to double)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def build_oracle():
+    so = os.path.join(HERE, "liboracle.so")
+    srcs = [os.path.join(HERE, f) for f in ("waveguide_oracle.c", "waveguide_oracle_body.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        for sfx in ("f32", "f64"):
+            f = getattr(self.lib, "wvo_step_" + sfx)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            g = getattr(self.lib, "wvo_run_" + sfx)
+            g.restype = C.c_int64
+            g.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                          C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self.lib.wvo_filter_test_2.argtypes = [C.c_void_p] * 4 + [C.c_int]
+        self.lib.wvo_filter_test.argtypes = [C.c_void_p] * 4 + [C.c_int]
+        self.lib.wvo_directional_receiver.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                                      C.c_double, C.c_void_p]
+
+    @staticmethod
+    def real(dtype):
+        dtype = np.dtype(dtype)
+        return "f32" if dtype == np.float32 else "f64"
+
+    def step(self, previous, current, mesh, bd, threads=1):
+        """previous <- next in place. bd = [bd1, bd2, bd3] boundary_data arrays. Returns flag."""
+        nx, ny, nz = mesh.dims
+        f = getattr(self.lib, "wvo_step_" + self.real(previous.dtype))
+        assert previous.dtype == current.dtype and previous.flags.c_contiguous
+        return f(_ptr(previous), _ptr(current), _ptr(mesh.nodes), nx, ny, nz,
+                 _ptr(bd[0]), _ptr(bd[1]), _ptr(bd[2]), _ptr(mesh.coefficients), threads)
+
+    def run(self, buf0, buf1, mesh, bd, source_kind, source_node, signal, n_steps, recv, threads=1):
+        """The run loop. Returns (steps_completed, flag, out[steps, n_recv])."""
+        nx, ny, nz = mesh.dims
+        sfx = self.real(buf0.dtype)
+        recv = np.ascontiguousarray(recv, dtype=np.int64)
+        signal = np.ascontiguousarray(signal, dtype=np.float64) if signal is not None else None
+        out = np.zeros((n_steps, len(recv)), dtype=buf0.dtype)
+        flag = C.c_int(0)
+        steps = getattr(self.lib, "wvo_run_" + sfx)(
+            _ptr(buf0), _ptr(buf1), _ptr(mesh.nodes), nx, ny, nz,
+            _ptr(bd[0]), _ptr(bd[1]), _ptr(bd[2]), _ptr(mesh.coefficients),
+            source_kind, source_node, _ptr(signal), n_steps, _ptr(recv), len(recv),
+            _ptr(out), threads, C.byref(flag))
+        return int(steps), int(flag.value), out
+
+    def filter_test_2(self, inp, memory, coeffs):
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        out = np.zeros_like(inp)
+        self.lib.wvo_filter_test_2(_ptr(inp), _ptr(out), _ptr(memory), _ptr(coeffs), len(inp))
+        return out
+
+    def filter_test(self, inp, memory, coeffs):
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        out = np.zeros_like(inp)
+        self.lib.wvo_filter_test(_ptr(inp), _ptr(out), _ptr(memory), _ptr(coeffs), len(inp))
+        return out
+
+    def directional_receiver(self, p7, spacing, sample_rate, ambient_density):
+        p7 = np.ascontiguousarray(p7, dtype=np.float32)
+        out = np.zeros((p7.shape[0], 4), dtype=np.float32)
+        self.lib.wvo_directional_receiver(_ptr(p7), p7.shape[0], spacing, sample_rate,
+                                          ambient_density, _ptr(out))
+        return out
+
+
+def reference_available():
+    return all(os.path.exists(os.path.join(HERE, "_ref", "libwvref_%s.so" % t)) for t in ("f32", "f64"))
+
+
+class Reference:
+    """The reference's own kernel, host-compiled (oracle/build_ref.py)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+        self.dtype = np.float32 if tag == "f32" else np.float64
+        self.lib = C.CDLL(os.path.join(HERE, "_ref", "libwvref_%s.so" % tag))
+        self._step = getattr(self.lib, "wvref_step_" + tag)
+        self._step.restype = None
+        self._step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int), C.c_int]
+        self._ft2 = getattr(self.lib, "wvref_filter_test_2_" + tag)
+        self._ft2.argtypes = [C.c_void_p] * 4 + [C.c_int]
+        self._ft = getattr(self.lib, "wvref_filter_test_" + tag)
+        self._ft.argtypes = [C.c_void_p] * 4 + [C.c_int]
+
+    def step(self, previous, current, mesh, bd, threads=1):
+        nx, ny, nz = mesh.dims
+        assert previous.dtype == self.dtype and current.dtype == self.dtype
+        flag = C.c_int(0)
+        self._step(_ptr(previous), _ptr(current), _ptr(mesh.nodes), nx, ny, nz,
+                   _ptr(bd[0]), _ptr(bd[1]), _ptr(bd[2]), _ptr(mesh.coefficients),
+                   C.byref(flag), threads)
+        return int(flag.value)
+
+    def run(self, buf0, buf1, mesh, bd, source_kind, source_node, signal, n_steps, recv, threads=1):
+        """The loop of waveguide.h:80-125 around the reference kernel (python driver)."""
+        previous, current = buf0, buf1
+        out = np.zeros((n_steps, len(recv)), dtype=self.dtype)
+        for step in range(n_steps):
+            if source_kind == 1:
+                current[source_node] = self.dtype(np.float32(signal[step])) if self.tag == "f32" \
+                    else self.dtype(signal[step])
+            elif source_kind == 2:
+                current[source_node] = current[source_node] + self.dtype(signal[step])
+            flag = self.step(previous, current, mesh, bd, threads)
+            if flag:
+                return step, flag, out
+            out[step] = current[np.asarray(recv, dtype=np.int64)]
+            previous, current = current, previous
+        return n_steps, 0, out
+
+    def filter_test_2(self, inp, memory, coeffs):
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        out = np.zeros_like(inp)
+        self._ft2(_ptr(inp), _ptr(out), _ptr(memory), _ptr(coeffs), len(inp))
+        return out
+
+    def filter_test(self, inp, memory, coeffs):
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        out = np.zeros_like(inp)
+        self._ft(_ptr(inp), _ptr(out), _ptr(memory), _ptr(coeffs), len(inp))
+        return out

@@ -1,0 +1,52 @@
+"""Build libwayverb_amd.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+`python -m wayverb_amd.build` or `wayverb_amd.build.build()`.  hipcc cross-compiles without a
+GPU; the resulting .so is git-ignored but travels to the GPU box with the tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libwayverb_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["engine.hip", "comm.cpp", "box_mesh.cpp"]
+HEADERS = ["device_common.hip.h", "stream_kernels.hip.h", "boundary_kernels.hip.h", "comm.h",
+           os.path.join("..", "..", "include", "wayverb_amd.h")]
+
+# -ffp-contract=off: results must not depend on where the compiler chooses to fuse a*b+c
+# (SURVEY.md Appendix A); correctly rounded fp32 divide/sqrt for the fp32-compat mode.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(f) > t for f in files)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[wayverb_amd.build]", " ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl", "-lpthread"]
+    if verbose:
+        print("[wayverb_amd.build]", " ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

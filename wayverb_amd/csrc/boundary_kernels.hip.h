@@ -1,0 +1,315 @@
+// boundary_kernels.hip.h -- locally-reacting boundary nodes with order-6 IIR wall filters,
+// source injection / receiver gather, and the one-off mesh set-up kernels.
+//
+// Replaces `boundary_1/2/3` and their helpers (src/waveguide/src/program.cpp:150-387) and
+// `filter_step_canonical` (src/waveguide/src/cl/filters.cpp:17-36,39).
+//
+// Data layout (HBM): boundary nodes are compacted into one entry list, all 1-D nodes first,
+// then 2-D, then 3-D, each in the reference's boundary_index order (increasing node index,
+// boundary_coefficient_finder.cpp:11-19) so consecutive lanes touch consecutive memory on the
+// y- and z-faces.  Filter state is structure-of-arrays: fmem[j][slot], slot = base_D + i*n_D + k
+// for filter i of node k, so the 6 state words of 64 neighbouring nodes are 6 coalesced 512-byte
+// rows instead of 64 strided 56-byte structs (cl/structs.h:38-41).
+//
+// Arithmetic: exactly SURVEY.md Appendix A -- pressure-type (Real) sums, double (filt_real)
+// quotients added into Real accumulators, no FMA contraction.
+#pragma once
+#include "device_common.hip.h"
+
+namespace wv {
+
+// Order-6 transposed direct form II with the reference's zero-coefficient guards
+// (filters.cpp:26-35): a rigid wall (a0 == 0) yields a non-finite `out` that every guarded
+// product then ignores.
+__device__ __forceinline__ void filter_step_6(double in, double m[6], const double* __restrict__ cb,
+                                              const double* __restrict__ ca) {
+    const double out = (in * cb[0] + m[0]) / ca[0];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double b = cb[i + 1] == 0 ? 0 : cb[i + 1] * in;
+        const double a = ca[i + 1] == 0 ? 0 : ca[i + 1] * out;
+        m[i] = b - a + m[i + 1];
+    }
+    const double b = cb[6] == 0 ? 0 : cb[6] * in;
+    const double a = ca[6] == 0 ? 0 : ca[6] * out;
+    m[5] = b - a;
+}
+
+template <typename Real, int D>
+__device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint32_t k, uint32_t entry,
+                                              uint32_t slot_base, uint32_t n_d, int& bad) {
+    const uint32_t idx = a.bnode[entry];
+    if (idx == INVALID_NODE) return;
+    const uint32_t dirs = a.btype[entry];  // bit p set: inner node through port p (nx,px,ny,py,nz,pz)
+    const int x = (int)(idx % (uint32_t)a.nx);
+    const uint32_t q = idx / (uint32_t)a.nx;
+    const int y = (int)(q % (uint32_t)a.ny);
+    const int z = (int)(q / (uint32_t)a.ny);
+    if (z < a.z_begin || z >= a.z_end) return;
+
+    const int64_t plane = (int64_t)a.nx * a.ny;
+    const int64_t stride[3] = {1, a.nx, plane};
+    const int pos[3] = {x, y, z};
+    const int lim[3] = {a.nx, a.ny, a.nz};
+    const Real* cur = a.cur;
+    const Real prev = a.prev[idx];
+
+    // 2 * inner pressures, x before y before z (program.cpp:19-87, :268-276)
+    Real sum = 0;
+    bool inner_axis[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
+        inner_axis[ax] = has_n || has_p;
+        if (inner_axis[ax]) {
+            const int c = pos[ax] + (has_p ? 1 : -1);
+            Real p = 0;
+            if (c >= 0 && c < lim[ax]) p = cur[(int64_t)idx + (has_p ? stride[ax] : -stride[ax])];
+            sum += 2 * p;
+        }
+    }
+    // un-doubled in-plane / along-edge neighbours, lower axis first, n before p
+    // (program.cpp:112-143, :178-227); off-grid ends the sum at 0 (statically flagged at create)
+    Real surr = 0;
+    if (D < 3) {
+        bool ok = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!inner_axis[ax]) {
+#pragma unroll
+                for (int s = -1; s <= 1; s += 2) {
+                    const int c = pos[ax] + s;
+                    if (ok) {
+                        if (c < 0 || c >= lim[ax]) {
+                            ok = false;
+                            surr = 0;
+                        } else {
+                            surr += cur[(int64_t)idx + s * stride[ax]];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const Real csw = a.courant_sq * (sum + surr);
+
+    // this node's D filters
+    double m[D][6];
+    const double* cf[D];
+    uint32_t slot[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        slot[i] = slot_base + (uint32_t)i * n_d + k;
+        cf[i] = a.coeffs + (size_t)a.cidx[slot[i]] * 14;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = a.fmem[(size_t)j * a.n_slots + slot[i]];
+    }
+
+    Real facc = 0, cacc = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) facc = (Real)((double)facc + m[i][0] / cf[i][0]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) cacc = (Real)((double)cacc + cf[i][7] / cf[i][0]);
+    const Real fw = a.courant_sq * facc;
+    const Real cw = cacc * a.courant;
+    const Real pw = (cw - 1) * prev;
+    const Real next = (csw + fw + pw) / (1 + cw);
+
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double b0 = cf[i][0], a0 = cf[i][7];
+        const double diff = (a0 * (double)(Real)(prev - next)) / (b0 * (double)a.courant) + (m[i][0] / b0);
+        filter_step_6(-diff, m[i], cf[i], cf[i] + 7);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a.fmem[(size_t)j * a.n_slots + slot[i]] = m[i][j];
+    }
+    bad |= bad_bits(next);
+    a.prev[idx] = next;
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (e < a.n1) {
+        boundary_node<Real, 1>(a, e, e, 0u, a.n1, bad);
+    } else if (e < a.n1 + a.n2) {
+        boundary_node<Real, 2>(a, e - a.n1, e, a.n1, a.n2, bad);
+    } else if (e < a.n1 + a.n2 + a.n3) {
+        boundary_node<Real, 3>(a, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
+    }
+    if (bad) atomicOr(a.flag, bad);
+}
+
+// ---- source injection + receiver gather: the pre/post callbacks, device resident -------------
+// hard source:  current[node] = sample              (preprocessor/hard_source.h:21)
+// soft source:  current[node] = current[node] + s   (preprocessor/soft_source.h:21-24)
+// receivers read the same `current` afterwards      (waveguide.h:121)
+template <typename Real>
+__global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a) {
+    const uint32_t t = threadIdx.x;
+    Real injected = 0;
+    const bool has_source = a.source_kind != 0;
+    if (has_source) {
+        const Real s = (Real)a.signal[a.signal_pos];
+        injected = (a.source_kind == 1) ? s : (Real)(a.cur[a.source_node] + s);
+    }
+    for (uint32_t r = t; r < a.n_recv; r += 64) {
+        const uint64_t node = a.recv[r];
+        Real v = 0;
+        if (node != ~0ull) v = (has_source && node == a.source_node) ? injected : a.cur[node];
+        a.recv_out[r] = v;
+    }
+    __syncthreads();
+    if (t == 0 && has_source) a.cur[a.source_node] = injected;
+}
+
+// ---- set-up (once per wv_create) ---------------------------------------------------------------
+struct NodeRec {                 // condensed_node, cl/structs.h:19-22
+    int32_t boundary_type;
+    uint32_t boundary_index;
+};
+
+struct SetupArgs {
+    const NodeRec* nodes;        // staged chunk: nodes [first, first+count)
+    int64_t first, count;        // chunk = whole x-rows
+    int nx;
+    int cls_pitch;
+    uint8_t* cls;
+    uint32_t* bnode;
+    uint8_t* btype;
+    uint32_t n1, n2, n3;
+    int* status;                 // bit0: invalid boundary type, bit1: boundary_index out of range
+};
+
+__device__ __forceinline__ uint32_t classify(int32_t t, int* dim_out) {
+    *dim_out = 0;
+    if (t == 0) return CLS_NONE;
+    const int bits = __popc((uint32_t)t);
+    if (bits == 1 && (t & 1)) return CLS_INSIDE;
+    if (bits == 1 && (t & 128)) return CLS_REENTRANT;
+    *dim_out = bits;
+    return CLS_BOUNDARY;
+}
+
+// one thread per class byte (4 nodes of one row)
+__global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) {
+    const int64_t rows = a.count / a.nx;
+    const int64_t n_bytes = rows * a.cls_pitch;
+    const int64_t first_row = a.first / a.nx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / a.cls_pitch;
+        const int xb = (int)(i % a.cls_pitch);
+        uint32_t byte = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int x = xb * 4 + j;
+            if (x >= a.nx) break;
+            const int64_t local = row * a.nx + x;
+            const NodeRec rec = a.nodes[local];
+            const int32_t t = rec.boundary_type;
+            int dim;
+            const uint32_t c = classify(t, &dim);
+            byte |= c << (2 * j);
+            if (c == CLS_BOUNDARY) {
+                // valid boundary type: only direction bits, at most one per axis, 1..3 of them
+                const uint32_t dirs = ((uint32_t)t >> 1) & 0x3Fu;
+                const bool only_dirs = ((uint32_t)t & ~0x7Eu) == 0;
+                const bool axes_ok = ((dirs & 3u) != 3u) && (((dirs >> 2) & 3u) != 3u) && (((dirs >> 4) & 3u) != 3u);
+                if (!only_dirs || !axes_ok || dim < 1 || dim > 3) {
+                    atomicOr(a.status, 1);
+                    continue;
+                }
+                const uint32_t n_d = dim == 1 ? a.n1 : (dim == 2 ? a.n2 : a.n3);
+                const uint32_t off = dim == 1 ? 0u : (dim == 2 ? a.n1 : a.n1 + a.n2);
+                const uint32_t k = rec.boundary_index;
+                if (k >= n_d) {
+                    atomicOr(a.status, 2);
+                    continue;
+                }
+                a.bnode[off + k] = (uint32_t)(a.first + local);
+                a.btype[off + k] = (uint8_t)dirs;
+            }
+        }
+        a.cls[(first_row + row) * a.cls_pitch + xb] = (uint8_t)byte;
+    }
+}
+
+// Static part of the reference's per-step checks (program.cpp:198-205, :245): an in-plane
+// neighbour of a boundary node that is id_none / id_inside -> suspicious boundary; a neighbour
+// off the grid -> outside mesh.  Mesh-invariant, so evaluated once and OR-ed into every step.
+struct ValidateArgs {
+    const uint32_t* bnode;
+    const uint8_t* btype;
+    const uint8_t* cls;
+    uint32_t n_entries;
+    int nx, ny, nz, cls_pitch;
+    int* static_flag;
+};
+
+__global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_entries) return;
+    const uint32_t idx = a.bnode[e];
+    if (idx == INVALID_NODE) return;
+    const uint32_t dirs = a.btype[e];
+    const int pos[3] = {(int)(idx % (uint32_t)a.nx), (int)((idx / (uint32_t)a.nx) % (uint32_t)a.ny),
+                        (int)(idx / ((uint32_t)a.nx * (uint32_t)a.ny))};
+    const int lim[3] = {a.nx, a.ny, a.nz};
+    int flag = 0;
+    int dim = __popc(dirs);
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
+        if (has_n || has_p) {
+            const int c = pos[ax] + (has_p ? 1 : -1);
+            if (c < 0 || c >= lim[ax]) flag |= FLAG_OUTSIDE_MESH;
+        } else if (dim < 3) {
+            for (int s = -1; s <= 1; s += 2) {
+                int p[3] = {pos[0], pos[1], pos[2]};
+                p[ax] += s;
+                if (p[ax] < 0 || p[ax] >= lim[ax]) {
+                    flag |= FLAG_OUTSIDE_MESH;
+                    break;  // the reference returns from the surrounding sum here
+                }
+                const uint8_t byte = a.cls[((int64_t)p[2] * a.ny + p[1]) * a.cls_pitch + (p[0] >> 2)];
+                const uint32_t c = (byte >> ((p[0] & 3) * 2)) & 3u;
+                if (c == CLS_NONE || c == CLS_INSIDE) flag |= FLAG_SUSPICIOUS;
+            }
+            if (flag & FLAG_OUTSIDE_MESH) break;
+        }
+    }
+    if (flag) atomicOr(a.static_flag, flag);
+}
+
+// ---- field conversion for wv_read_field / wv_write_field ---------------------------------------
+template <typename Dst, typename Src>
+__global__ void __launch_bounds__(256) convert_kernel(Dst* dst, const Src* src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (Dst)src[i];
+}
+
+// AoS <-> SoA transposition of the boundary filter state (cl/structs.h:38-58)
+struct BoundaryDataArgs {
+    double* fmem;
+    uint32_t* cidx;
+    uint32_t n_slots, slot_base, n_d;
+    int dim;
+    uint64_t* aos;  // boundary_data_array<dim>[n_d] as 7 x 8-byte words per filter
+};
+
+__global__ void __launch_bounds__(256) boundary_data_scatter_kernel(const BoundaryDataArgs a, int to_device) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_d * (uint32_t)a.dim) return;
+    const uint32_t k = t / (uint32_t)a.dim, i = t % (uint32_t)a.dim;
+    const uint32_t slot = a.slot_base + i * a.n_d + k;
+    uint64_t* rec = a.aos + (size_t)t * 7;
+    if (to_device) {
+        for (int j = 0; j < 6; ++j) a.fmem[(size_t)j * a.n_slots + slot] = __longlong_as_double((long long)rec[j]);
+        a.cidx[slot] = (uint32_t)(rec[6] & 0xFFFFFFFFull);
+    } else {
+        for (int j = 0; j < 6; ++j) rec[j] = (uint64_t)__double_as_longlong(a.fmem[(size_t)j * a.n_slots + slot]);
+        rec[6] = (uint64_t)a.cidx[slot];
+    }
+}
+
+}  // namespace wv

@@ -1,0 +1,110 @@
+// device_common.hip.h -- shared device-side definitions for the gfx950 waveguide kernels.
+//
+// Written for CDNA4 only: wave64, DPP wave shifts, 16-byte per-lane global accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wv {
+
+// ---- per-node class map: 2 bits per node, 4 nodes per byte along x ---------------------------
+// Replaces the reference's 8-byte condensed_node in the streaming kernel
+// (src/waveguide/include/waveguide/cl/structs.h:19-22; todo.md:11).
+//   bit0 set  -> node takes the 7-point update (id_inside / id_reentrant, program.cpp:442-445)
+//   value 2   -> boundary node: written by the boundary kernel, never by the streaming kernel
+//   value 0   -> id_none: rewritten to 0 every step (program.cpp:485,529)
+enum : uint32_t { CLS_NONE = 0, CLS_INSIDE = 1, CLS_BOUNDARY = 2, CLS_REENTRANT = 3 };
+
+// error_code bits (cl/structs.h:8-15)
+enum : int { FLAG_INF = 1, FLAG_NAN = 2, FLAG_OUTSIDE_RANGE = 4, FLAG_OUTSIDE_MESH = 8,
+             FLAG_SUSPICIOUS = 16 };
+
+constexpr uint32_t INVALID_NODE = 0xFFFFFFFFu;
+
+template <typename Real>
+struct Vec16;
+template <>
+struct Vec16<double> {
+    typedef double aligned_t __attribute__((ext_vector_type(2)));
+    typedef aligned_t type __attribute__((aligned(8)));
+    static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+    typedef float aligned_t __attribute__((ext_vector_type(4)));
+    typedef aligned_t type __attribute__((aligned(4)));
+    static constexpr int N = 4;
+};
+
+// ---- wave64 neighbour exchange through DPP (no LDS) -------------------------------------------
+// lane i receives `v` of lane i-1; lane 0 keeps `edge`.
+__device__ __forceinline__ float lane_from_below(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v),
+                                                      0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+// lane i receives `v` of lane i+1; lane 63 keeps `edge`.
+__device__ __forceinline__ float lane_from_above(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v),
+                                                      0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_from_below(double edge, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_above(double edge, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename Real>
+__device__ __forceinline__ int bad_bits(Real v) {
+    return (isinf(v) ? FLAG_INF : 0) | (isnan(v) ? FLAG_NAN : 0);
+}
+
+// ---- kernel argument blocks -----------------------------------------------------------------
+template <typename Real>
+struct StreamArgs {
+    Real* prev;          // previous field, overwritten in place with the next field
+    const Real* cur;     // current field (read only)
+    const uint8_t* cls;  // class map, cls_pitch bytes per x-row
+    int* flag;           // error_code word of this step
+    int nx, ny, nz;
+    int cls_pitch;
+    int z_begin, z_end;  // planes this engine updates (ghost planes excluded)
+    int zc;              // planes marched by one workgroup
+    int tiles_x, tiles_y, chunks_z;
+    int total_tiles, tiles_per_xcd;
+};
+
+template <typename Real>
+struct BoundaryArgs {
+    Real* prev;
+    const Real* cur;
+    int* flag;
+    const uint32_t* bnode;   // [n_entries] local node index, INVALID_NODE = unused slot
+    const uint8_t* btype;    // [n_entries] direction bits (boundary_type >> 1)
+    double* fmem;            // [6][n_slots] filter memories, structure-of-arrays
+    const uint32_t* cidx;    // [n_slots] coefficient (surface) index per filter
+    const double* coeffs;    // [n_coeffs][14] = {b[7], a[7]}
+    uint32_t n1, n2, n3;     // entries per dimensionality; entry order: all 1D, all 2D, all 3D
+    uint32_t n_slots;        // n1 + 2 n2 + 3 n3
+    int nx, ny, nz;
+    int z_begin, z_end;
+    Real courant, courant_sq;
+};
+
+template <typename Real>
+struct PrePostArgs {
+    Real* cur;
+    const double* signal;    // device copy of the source signal
+    uint64_t signal_pos;     // sample index for this step
+    uint64_t source_node;
+    int source_kind;         // 0 none, 1 hard, 2 soft
+    const uint64_t* recv;    // [n_recv]
+    Real* recv_out;          // row of this step: [n_recv]
+    uint32_t n_recv;
+};
+
+}  // namespace wv

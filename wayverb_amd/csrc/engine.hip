@@ -1,0 +1,848 @@
+// engine.hip -- host side of the MI355X waveguide engine + the C ABI of include/wayverb_amd.h.
+//
+// Replaces the body of `waveguide::run` (src/waveguide/include/waveguide/waveguide.h:36-126):
+// device buffers, the step loop, the error-flag protocol, and (device-resident) the single-node
+// source / node-gather receivers every caller of `run` uses.
+//
+// There is no CPU path in this library: without a HIP device every entry point fails.
+#include "../../include/wayverb_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "boundary_kernels.hip.h"
+#include "comm.h"
+#include "stream_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define WV_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t err__ = (expr);                                                                \
+        if (err__ != hipSuccess)                                                                  \
+            return fail(WV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));          \
+    } while (0)
+
+constexpr int kRing = 1024;  // steps per device batch (flag words / receiver rows kept on device)
+
+struct StreamPlan {
+    int variant = 0;  // 0 = march, 1 = naive
+    int ry = 4, nw = 4;
+    int zc = 0, tiles_x = 0, tiles_y = 0, chunks_z = 0, total_tiles = 0, tiles_per_xcd = 0;
+    unsigned grid = 0, block = 0;
+};
+
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+struct wv_engine {
+    virtual ~wv_engine() {}
+    virtual int init(const wv_mesh& mesh, const wv_options& opt) = 0;
+    virtual int read_value(int buffer, uint64_t index, double* v) = 0;
+    virtual int write_value(int buffer, uint64_t index, double v) = 0;
+    virtual int read_field(int buffer, void* dst, int elem_size) = 0;
+    virtual int write_field(int buffer, const void* src, int elem_size) = 0;
+    virtual int boundary_data(int dim, wv_boundary_data* host, bool to_device) = 0;
+    virtual int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) = 0;
+    virtual int device_buffer(int buffer, void** p) = 0;
+    virtual int step(int32_t* flag) = 0;
+    virtual int swap() = 0;
+    virtual int set_source(int kind, uint64_t node, const double* signal, uint64_t n) = 0;
+    virtual int set_receivers(const uint64_t* nodes, uint32_t n) = 0;
+    virtual int run(uint64_t n_steps, uint64_t* done, int32_t* flag) = 0;
+    virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
+    virtual int kernel_time(double* mean_ms, uint64_t* launches) = 0;
+    virtual int synchronize() = 0;
+    virtual int comm_init(const void* id, int rank, int nranks) = 0;
+    virtual int comm_destroy() = 0;
+    uint64_t steps_done = 0;
+    bool timing = false;
+};
+
+namespace {
+
+template <typename Real>
+class Engine final : public wv_engine {
+public:
+    ~Engine() override { release(); }
+
+    int init(const wv_mesh& m, const wv_options& opt) override {
+        opt_ = opt;
+        nx_ = m.nx;
+        ny_ = m.ny;
+        nz_ = m.nz;
+        if (nx_ < 1 || ny_ < 1 || nz_ < 1) return fail(WV_E_INVALID_ARGUMENT, "mesh dimensions must be positive");
+        n_nodes_ = (uint64_t)nx_ * ny_ * nz_;
+        if (n_nodes_ >= 0xFFFFFFFEull)
+            return fail(WV_E_INVALID_ARGUMENT,
+                        "more than 2^32-2 nodes in one engine: decompose into z-slabs (32-bit local node indices)");
+        if (!m.nodes || (!m.coefficients && m.num_coefficients))
+            return fail(WV_E_INVALID_ARGUMENT, "mesh arrays missing");
+        z_begin_ = opt.ghost_lo ? 1 : 0;
+        z_end_ = opt.ghost_hi ? nz_ - 1 : nz_;
+        if (z_end_ <= z_begin_) return fail(WV_E_INVALID_ARGUMENT, "slab has no owned planes");
+
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+        if (opt.device >= 0) WV_HIP(hipSetDevice(opt.device));
+        WV_HIP(hipGetDevice(&device_));
+        WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+
+        // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
+        field_bytes_ = n_nodes_ * sizeof(Real);
+        for (int i = 0; i < 2; ++i) {
+            WV_HIP(hipMalloc((void**)&field_[i], field_bytes_ + 256));
+            WV_HIP(hipMemsetAsync(field_[i], 0, field_bytes_ + 256, stream_));
+        }
+        cur_ = 1;  // field_[0] = previous, field_[1] = current
+
+        // ---- class map + compact boundary lists ------------------------------------------------
+        cls_pitch_ = (nx_ + 3) / 4;
+        const uint64_t cls_bytes = (uint64_t)cls_pitch_ * ny_ * nz_;
+        WV_HIP(hipMalloc((void**)&cls_, cls_bytes + 16));
+        n1_ = (uint32_t)m.num_boundary_1;
+        n2_ = (uint32_t)m.num_boundary_2;
+        n3_ = (uint32_t)m.num_boundary_3;
+        if (m.num_boundary_1 + m.num_boundary_2 + m.num_boundary_3 >= 0xFFFFFFFFull)
+            return fail(WV_E_INVALID_ARGUMENT, "too many boundary nodes");
+        n_entries_ = n1_ + n2_ + n3_;
+        n_slots_ = n1_ + 2u * n2_ + 3u * n3_;
+        const size_t ne = std::max<size_t>(n_entries_, 1), ns = std::max<size_t>(n_slots_, 1);
+        WV_HIP(hipMalloc((void**)&bnode_, ne * sizeof(uint32_t)));
+        WV_HIP(hipMemsetAsync(bnode_, 0xFF, ne * sizeof(uint32_t), stream_));
+        WV_HIP(hipMalloc((void**)&btype_, ne));
+        WV_HIP(hipMemsetAsync(btype_, 0, ne, stream_));
+        WV_HIP(hipMalloc((void**)&fmem_, ns * 6 * sizeof(double)));
+        WV_HIP(hipMemsetAsync(fmem_, 0, ns * 6 * sizeof(double), stream_));
+        WV_HIP(hipMalloc((void**)&cidx_, ns * sizeof(uint32_t)));
+        WV_HIP(hipMalloc((void**)&status_, 4 * sizeof(int)));
+        WV_HIP(hipMemsetAsync(status_, 0, 4 * sizeof(int), stream_));
+        static_flag_dev_ = status_ + 1;
+
+        // nodes are staged through a bounded device buffer, whole x-rows at a time
+        {
+            const int64_t rows_total = (int64_t)ny_ * nz_;
+            const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(32 << 20) / nx_);
+            wv::NodeRec* stage = nullptr;
+            WV_HIP(hipMalloc((void**)&stage, (size_t)rows_per_chunk * nx_ * sizeof(wv::NodeRec)));
+            for (int64_t row = 0; row < rows_total; row += rows_per_chunk) {
+                const int64_t rows = std::min(rows_per_chunk, rows_total - row);
+                const int64_t first = row * nx_, cnt = rows * nx_;
+                WV_HIP(hipMemcpyAsync(stage, m.nodes + first, (size_t)cnt * sizeof(wv::NodeRec),
+                                      hipMemcpyHostToDevice, stream_));
+                wv::SetupArgs a{};
+                a.nodes = stage;
+                a.first = first;
+                a.count = cnt;
+                a.nx = nx_;
+                a.cls_pitch = cls_pitch_;
+                a.cls = cls_;
+                a.bnode = bnode_;
+                a.btype = btype_;
+                a.n1 = n1_;
+                a.n2 = n2_;
+                a.n3 = n3_;
+                a.status = status_;
+                const int64_t n_bytes = rows * cls_pitch_;
+                const unsigned grid = (unsigned)std::min<int64_t>((n_bytes + 255) / 256, 65536);
+                hipLaunchKernelGGL(wv::setup_classify_kernel, dim3(grid), dim3(256), 0, stream_, a);
+                WV_HIP(hipGetLastError());
+                WV_HIP(hipStreamSynchronize(stream_));  // `stage` is reused by the next chunk
+            }
+            WV_HIP(hipFree(stage));
+        }
+        if (n_entries_) {
+            wv::ValidateArgs v{};
+            v.bnode = bnode_;
+            v.btype = btype_;
+            v.cls = cls_;
+            v.n_entries = n_entries_;
+            v.nx = nx_;
+            v.ny = ny_;
+            v.nz = nz_;
+            v.cls_pitch = cls_pitch_;
+            v.static_flag = static_flag_dev_;
+            hipLaunchKernelGGL(wv::setup_validate_kernel, dim3((n_entries_ + 255) / 256), dim3(256), 0, stream_, v);
+            WV_HIP(hipGetLastError());
+        }
+        int status_host[4] = {0, 0, 0, 0};
+        WV_HIP(hipMemcpyAsync(status_host, status_, sizeof(status_host), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        if (status_host[0] & 1)
+            return fail(WV_E_INVALID_MESH,
+                        "node with an invalid boundary_type (boundary bits must be 1-3 direction bits on distinct axes)");
+        if (status_host[0] & 2) return fail(WV_E_INVALID_MESH, "boundary_index exceeds the boundary array length");
+        static_flag_ = status_host[1];
+
+        // ---- filter state: coefficient indices per filter slot (get_boundary_data<N>, setup.h:68-85)
+        {
+            std::vector<uint32_t> cidx(ns, 0u);
+            const uint32_t* src[3] = {m.boundary_indices_1, m.boundary_indices_2, m.boundary_indices_3};
+            const uint32_t nd[3] = {n1_, n2_, n3_};
+            uint32_t base = 0;
+            for (int d = 1; d <= 3; ++d) {
+                if (nd[d - 1] && !src[d - 1]) return fail(WV_E_INVALID_ARGUMENT, "boundary index array missing");
+                for (uint32_t k = 0; k < nd[d - 1]; ++k)
+                    for (int i = 0; i < d; ++i) {
+                        const uint32_t c = src[d - 1][(size_t)k * d + i];
+                        if (c >= m.num_coefficients)
+                            return fail(WV_E_INVALID_MESH, "coefficient index exceeds the coefficient array length");
+                        cidx[base + (uint32_t)i * nd[d - 1] + k] = c;
+                    }
+                base += (uint32_t)d * nd[d - 1];
+            }
+            WV_HIP(hipMemcpy(cidx_, cidx.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        n_coeffs_ = m.num_coefficients;
+        WV_HIP(hipMalloc((void**)&coeffs_, std::max<size_t>(n_coeffs_, 1) * sizeof(wv_coefficients_canonical)));
+        if (n_coeffs_)
+            WV_HIP(hipMemcpy(coeffs_, m.coefficients, n_coeffs_ * sizeof(wv_coefficients_canonical),
+                             hipMemcpyHostToDevice));
+
+        // ---- per-step rings ---------------------------------------------------------------------
+        WV_HIP(hipMalloc((void**)&flags_, kRing * sizeof(int)));
+        WV_HIP(hipHostMalloc((void**)&flags_host_, kRing * sizeof(int), hipHostMallocDefault));
+        WV_HIP(hipMalloc((void**)&scratch_, 64));
+
+        // courant numbers in the pressure type (program.cpp:12-13)
+        courant_ = (Real)1 / (Real)std::sqrt((Real)3);
+        courant_sq_ = (Real)1 / (Real)3;
+
+        plan_stream();
+        const int n_ev = 2 * kRing;
+        events_.resize(n_ev);
+        for (auto& e : events_) WV_HIP(hipEventCreate(&e));
+        return WV_OK;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    void plan_stream() {
+        StreamPlan& p = plan_;
+        constexpr int VX = 16 / (int)sizeof(Real);
+        constexpr int WX = 64 * VX;
+        p.variant = opt_.stream_variant == 1 ? 1 : 0;
+        p.variant = env_int("WV_STREAM_VARIANT", p.variant);
+        p.ry = env_int("WV_STREAM_RY", 4);
+        p.nw = env_int("WV_STREAM_NW", 4);
+        if (p.ry != 2 && p.ry != 4 && p.ry != 8) p.ry = 4;
+        if (p.nw != 1 && p.nw != 2 && p.nw != 4) p.nw = 4;
+        p.tiles_x = (nx_ + WX - 1) / WX;
+        p.tiles_y = (ny_ + p.ry * p.nw - 1) / (p.ry * p.nw);
+        const int owned = z_end_ - z_begin_;
+        // enough workgroups to fill 256 CUs a few times over; otherwise march the whole column
+        const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nw;
+        int64_t want = env_int("WV_STREAM_ZCHUNKS", 0);
+        if (want <= 0) want = (8192 + wave_tiles - 1) / wave_tiles;
+        want = std::max<int64_t>(1, std::min<int64_t>(want, owned));
+        p.zc = (int)((owned + want - 1) / want);
+        p.chunks_z = (owned + p.zc - 1) / p.zc;
+        p.total_tiles = p.tiles_x * p.tiles_y * p.chunks_z;
+        p.tiles_per_xcd = (p.total_tiles + 7) / 8;
+        p.grid = (unsigned)p.tiles_per_xcd * 8u;
+        p.block = 64u * (unsigned)p.nw;
+        if (p.variant == 1) {
+            p.block = 256;
+            p.grid = (unsigned)std::min<uint64_t>((n_nodes_ + 255) / 256, 256ull * 64);
+        }
+    }
+
+    template <int RY, int NW>
+    void launch_march(const wv::StreamArgs<Real>& a, unsigned grid) {
+        hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NW>), dim3(grid), dim3(plan_.block), 0, stream_, a);
+    }
+    template <int RY>
+    void launch_march_nw(const wv::StreamArgs<Real>& a, unsigned grid) {
+        switch (plan_.nw) {
+            case 1: launch_march<RY, 1>(a, grid); break;
+            case 2: launch_march<RY, 2>(a, grid); break;
+            default: launch_march<RY, 4>(a, grid); break;
+        }
+    }
+
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed) {
+        if (z0 >= z1) return WV_OK;
+        constexpr int VX = 16 / (int)sizeof(Real);
+        constexpr int WX = 64 * VX;
+        wv::StreamArgs<Real> a{};
+        a.prev = prev;
+        a.cur = cur;
+        a.cls = cls_;
+        a.flag = flag;
+        a.nx = nx_;
+        a.ny = ny_;
+        a.nz = nz_;
+        a.cls_pitch = cls_pitch_;
+        a.z_begin = z0;
+        a.z_end = z1;
+        // z-chunking of this launch: the plan's chunk length, clipped to the range
+        a.zc = std::min(plan_.zc, z1 - z0);
+        a.tiles_x = (nx_ + WX - 1) / WX;
+        a.tiles_y = plan_.tiles_y;
+        a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
+        a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
+        a.tiles_per_xcd = (a.total_tiles + 7) / 8;
+        const unsigned grid = plan_.variant == 1 ? plan_.grid : (unsigned)a.tiles_per_xcd * 8u;
+        timed = timed && timing && ev_used_ + 2 <= (int)events_.size();
+        if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+        if (plan_.variant == 1) {
+            hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
+        } else {
+            switch (plan_.ry) {
+                case 2: launch_march_nw<2>(a, grid); break;
+                case 8: launch_march_nw<8>(a, grid); break;
+                default: launch_march_nw<4>(a, grid); break;
+            }
+        }
+        if (timed) {
+            WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
+            ev_used_ += 2;
+        }
+        return WV_OK;
+    }
+
+    int launch_boundary(Real* prev, const Real* cur, int* flag) {
+        if (!n_entries_) return WV_OK;
+        wv::BoundaryArgs<Real> b{};
+        b.prev = prev;
+        b.cur = cur;
+        b.flag = flag;
+        b.bnode = bnode_;
+        b.btype = btype_;
+        b.fmem = fmem_;
+        b.cidx = cidx_;
+        b.coeffs = coeffs_;
+        b.n1 = n1_;
+        b.n2 = n2_;
+        b.n3 = n3_;
+        b.n_slots = n_slots_;
+        b.nx = nx_;
+        b.ny = ny_;
+        b.nz = nz_;
+        b.z_begin = z_begin_;
+        b.z_end = z_end_;
+        b.courant = courant_;
+        b.courant_sq = courant_sq_;
+        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n_entries_ + 255) / 256), dim3(256), 0, stream_, b);
+        return WV_OK;
+    }
+
+    // One loop body: [pre/post on device] + pressure update + boundary update; flag -> flags_[slot]
+    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) {
+        Real* prev = field_[cur_ ^ 1];
+        Real* cur = field_[cur_];
+        int* flag = flags_ + slot;
+        int rc;
+        // the flag word starts from the mesh-static bits (see setup_validate_kernel)
+        if (static_flag_ == 0) {
+            WV_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream_));
+        } else {
+            WV_HIP(hipMemcpyAsync(flag, static_flag_dev_, sizeof(int), hipMemcpyDeviceToDevice, stream_));
+        }
+        std::string cerr;
+        // ghost planes of `cur` come from the exchange issued at the end of the previous step
+        if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+        if (with_pre_post && (n_recv_ || source_live)) {
+            wv::PrePostArgs<Real> pp{};
+            pp.cur = cur;
+            pp.signal = signal_;
+            pp.signal_pos = signal_pos;
+            pp.source_node = source_node_;
+            pp.source_kind = source_live ? source_kind_ : 0;
+            pp.recv = recv_nodes_;
+            pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
+            pp.n_recv = n_recv_;
+            hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
+        if (comm_) {
+            // slab faces first, so that their exchange overlaps the interior update
+            const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
+            const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+            if ((rc = launch_stream(prev, cur, flag, z_begin_, zi0, false))) return rc;
+            if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag))) return rc;
+            WV_HIP(hipGetLastError());
+            if (!comm_->exchange_faces(stream_, prev, sizeof(Real), nx_, ny_, nz_, &cerr)) return fail(WV_E_COMM, cerr);
+            if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
+        } else {
+            if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag))) return rc;
+        }
+        WV_HIP(hipGetLastError());
+        return WV_OK;
+    }
+
+    int drain_timing() {
+        for (int i = 0; i + 1 < ev_used_; i += 2) {
+            float ms = 0;
+            WV_HIP(hipEventElapsedTime(&ms, events_[i], events_[i + 1]));
+            time_ms_ += ms;
+            ++time_n_;
+        }
+        ev_used_ = 0;
+        return WV_OK;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    int step(int32_t* flag) override {
+        int rc = enqueue_step(0, false, 0, false);
+        if (rc) return rc;
+        WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        if ((rc = drain_timing())) return rc;
+        if (flag) *flag = flags_host_[0];
+        return WV_OK;
+    }
+
+    int swap() override {
+        cur_ ^= 1;
+        ++steps_done;
+        return WV_OK;
+    }
+
+    int run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) override {
+        uint64_t completed = 0;
+        int32_t flag = 0;
+        const uint64_t interval = opt_.flag_interval > 0 ? (uint64_t)opt_.flag_interval : (uint64_t)kRing;
+        while (completed < n_steps && flag == 0) {
+            uint64_t batch = std::min<uint64_t>(std::min<uint64_t>(interval, kRing), n_steps - completed);
+            // an exhausted source ends the run (hard_source.h:18-20 returns false)
+            if (source_kind_ != WV_SOURCE_NONE) {
+                const uint64_t left = signal_len_ - std::min(signal_len_, signal_pos_);
+                if (left == 0) break;
+                batch = std::min(batch, left);
+            }
+            for (uint64_t i = 0; i < batch; ++i) {
+                int rc = enqueue_step((int)i, true, signal_pos_ + i, source_kind_ != WV_SOURCE_NONE);
+                if (rc) return rc;
+                cur_ ^= 1;
+            }
+            WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            if (n_recv_) {
+                recv_stage_.resize((size_t)batch * n_recv_);
+                WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real),
+                                      hipMemcpyDeviceToHost, stream_));
+            }
+            WV_HIP(hipStreamSynchronize(stream_));
+            int rc = drain_timing();
+            if (rc) return rc;
+            uint64_t good = batch;
+            for (uint64_t i = 0; i < batch; ++i) {
+                if (flags_host_[i]) {
+                    good = i;
+                    flag = flags_host_[i];
+                    break;
+                }
+            }
+            if (n_recv_) {
+                for (size_t i = 0; i < (size_t)good * n_recv_; ++i) recv_log_.push_back((double)recv_stage_[i]);
+            }
+            completed += good;
+            steps_done += good;
+            signal_pos_ += good;
+            if (flag && good < batch) {
+                // fields have advanced past the failing step: like the reference after its throw,
+                // the state is no longer meaningful; keep buffer roles consistent with `good` swaps
+                if ((batch - good) & 1) cur_ ^= 1;
+            }
+        }
+        if (done) *done = completed;
+        if (flag_out) *flag_out = flag;
+        return WV_OK;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    int set_source(int kind, uint64_t node, const double* signal, uint64_t n) override {
+        if (kind != WV_SOURCE_NONE && kind != WV_SOURCE_HARD && kind != WV_SOURCE_SOFT)
+            return fail(WV_E_INVALID_ARGUMENT, "unknown source kind");
+        if (signal_) {
+            WV_HIP(hipFree(signal_));
+            signal_ = nullptr;
+        }
+        source_kind_ = kind;
+        signal_len_ = 0;
+        signal_pos_ = 0;
+        if (kind == WV_SOURCE_NONE) return WV_OK;
+        if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
+        if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
+        source_node_ = node;
+        signal_len_ = n;
+        WV_HIP(hipMalloc((void**)&signal_, std::max<uint64_t>(n, 1) * sizeof(double)));
+        if (n) WV_HIP(hipMemcpy(signal_, signal, n * sizeof(double), hipMemcpyHostToDevice));
+        return WV_OK;
+    }
+
+    int set_receivers(const uint64_t* nodes, uint32_t n) override {
+        if (recv_nodes_) {
+            WV_HIP(hipFree(recv_nodes_));
+            recv_nodes_ = nullptr;
+        }
+        if (recv_out_) {
+            WV_HIP(hipFree(recv_out_));
+            recv_out_ = nullptr;
+        }
+        recv_log_.clear();
+        recv_first_step_ = steps_done;
+        n_recv_ = n;
+        if (!n) return WV_OK;
+        for (uint32_t i = 0; i < n; ++i)
+            if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
+                return fail(WV_E_INVALID_ARGUMENT, "receiver node outside the mesh");
+        WV_HIP(hipMalloc((void**)&recv_nodes_, n * sizeof(uint64_t)));
+        WV_HIP(hipMemcpy(recv_nodes_, nodes, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        WV_HIP(hipMalloc((void**)&recv_out_, (size_t)kRing * n * sizeof(Real)));
+        return WV_OK;
+    }
+
+    int fetch_receivers(uint64_t first, uint64_t n, double* dst) override {
+        if (first < recv_first_step_) return fail(WV_E_INVALID_ARGUMENT, "steps before wv_set_receivers are not recorded");
+        const uint64_t off = first - recv_first_step_;
+        if ((off + n) * n_recv_ > recv_log_.size()) return fail(WV_E_INVALID_ARGUMENT, "steps not recorded yet");
+        std::memcpy(dst, recv_log_.data() + off * n_recv_, (size_t)n * n_recv_ * sizeof(double));
+        return WV_OK;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[cur_ ^ 1]; }
+
+    int read_value(int buffer_id, uint64_t index, double* v) override {
+        if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
+        Real tmp;
+        WV_HIP(hipMemcpyAsync(&tmp, buffer(buffer_id) + index, sizeof(Real), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        *v = (double)tmp;
+        return WV_OK;
+    }
+    int write_value(int buffer_id, uint64_t index, double v) override {
+        if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
+        const Real tmp = (Real)v;
+        WV_HIP(hipMemcpyAsync(buffer(buffer_id) + index, &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        return WV_OK;
+    }
+
+    template <typename Other>
+    int copy_converted(void* dst, const void* src, bool to_device) {
+        // stage through a device buffer of the foreign element type
+        Other* tmp = nullptr;
+        const int64_t chunk = std::min<int64_t>((int64_t)n_nodes_, 64ll << 20);
+        WV_HIP(hipMalloc((void**)&tmp, (size_t)chunk * sizeof(Other)));
+        for (int64_t off = 0; off < (int64_t)n_nodes_; off += chunk) {
+            const int64_t n = std::min<int64_t>(chunk, (int64_t)n_nodes_ - off);
+            const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+            if (to_device) {
+                WV_HIP(hipMemcpyAsync(tmp, (const Other*)src + off, (size_t)n * sizeof(Other), hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL((wv::convert_kernel<Real, Other>), dim3(grid), dim3(256), 0, stream_,
+                                   (Real*)dst + off, (const Other*)tmp, n);
+            } else {
+                hipLaunchKernelGGL((wv::convert_kernel<Other, Real>), dim3(grid), dim3(256), 0, stream_, tmp,
+                                   (const Real*)src + off, n);
+                WV_HIP(hipMemcpyAsync((Other*)dst + off, tmp, (size_t)n * sizeof(Other), hipMemcpyDeviceToHost, stream_));
+            }
+            WV_HIP(hipStreamSynchronize(stream_));
+        }
+        WV_HIP(hipFree(tmp));
+        return WV_OK;
+    }
+
+    int read_field(int buffer_id, void* dst, int elem_size) override {
+        if (elem_size == (int)sizeof(Real)) {
+            WV_HIP(hipMemcpyAsync(dst, buffer(buffer_id), field_bytes_, hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            return WV_OK;
+        }
+        if (elem_size == 4) return copy_converted<float>(dst, buffer(buffer_id), false);
+        if (elem_size == 8) return copy_converted<double>(dst, buffer(buffer_id), false);
+        return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
+    }
+    int write_field(int buffer_id, const void* src, int elem_size) override {
+        if (elem_size == (int)sizeof(Real)) {
+            WV_HIP(hipMemcpyAsync(buffer(buffer_id), src, field_bytes_, hipMemcpyHostToDevice, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            return WV_OK;
+        }
+        if (elem_size == 4) return copy_converted<float>(buffer(buffer_id), src, true);
+        if (elem_size == 8) return copy_converted<double>(buffer(buffer_id), src, true);
+        return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
+    }
+
+    int boundary_data(int dim, wv_boundary_data* host, bool to_device) override {
+        if (dim < 1 || dim > 3) return fail(WV_E_INVALID_ARGUMENT, "dimensionality must be 1, 2 or 3");
+        const uint32_t nd = dim == 1 ? n1_ : (dim == 2 ? n2_ : n3_);
+        if (!nd) return WV_OK;
+        const uint32_t base = dim == 1 ? 0u : (dim == 2 ? n1_ : n1_ + 2u * n2_);
+        const size_t bytes = (size_t)nd * dim * sizeof(wv_boundary_data);
+        uint64_t* aos = nullptr;
+        WV_HIP(hipMalloc((void**)&aos, bytes));
+        if (to_device) WV_HIP(hipMemcpyAsync(aos, host, bytes, hipMemcpyHostToDevice, stream_));
+        wv::BoundaryDataArgs a{};
+        a.fmem = fmem_;
+        a.cidx = cidx_;
+        a.n_slots = n_slots_;
+        a.slot_base = base;
+        a.n_d = nd;
+        a.dim = dim;
+        a.aos = aos;
+        const uint32_t n = nd * (uint32_t)dim;
+        hipLaunchKernelGGL(wv::boundary_data_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream_, a,
+                           to_device ? 1 : 0);
+        if (!to_device) WV_HIP(hipMemcpyAsync(host, aos, bytes, hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        WV_HIP(hipFree(aos));
+        return WV_OK;
+    }
+
+    int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) override {
+        if (n != n_coeffs_)
+            return fail(WV_E_INVALID_ARGUMENT,
+                        "Size of new coefficients vector must be equal to the existing one");  // setup.cpp:43-47
+        if (n) {
+            WV_HIP(hipMemcpyAsync(coeffs_, c, n * sizeof(wv_coefficients_canonical), hipMemcpyHostToDevice, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+        }
+        return WV_OK;
+    }
+
+    int device_buffer(int buffer_id, void** p) override {
+        *p = buffer(buffer_id);
+        return WV_OK;
+    }
+
+    int kernel_time(double* mean_ms, uint64_t* launches) override {
+        if (mean_ms) *mean_ms = time_n_ ? time_ms_ / (double)time_n_ : 0.0;
+        if (launches) *launches = time_n_;
+        time_ms_ = 0;
+        time_n_ = 0;
+        return WV_OK;
+    }
+
+    int synchronize() override {
+        WV_HIP(hipStreamSynchronize(stream_));
+        WV_HIP(hipStreamSynchronize(comm_stream_));
+        return WV_OK;
+    }
+
+    int comm_init(const void* id, int rank, int nranks) override {
+        if (comm_) return fail(WV_E_STATE, "communicator already initialised");
+        std::unique_ptr<wv::SlabComm> c(new wv::SlabComm());
+        std::string err;
+        if (!c->init(id, rank, nranks, device_, comm_stream_, opt_.ghost_lo != 0, opt_.ghost_hi != 0, &err))
+            return fail(WV_E_COMM, err);
+        comm_ = std::move(c);
+        return WV_OK;
+    }
+    int comm_destroy() override {
+        comm_.reset();
+        return WV_OK;
+    }
+
+private:
+    void release() {
+        comm_.reset();
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        for (auto& e : events_) (void)hipEventDestroy(e);
+        events_.clear();
+        for (int i = 0; i < 2; ++i)
+            if (field_[i]) (void)hipFree(field_[i]);
+        void* ptrs[] = {cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (flags_host_) (void)hipHostFree(flags_host_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+        if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+    }
+
+    wv_options opt_{};
+    int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = 0;
+    uint64_t n_nodes_ = 0, field_bytes_ = 0;
+    Real* field_[2] = {nullptr, nullptr};
+    int cur_ = 1;
+    uint8_t* cls_ = nullptr;
+    int cls_pitch_ = 0;
+    uint32_t n1_ = 0, n2_ = 0, n3_ = 0, n_entries_ = 0, n_slots_ = 0, n_coeffs_ = 0;
+    uint32_t* bnode_ = nullptr;
+    uint8_t* btype_ = nullptr;
+    double* fmem_ = nullptr;
+    uint32_t* cidx_ = nullptr;
+    int* status_ = nullptr;
+    int* static_flag_dev_ = nullptr;
+    int static_flag_ = 0;
+    double* coeffs_ = nullptr;
+    int* flags_ = nullptr;
+    int* flags_host_ = nullptr;
+    void* scratch_ = nullptr;
+    Real courant_ = 0, courant_sq_ = 0;
+    hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
+    StreamPlan plan_;
+    std::vector<hipEvent_t> events_;
+    int ev_used_ = 0;
+    double time_ms_ = 0;
+    uint64_t time_n_ = 0;
+    // source / receivers
+    int source_kind_ = WV_SOURCE_NONE;
+    uint64_t source_node_ = 0, signal_len_ = 0, signal_pos_ = 0;
+    double* signal_ = nullptr;
+    uint64_t* recv_nodes_ = nullptr;
+    Real* recv_out_ = nullptr;
+    uint32_t n_recv_ = 0;
+    uint64_t recv_first_step_ = 0;
+    std::vector<Real> recv_stage_;
+    std::vector<double> recv_log_;
+    std::unique_ptr<wv::SlabComm> comm_;
+};
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* wv_last_error(void) { return g_last_error.c_str(); }
+
+void wv_default_options(wv_options* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (int32_t)sizeof(wv_options);
+    o->precision = WV_PRECISION_F64;
+    o->device = -1;
+    o->flag_interval = 0;
+}
+
+int wv_create(const wv_mesh* mesh, const wv_options* options, wv_engine** out) {
+    if (!mesh || !out) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    wv_options opt;
+    wv_default_options(&opt);
+    if (options) {
+        const size_t n = std::min<size_t>(sizeof(opt), options->struct_size > 0 ? (size_t)options->struct_size : sizeof(opt));
+        std::memcpy(&opt, options, n);
+        opt.struct_size = (int32_t)sizeof(opt);
+    }
+    std::unique_ptr<wv_engine> e;
+    if (opt.precision == WV_PRECISION_F32) {
+        e.reset(new Engine<float>());
+    } else if (opt.precision == WV_PRECISION_F64) {
+        e.reset(new Engine<double>());
+    } else {
+        return fail(WV_E_INVALID_ARGUMENT, "unknown precision");
+    }
+    const int rc = e->init(*mesh, opt);
+    if (rc != WV_OK) return rc;
+    *out = e.release();
+    return WV_OK;
+}
+
+void wv_destroy(wv_engine* e) { delete e; }
+
+#define WV_NEED(e) \
+    if (!(e)) return fail(WV_E_INVALID_ARGUMENT, "null engine")
+
+int wv_read_value(wv_engine* e, int buffer, uint64_t index, double* value) {
+    WV_NEED(e);
+    return e->read_value(buffer, index, value);
+}
+int wv_write_value(wv_engine* e, int buffer, uint64_t index, double value) {
+    WV_NEED(e);
+    return e->write_value(buffer, index, value);
+}
+int wv_read_field(wv_engine* e, int buffer, void* dst, int elem_size) {
+    WV_NEED(e);
+    return e->read_field(buffer, dst, elem_size);
+}
+int wv_write_field(wv_engine* e, int buffer, const void* src, int elem_size) {
+    WV_NEED(e);
+    return e->write_field(buffer, src, elem_size);
+}
+int wv_read_boundary_data(wv_engine* e, int dim, wv_boundary_data* dst) {
+    WV_NEED(e);
+    return e->boundary_data(dim, dst, false);
+}
+int wv_write_boundary_data(wv_engine* e, int dim, const wv_boundary_data* src) {
+    WV_NEED(e);
+    return e->boundary_data(dim, const_cast<wv_boundary_data*>(src), true);
+}
+int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32_t n) {
+    WV_NEED(e);
+    return e->set_coefficients(c, n);
+}
+int wv_device_buffer(wv_engine* e, int buffer, void** p) {
+    WV_NEED(e);
+    return e->device_buffer(buffer, p);
+}
+int wv_step(wv_engine* e, int32_t* flag) {
+    WV_NEED(e);
+    return e->step(flag);
+}
+int wv_swap(wv_engine* e) {
+    WV_NEED(e);
+    return e->swap();
+}
+int wv_set_source(wv_engine* e, int kind, uint64_t node, const double* signal, uint64_t n) {
+    WV_NEED(e);
+    return e->set_source(kind, node, signal, n);
+}
+int wv_set_receivers(wv_engine* e, const uint64_t* nodes, uint32_t n) {
+    WV_NEED(e);
+    return e->set_receivers(nodes, n);
+}
+int wv_run(wv_engine* e, uint64_t n_steps, uint64_t* done, int32_t* flag) {
+    WV_NEED(e);
+    return e->run(n_steps, done, flag);
+}
+int wv_fetch_receivers(wv_engine* e, uint64_t first, uint64_t n, double* dst) {
+    WV_NEED(e);
+    return e->fetch_receivers(first, n, dst);
+}
+int wv_step_count(wv_engine* e, uint64_t* steps) {
+    WV_NEED(e);
+    *steps = e->steps_done;
+    return WV_OK;
+}
+int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches) {
+    WV_NEED(e);
+    return e->kernel_time(mean_ms, launches);
+}
+int wv_enable_kernel_timing(wv_engine* e, int enable) {
+    WV_NEED(e);
+    e->timing = enable != 0;
+    return WV_OK;
+}
+int wv_synchronize(wv_engine* e) {
+    WV_NEED(e);
+    return e->synchronize();
+}
+int wv_comm_unique_id(void* id_bytes) {
+    std::string err;
+    if (!wv::SlabComm::unique_id(id_bytes, &err)) return fail(WV_E_COMM, err);
+    return WV_OK;
+}
+int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks) {
+    WV_NEED(e);
+    return e->comm_init(id_bytes, rank, nranks);
+}
+int wv_comm_destroy(wv_engine* e) {
+    WV_NEED(e);
+    return e->comm_destroy();
+}
+
+}  // extern "C"

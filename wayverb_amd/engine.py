@@ -1,0 +1,318 @@
+"""ctypes binding of the C ABI (include/wayverb_amd.h) + a Python mirror of `waveguide::run`.
+
+The library is the product; this file is plumbing.  There is no fallback: if
+libwayverb_amd.so is missing or no HIP device is visible, constructing an Engine raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import mesh as M
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwayverb_amd.so")
+
+WV_OK = 0
+PRECISION_F32 = 0
+PRECISION_F64 = 1
+BUF_CURRENT = 0
+BUF_PREVIOUS = 1
+SOURCE_NONE, SOURCE_HARD, SOURCE_SOFT = 0, 1, 2
+NO_NODE = 0xFFFFFFFFFFFFFFFF
+UNIQUE_ID_BYTES = 128
+
+EXPORTS = [
+    "wv_create", "wv_destroy", "wv_last_error", "wv_default_options", "wv_read_value", "wv_write_value",
+    "wv_read_field", "wv_write_field", "wv_read_boundary_data", "wv_write_boundary_data",
+    "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
+    "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
+    "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
+    "wv_comm_destroy", "wv_make_box_nodes",
+]
+
+
+class WvMesh(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("nodes", C.c_void_p), ("coefficients", C.c_void_p), ("num_coefficients", C.c_uint32),
+                ("boundary_indices_1", C.c_void_p), ("boundary_indices_2", C.c_void_p),
+                ("boundary_indices_3", C.c_void_p),
+                ("num_boundary_1", C.c_uint64), ("num_boundary_2", C.c_uint64), ("num_boundary_3", C.c_uint64)]
+
+
+class WvOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
+                ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
+                ("stream_variant", C.c_int32), ("reserved_", C.c_int32 * 9)]
+
+
+class WaveguideError(RuntimeError):
+    pass
+
+
+class ValueIsInf(WaveguideError):
+    """core::exceptions::value_is_inf (src/core/include/core/exceptions.h:28-30)"""
+
+
+class ValueIsNan(WaveguideError):
+    """core::exceptions::value_is_nan (exceptions.h:24-26)"""
+
+
+_lib = None
+
+
+def load_library():
+    """Load libwayverb_amd.so.  If torch is installed it is imported first so that both share
+    one HIP runtime (torch bundles its own libamdhip64 with the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise WaveguideError(
+            "%s not built: run `python -m wayverb_amd.build` (there is no CPU fallback)" % _LIB_PATH)
+    if os.environ.get("WV_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.wv_last_error.restype = C.c_char_p
+    lib.wv_create.argtypes = [C.POINTER(WvMesh), C.POINTER(WvOptions), C.POINTER(C.c_void_p)]
+    lib.wv_destroy.argtypes = [C.c_void_p]
+    lib.wv_destroy.restype = None
+    lib.wv_default_options.argtypes = [C.POINTER(WvOptions)]
+    lib.wv_default_options.restype = None
+    lib.wv_read_value.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_double)]
+    lib.wv_write_value.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_double]
+    lib.wv_read_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.wv_write_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.wv_read_boundary_data.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.wv_write_boundary_data.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.wv_set_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.wv_device_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.wv_step.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.wv_swap.argtypes = [C.c_void_p]
+    lib.wv_set_source.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]
+    lib.wv_set_receivers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.wv_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.wv_fetch_receivers.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.wv_step_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.wv_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.wv_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.wv_synchronize.argtypes = [C.c_void_p]
+    lib.wv_comm_unique_id.argtypes = [C.c_void_p]
+    lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.wv_comm_destroy.argtypes = [C.c_void_p]
+    lib.wv_make_box_nodes.argtypes = [C.c_int32] * 7 + [C.c_void_p, C.POINTER(C.c_uint64)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != WV_OK:
+        raise WaveguideError("wayverb_amd error %d: %s" % (rc, load_library().wv_last_error().decode()))
+
+
+def raise_for_flag(flag):
+    """The flag -> exception mapping of waveguide.h:102-118."""
+    if flag & M.ERR_INF:
+        raise ValueIsInf("Pressure value is inf, check filter coefficients.")
+    if flag & M.ERR_NAN:
+        raise ValueIsNan("Pressure value is nan, check filter coefficients.")
+    if flag & M.ERR_OUTSIDE_MESH:
+        raise WaveguideError("Tried to read non-existant node.")
+    if flag & M.ERR_SUSPICIOUS_BOUNDARY:
+        raise WaveguideError("Suspicious boundary read.")
+
+
+def make_box_nodes(nx, ny, nz_global, z_begin=0, z_count=None, number_from=None, number_to=None):
+    """wv_make_box_nodes -> (nodes[z_count*ny*nx], (n1, n2, n3))."""
+    lib = load_library()
+    if z_count is None:
+        z_count = nz_global - z_begin
+    if number_from is None:
+        number_from = z_begin
+    if number_to is None:
+        number_to = z_begin + z_count
+    nodes = np.empty(z_count * ny * nx, dtype=M.condensed_node_dtype)
+    counts = (C.c_uint64 * 3)()
+    _check(lib.wv_make_box_nodes(nx, ny, nz_global, z_begin, z_count, number_from, number_to,
+                                 nodes.ctypes.data_as(C.c_void_p), counts))
+    return nodes, tuple(int(c) for c in counts)
+
+
+class Engine:
+    """One `run` worth of device state: the buffers of waveguide.h:43-76."""
+
+    def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
+                 flag_interval=0, stream_variant=0):
+        self.lib = load_library()
+        self.mesh = mesh
+        self.precision = precision
+        self.dtype = np.float32 if precision == "f32" else np.float64
+        nx, ny, nz = mesh.dims
+        wm = WvMesh()
+        wm.nx, wm.ny, wm.nz = nx, ny, nz
+        wm.nodes = mesh.nodes.ctypes.data
+        wm.coefficients = mesh.coefficients.ctypes.data
+        wm.num_coefficients = mesh.coefficients.shape[0]
+        for d in range(3):
+            setattr(wm, "boundary_indices_%d" % (d + 1), mesh.bidx[d].ctypes.data if mesh.bidx[d].size else None)
+            setattr(wm, "num_boundary_%d" % (d + 1), mesh.bidx[d].shape[0])
+        opt = WvOptions()
+        self.lib.wv_default_options(C.byref(opt))
+        opt.precision = PRECISION_F32 if precision == "f32" else PRECISION_F64
+        opt.device = device
+        opt.ghost_lo = int(ghost_lo)
+        opt.ghost_hi = int(ghost_hi)
+        opt.flag_interval = flag_interval
+        opt.stream_variant = stream_variant
+        handle = C.c_void_p()
+        _check(self.lib.wv_create(C.byref(wm), C.byref(opt), C.byref(handle)))
+        self.h = handle
+        self.n_recv = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- buffer helpers (core::read_value / write_value / read_from_buffer) -----------------
+    def read_value(self, index, buffer=BUF_CURRENT):
+        v = C.c_double()
+        _check(self.lib.wv_read_value(self.h, buffer, index, C.byref(v)))
+        return v.value
+
+    def write_value(self, index, value, buffer=BUF_CURRENT):
+        _check(self.lib.wv_write_value(self.h, buffer, index, float(value)))
+
+    def read_field(self, buffer=BUF_CURRENT, dtype=None):
+        dtype = np.dtype(dtype or self.dtype)
+        out = np.empty(self.mesh.num_nodes, dtype=dtype)
+        _check(self.lib.wv_read_field(self.h, buffer, out.ctypes.data_as(C.c_void_p), dtype.itemsize))
+        return out
+
+    def write_field(self, values, buffer=BUF_CURRENT):
+        values = np.ascontiguousarray(values)
+        assert values.shape == (self.mesh.num_nodes,) and values.dtype in (np.float32, np.float64)
+        _check(self.lib.wv_write_field(self.h, buffer, values.ctypes.data_as(C.c_void_p), values.dtype.itemsize))
+
+    def read_boundary_data(self, d):
+        out = np.zeros((self.mesh.bidx[d - 1].shape[0], d), dtype=M.boundary_data_dtype)
+        if out.size:
+            _check(self.lib.wv_read_boundary_data(self.h, d, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def write_boundary_data(self, d, data):
+        data = np.ascontiguousarray(data, dtype=M.boundary_data_dtype)
+        if data.size:
+            _check(self.lib.wv_write_boundary_data(self.h, d, data.ctypes.data_as(C.c_void_p)))
+
+    def set_coefficients(self, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=M.coefficients_dtype)
+        _check(self.lib.wv_set_coefficients(self.h, coeffs.ctypes.data_as(C.c_void_p), coeffs.shape[0]))
+
+    def device_buffer(self, buffer=BUF_CURRENT):
+        p = C.c_void_p()
+        _check(self.lib.wv_device_buffer(self.h, buffer, C.byref(p)))
+        return p.value
+
+    # ---- stepping ---------------------------------------------------------------------------
+    def step(self):
+        flag = C.c_int32()
+        _check(self.lib.wv_step(self.h, C.byref(flag)))
+        return flag.value
+
+    def swap(self):
+        _check(self.lib.wv_swap(self.h))
+
+    def set_source(self, kind, node=0, signal=None):
+        if kind == SOURCE_NONE:
+            _check(self.lib.wv_set_source(self.h, kind, 0, None, 0))
+            return
+        sig = np.ascontiguousarray(signal, dtype=np.float64)
+        _check(self.lib.wv_set_source(self.h, kind, int(node), sig.ctypes.data_as(C.c_void_p), sig.shape[0]))
+
+    def set_receivers(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        self.n_recv = nodes.shape[0]
+        _check(self.lib.wv_set_receivers(self.h, nodes.ctypes.data_as(C.c_void_p) if self.n_recv else None,
+                                         self.n_recv))
+
+    def run_steps(self, n_steps):
+        """wv_run: returns (steps_done, flag)."""
+        done = C.c_uint64()
+        flag = C.c_int32()
+        _check(self.lib.wv_run(self.h, int(n_steps), C.byref(done), C.byref(flag)))
+        return done.value, flag.value
+
+    def fetch_receivers(self, first, n):
+        out = np.zeros((n, self.n_recv), dtype=np.float64)
+        if out.size:
+            _check(self.lib.wv_fetch_receivers(self.h, first, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def step_count(self):
+        s = C.c_uint64()
+        _check(self.lib.wv_step_count(self.h, C.byref(s)))
+        return s.value
+
+    def enable_kernel_timing(self, on=True):
+        _check(self.lib.wv_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_time_ms(self):
+        ms = C.c_double()
+        n = C.c_uint64()
+        _check(self.lib.wv_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        _check(self.lib.wv_synchronize(self.h))
+
+    # ---- slab communicator ------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        _check(load_library().wv_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, id_bytes, rank, nranks):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(id_bytes)
+        _check(self.lib.wv_comm_init(self.h, buf, rank, nranks))
+
+
+def run(engine, pre, post, keep_going=lambda: True):
+    """`waveguide::run<pre, post>` with arbitrary callbacks (waveguide.h:36-126): the generic,
+    per-step-synchronised path.  pre(engine, step) -> bool; post(engine, step) -> None; both see
+    the `current` buffer through engine.read_value / write_value / read_field / write_field."""
+    step = 0
+    while pre(engine, step) and keep_going():
+        flag = engine.step()
+        raise_for_flag(flag)
+        post(engine, step)
+        engine.swap()
+        step += 1
+    return step
+
+
+def run_fast(engine, source_kind, source_node, signal, receivers, keep_going=lambda: True, chunk=1024):
+    """`run` with a hard/soft single-node source and node receivers, device resident.
+    Returns (steps, out[steps, n_receivers])."""
+    n = len(signal)
+    engine.set_source(source_kind, source_node, signal)
+    engine.set_receivers(receivers)
+    first = engine.step_count()
+    done_total = 0
+    while done_total < n and keep_going():
+        done, flag = engine.run_steps(min(chunk, n - done_total))
+        done_total += done
+        raise_for_flag(flag)
+        if done == 0:
+            break
+    return done_total, engine.fetch_receivers(first, done_total)
