@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- Gnode-updates/s of the waveguide step on synthetic fp64 box meshes (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one loop body of `waveguide::run`: source injection + receiver gather, pressure
+update of every node, boundary-filter update.  Inputs (mesh, fields, filter state) are resident
+in HBM before the timed region.
+
+  N = 1 : 1024^3 fp64 box (BASELINE configs[2], the mesh the north-star target is quoted on).
+  N > 1 : weak scaling -- rank r owns planes [1024 r, 1024 (r+1)) of a 1024 x 1024 x (1024 N) box
+          (configs[3] at N = 8), ghost planes exchanged each step over RCCL inside the engine.
+
+Prints ONE JSON line on rank 0 (see the README of the driver contract); `roofline` is for the
+dominant kernel (the streaming pressure update), timed with HIP events on the engine's stream;
+`cpu_baseline` is the CPU restatement (oracle/, kind "port") on all host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--nx", type=int, default=1024)
+    p.add_argument("--ny", type=int, default=1024)
+    p.add_argument("--nz", type=int, default=1024, help="planes per GPU")
+    p.add_argument("--precision", default="f64", choices=["f32", "f64"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--no-small", action="store_true", help="skip the 256^3 side measurement")
+    return p.parse_args()
+
+
+def cpu_baseline(args, elem):
+    """The CPU restatement on all host cores, on a bounded sample of the same workload:
+    a 1024 x 1024 x 32 slice of the box (same node mix per plane), timed for ~cpu_seconds."""
+    from oracle.oracle import Oracle
+    from wayverb_amd import mesh as M
+    from wayverb_amd.engine import make_box_nodes
+    cores = os.cpu_count() or 1
+    nx, ny, nz = args.nx, args.ny, 32
+    nodes, counts = make_box_nodes(nx, ny, nz)
+    coeffs = np.array([M.flat_coefficients(0.1)], dtype=M.coefficients_dtype)
+    mesh = M.Mesh((nx, ny, nz), nodes, coeffs, *[np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)])
+    dtype = np.float32 if args.precision == "f32" else np.float64
+    prev = np.zeros(mesh.num_nodes, dtype=dtype)
+    cur = np.zeros(mesh.num_nodes, dtype=dtype)
+    cur[mesh.compute_index(nx // 2, ny // 2, nz // 2)] = 1.0
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    o = Oracle()
+    o.step(prev, cur, mesh, bd, threads=cores)  # first touch
+    prev, cur = cur, prev
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        assert o.step(prev, cur, mesh, bd, threads=cores) == 0
+        prev, cur = cur, prev
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds and steps >= 2:
+            break
+    rate = mesh.num_nodes * steps / dt / 1e9
+    return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": cores, "kind": "port",
+            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d OpenMP threads (z-chunks)"
+                      % (nx, ny, nz, args.precision, steps, dt, cores)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from wayverb_amd import build
+    from wayverb_amd import engine as E
+    from wayverb_amd import mesh as M
+    from wayverb_amd.slab import SlabLayout, box_slab_mesh
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+
+    elem = 4 if args.precision == "f32" else 8
+    nx, ny = args.nx, args.ny
+    nz_global = args.nz * world
+    layout = SlabLayout((nx, ny, nz_global), rank, world)
+    t_setup = time.perf_counter()
+    mesh = box_slab_mesh(nx, ny, nz_global, layout)
+    eng = E.Engine(mesh, precision=args.precision, device=local_rank,
+                   ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi)
+    mesh.nodes = None  # host copy no longer needed
+    if world > 1:
+        idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(E.Engine.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    t_setup = time.perf_counter() - t_setup
+
+    # canonical pairing: calibrated hard-source impulse at the centre of the global mesh, one
+    # receiver a few nodes away (canonical.h:55-81), both device resident
+    total_steps = args.warmup + args.steps
+    signal = np.zeros(total_steps)
+    signal[0] = 1.0
+    plane = nx * ny
+    src_global = (nz_global // 2) * plane + (ny // 2) * nx + nx // 2
+    src_local = layout.to_local(src_global)
+    if src_local is not None:
+        eng.set_source(E.SOURCE_HARD, src_local, signal)
+    if layout.owns_z(nz_global // 2):
+        eng.set_receivers([layout.to_local(src_global + 3)])
+
+    def run(n):
+        done, flag = eng.run_steps(n)
+        if flag or done != n:
+            raise SystemExit("run stopped: steps %d flag %d" % (done, flag))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    eng.enable_kernel_timing(True)
+    eng.kernel_time_ms()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = eng.kernel_time_ms()
+    eng.enable_kernel_timing(False)
+
+    owned_nodes = nx * ny * (layout.z1 - layout.z0)
+    total_nodes = nx * ny * nz_global
+    value = total_nodes * args.steps / elapsed / 1e9
+
+    # nodes covered by the timed launch: all owned planes at N=1, the interior planes (faces are
+    # updated by two small launches before the halo exchange) at N>1
+    timed_planes = (layout.z1 - layout.z0) - (int(layout.ghost_lo) + int(layout.ghost_hi))
+    alg_bytes = 3 * elem * nx * ny * timed_planes
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if world == 1 and os.path.exists(prof):
+        try:
+            rec = json.load(open(prof))
+            if rec.get("workload") == "%dx%dx%d %s" % (nx, ny, args.nz, args.precision):
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Gnode-updates/s, fp64 box mesh" if args.precision == "f64" else "Gnode-updates/s, fp32 box mesh",
+        "value": round(value, 3), "unit": "Gnode-updates/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "%dx%dx%d box mesh, %s pressures, flat absorption 0.1 walls, hard-source impulse + 1 receiver"
+                               % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
+                   "per_gpu": "%dx%dx%d z-slab" % (nx, ny, args.nz), "decomposition": "z-slabs x%d" % world,
+                   "halo": "RCCL send/recv, 1 plane per neighbour per step" if world > 1 else "none",
+                   "setup_s": round(t_setup, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "stream_march_kernel", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                     "alg_bytes_per_launch": alg_bytes,
+                     "whole_step_frac": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    eng.close()
+
+    if world == 1 and rank == 0 and not args.no_small and (nx, ny, args.nz) == (1024, 1024, 1024):
+        # side measurement: BASELINE configs[1] (256^3; the whole working set sits in the 256 MiB
+        # Infinity Cache, so it is not an HBM roofline point)
+        m2 = M.box_mesh(256, 256, 256)
+        e2 = E.Engine(m2, precision=args.precision, device=local_rank)
+        sig = np.zeros(2200)
+        sig[0] = 1.0
+        e2.set_source(E.SOURCE_HARD, m2.compute_index(128, 128, 128), sig)
+        e2.set_receivers([m2.compute_index(131, 128, 128)])
+        e2.run_steps(200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e2.run_steps(2000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["config"]["also_256cubed_gnode_per_s"] = round(256 ** 3 * 2000 / dt / 1e9, 2)
+        e2.close()
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, elem)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

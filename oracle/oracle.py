@@ -35,6 +35,10 @@ class Oracle:
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            h = getattr(self.lib, "wvo_step_range_" + sfx)
+            h.restype = C.c_int
+            h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
             g = getattr(self.lib, "wvo_run_" + sfx)
             g.restype = C.c_int64
             g.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -58,6 +62,13 @@ class Oracle:
         assert previous.dtype == current.dtype and previous.flags.c_contiguous
         return f(_ptr(previous), _ptr(current), _ptr(mesh.nodes), nx, ny, nz,
                  _ptr(bd[0]), _ptr(bd[1]), _ptr(bd[2]), _ptr(mesh.coefficients), threads)
+
+    def step_range(self, previous, current, mesh, bd, z_begin, z_end, threads=1):
+        """Like step(), restricted to planes [z_begin, z_end) (z-slab tests)."""
+        nx, ny, nz = mesh.dims
+        f = getattr(self.lib, "wvo_step_range_" + self.real(previous.dtype))
+        return f(_ptr(previous), _ptr(current), _ptr(mesh.nodes), nx, ny, nz,
+                 _ptr(bd[0]), _ptr(bd[1]), _ptr(bd[2]), _ptr(mesh.coefficients), z_begin, z_end, threads)
 
     def run(self, buf0, buf1, mesh, bd, source_kind, source_node, signal, n_steps, recv, threads=1):
         """The run loop. Returns (steps_completed, flag, out[steps, n_recv])."""

@@ -154,17 +154,20 @@ static inline void FN(node)(int64_t index, REAL* previous, const REAL* cur,
     previous[index] = next;
 }
 
-/* One launch over all nodes: previous <- next in place
- * (src/waveguide/include/waveguide/waveguide.h:85-97).  threads>1: static z-chunk partition. */
-int FN(wvo_step)(REAL* previous, const REAL* current, const wvo_condensed_node* nodes, int nx, int ny,
-                 int nz, wvo_boundary_data* b1, wvo_boundary_data* b2, wvo_boundary_data* b3,
-                 const wvo_coefficients* coeffs, int threads) {
+/* One launch over the nodes of planes [z_begin, z_end): previous <- next in place
+ * (src/waveguide/include/waveguide/waveguide.h:85-97 covers all planes; the sub-range form
+ * serves the z-slab tests, where ghost planes are read but never updated).
+ * threads>1: static z-chunk partition. */
+int FN(wvo_step_range)(REAL* previous, const REAL* current, const wvo_condensed_node* nodes, int nx,
+                       int ny, int nz, wvo_boundary_data* b1, wvo_boundary_data* b2,
+                       wvo_boundary_data* b3, const wvo_coefficients* coeffs, int z_begin, int z_end,
+                       int threads) {
     const wvo_dims d = {nx, ny, nz};
     const int64_t plane = (int64_t)nx * ny;
     int flag = 0;
     if (threads < 1) threads = 1;
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(| : flag)
-    for (int z = 0; z < nz; ++z) {
+    for (int z = z_begin; z < z_end; ++z) {
         int local = 0;
         for (int64_t i = z * plane; i < (z + 1) * plane; ++i) {
             FN(node)(i, previous, current, nodes, &d, b1, b2, b3, coeffs, &local);
@@ -172,6 +175,12 @@ int FN(wvo_step)(REAL* previous, const REAL* current, const wvo_condensed_node* 
         flag |= local;
     }
     return flag;
+}
+
+int FN(wvo_step)(REAL* previous, const REAL* current, const wvo_condensed_node* nodes, int nx, int ny,
+                 int nz, wvo_boundary_data* b1, wvo_boundary_data* b2, wvo_boundary_data* b3,
+                 const wvo_coefficients* coeffs, int threads) {
+    return FN(wvo_step_range)(previous, current, nodes, nx, ny, nz, b1, b2, b3, coeffs, 0, nz, threads);
 }
 
 /* The run loop (waveguide.h:80-125) with the single-node source / node-gather receivers that

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wayverb_amd.h declares; host
+helpers; the product fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from wayverb_amd import mesh as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wayverb_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = ctypes.CDLL(built_library)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libwayverb_amd.so does not export %s" % n
+    from wayverb_amd import engine as E
+    assert sorted(E.EXPORTS) == names
+
+
+def test_struct_layouts_match_the_reference_contract():
+    from wayverb_amd import engine as E
+    assert M.condensed_node_dtype.itemsize == 8 and M.boundary_data_dtype.itemsize == 56
+    assert M.coefficients_dtype.itemsize == 112
+    assert ctypes.sizeof(E.WvOptions) == 64
+
+
+def test_box_mesh_counts_match_survey_table():
+    m = M.box_mesh(32, 32, 32)
+    t = m.nodes["boundary_type"]
+    assert int((t == M.ID_INSIDE).sum()) == 21952 and int((t == 0).sum()) == 5768
+    assert [b.shape[0] for b in m.bidx] == [4704, 336, 8]
+
+
+def test_native_box_helper_matches_numpy_and_slabs(built_library):
+    from wayverb_amd import engine as E
+    nodes, counts = E.make_box_nodes(13, 9, 11)
+    ref = M.box_mesh(13, 9, 11)
+    assert nodes.tobytes() == ref.nodes.tobytes()
+    assert counts == tuple(b.shape[0] for b in ref.bidx)
+    # a slab [3, 8) with ghosts [2, 9): types global, numbering restarts over owned planes
+    slab, c = E.make_box_nodes(13, 9, 11, z_begin=2, z_count=7, number_from=3, number_to=8)
+    plane = 13 * 9
+    assert np.array_equal(slab["boundary_type"], ref.nodes["boundary_type"][2 * plane:9 * plane])
+    owned = slab[plane:6 * plane]
+    for d in (1, 2, 3):
+        sel = np.array([bin(int(t)).count("1") == d and not (t & 1) for t in owned["boundary_type"]])
+        assert np.array_equal(owned["boundary_index"][sel], np.arange(sel.sum()))
+        assert c[d - 1] == sel.sum()
+
+
+def test_no_cpu_fallback(built_library):
+    """Without a HIP device wv_create must fail loudly (never compute on the host)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from wayverb_amd import engine as E
+    with pytest.raises(E.WaveguideError, match="(?i)no HIP device|hip"):
+        E.Engine(M.box_mesh(8, 8, 8))
+
+
+def test_product_does_not_touch_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "wayverb_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.replace("no CPU fallback", ""), f

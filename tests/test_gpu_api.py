@@ -1,0 +1,137 @@
+"""GPU: behaviour of the run loop / C ABI that the reference's own tests assert
+(src/waveguide/tests/waveguide_tests.cpp:95-107, nan_in_waveguide.cpp, verify_compensation_signal.cpp)."""
+import numpy as np
+import pytest
+
+import cases
+from helpers import run_engine
+from wayverb_amd import engine as E
+from wayverb_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generic_callbacks_fire_once_per_step_in_order_and_match_fast_path(built_library):
+    """waveguide_tests.cpp:105 + Q1 (post sees the field pre just injected into)."""
+    case = cases.CASES["random"]()
+    mesh = case["mesh"]
+    fast = run_engine(case, "f32")
+    eng = E.Engine(mesh, precision="f32")
+    eng.write_field(case["init"][0].astype(np.float32), E.BUF_PREVIOUS)
+    eng.write_field(case["init"][1].astype(np.float32), E.BUF_CURRENT)
+    calls = []
+    trace = []
+    sig = case["signal"]
+
+    def pre(e, step):
+        calls.append(("pre", step))
+        if step == len(sig):
+            return False
+        # soft source through the value helpers (soft_source.h:21-24), float arithmetic
+        v = np.float32(e.read_value(case["source_node"])) + np.float32(sig[step])
+        e.write_value(case["source_node"], v)
+        return True
+
+    def post(e, step):
+        calls.append(("post", step))
+        trace.append([e.read_value(r) for r in case["recv"]])
+
+    steps = E.run(eng, pre, post)
+    got_cur = eng.read_field(E.BUF_CURRENT)
+    eng.close()
+    assert steps == len(sig)
+    expect = []
+    for s in range(len(sig)):
+        expect += [("pre", s), ("post", s)]
+    expect.append(("pre", len(sig)))
+    assert calls == expect
+    assert np.array_equal(np.array(trace, dtype=np.float32), fast["trace"])
+    assert got_cur.tobytes() == fast["current"].tobytes()
+
+
+@pytest.mark.parametrize("poison,exc", [(np.nan, E.ValueIsNan), (np.inf, E.ValueIsInf)])
+def test_nan_and_inf_raise_like_the_reference(built_library, poison, exc):
+    mesh = M.box_mesh(12, 12, 12)
+    eng = E.Engine(mesh, precision="f64")
+    eng.write_value(mesh.compute_index(6, 6, 6), 1.0)
+    assert eng.step() == 0
+    eng.swap()
+    eng.write_value(mesh.compute_index(6, 6, 6), poison)
+    flag = eng.step()
+    assert flag & (M.ERR_NAN if np.isnan(poison) else M.ERR_INF)
+    with pytest.raises(exc):
+        E.raise_for_flag(flag)
+    eng.close()
+
+
+def test_fast_path_stops_at_the_failing_step(built_library):
+    mesh = M.box_mesh(12, 12, 12)
+    eng = E.Engine(mesh, precision="f32")
+    sig = np.zeros(40)
+    sig[0] = 1.0
+    sig[17] = np.inf
+    eng.set_source(E.SOURCE_HARD, mesh.compute_index(6, 6, 6), sig)
+    eng.set_receivers([mesh.compute_index(7, 6, 6)])
+    done, flag = eng.run_steps(40)
+    assert done == 17 and flag & M.ERR_INF
+    assert eng.fetch_receivers(0, 17).shape == (17, 1)
+    eng.close()
+
+
+def test_malformed_meshes(built_library):
+    bad = M.box_mesh(8, 8, 8)
+    bad.nodes["boundary_type"][bad.compute_index(2, 1, 4)] = M.ID_INSIDE   # in-plane neighbour is id_inside
+    eng = E.Engine(bad, precision="f32")
+    assert eng.step() & M.ERR_SUSPICIOUS_BOUNDARY
+    with pytest.raises(E.WaveguideError, match="Suspicious boundary read."):
+        E.raise_for_flag(eng.step())
+    eng.close()
+    edge = M.box_mesh(8, 8, 8)
+    edge.nodes["boundary_type"][edge.compute_index(0, 3, 3)] = M.ID_NX      # inner node would be off-grid
+    edge.nodes["boundary_index"][edge.compute_index(0, 3, 3)] = 0
+    eng = E.Engine(edge, precision="f32")
+    assert eng.step() & M.ERR_OUTSIDE_MESH
+    eng.close()
+    invalid = M.box_mesh(8, 8, 8)
+    invalid.nodes["boundary_type"][invalid.compute_index(1, 4, 4)] = M.ID_NX | M.ID_PX
+    with pytest.raises(E.WaveguideError, match="invalid boundary_type"):
+        E.Engine(invalid, precision="f32")
+    toolong = M.box_mesh(8, 8, 8)
+    toolong.nodes["boundary_index"][toolong.compute_index(1, 4, 4)] = 10 ** 6
+    with pytest.raises(E.WaveguideError, match="boundary_index"):
+        E.Engine(toolong, precision="f32")
+
+
+def test_buffer_helpers_and_state_round_trip(built_library):
+    case = cases.CASES["random"]()
+    mesh = case["mesh"]
+    eng = E.Engine(mesh, precision="f64")
+    rng = np.random.default_rng(0)
+    f = rng.uniform(-1, 1, mesh.num_nodes)
+    eng.write_field(f.astype(np.float32), E.BUF_CURRENT)            # float -> double conversion on device
+    assert np.array_equal(eng.read_field(E.BUF_CURRENT), f.astype(np.float32).astype(np.float64))
+    assert np.array_equal(eng.read_field(E.BUF_CURRENT, np.float32), f.astype(np.float32))
+    eng.write_value(17, 0.125)
+    assert eng.read_value(17) == 0.125
+    assert eng.read_value(17, E.BUF_PREVIOUS) == 0.0
+    for d in (1, 2, 3):
+        bd = eng.read_boundary_data(d)
+        assert np.array_equal(bd["coefficient_index"], mesh.bidx[d - 1])
+        assert not bd["filter_memory"].any()
+        bd["filter_memory"] = rng.uniform(-1, 1, bd["filter_memory"].shape)
+        eng.write_boundary_data(d, bd)
+        assert eng.read_boundary_data(d).tobytes() == bd.tobytes()
+    with pytest.raises(E.WaveguideError, match="Size of new coefficients"):
+        eng.set_coefficients(mesh.coefficients[:2])
+    eng.set_coefficients(mesh.coefficients)
+    eng.close()
+
+
+def test_exhausted_source_ends_the_run(built_library):
+    """hard_source.h:18-20: `pre` returns false when the signal is used up."""
+    mesh = M.box_mesh(10, 10, 10)
+    eng = E.Engine(mesh, precision="f32")
+    eng.set_source(E.SOURCE_HARD, mesh.compute_index(5, 5, 5), np.ones(5))
+    done, flag = eng.run_steps(100)
+    assert (done, flag) == (5, 0)
+    eng.close()

@@ -1,0 +1,163 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the committed golden
+vectors (reference kernel output) and against the CPU restatement on the same seeded inputs.
+Bit-exact in fp32 AND fp64: the engine reproduces the reference's operation order with FMA
+contraction off, so no tolerance is needed (the north star's 1e-12 relative bound for fp64 is
+implied by, and asserted alongside, bit equality)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import golden
+from helpers import run_engine, run_oracle, sha
+from wayverb_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_env(**kw):
+    for k in ("WV_STREAM_RY", "WV_STREAM_NW", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS"):
+        os.environ.pop(k, None)
+    for k, v in kw.items():
+        os.environ[k] = str(v)
+
+
+@pytest.fixture(autouse=True)
+def _clean_env(built_library):
+    _set_env()
+    yield
+    _set_env()
+
+
+def assert_same_run(r, g, tag, name):
+    assert np.array_equal(r["trace"].view(np.uint8), g["trace_" + tag].view(np.uint8)), "receiver traces differ"
+    assert sha(r["current"]) == str(g["sha_current_" + tag]), "final current field differs"
+    assert sha(r["previous"]) == str(g["sha_previous_" + tag]), "final previous field differs"
+    assert [sha(b) for b in r["bd"]] == [str(s) for s in g["sha_bd_" + tag]], "filter memories differ"
+    if tag == "f64" and name == "random":
+        ref = g["final_current_f64"]
+        rel = np.max(np.abs(r["current"] - ref)) / np.max(np.abs(ref))
+        assert rel <= 1e-12  # BASELINE.json north star tolerance
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_engine_matches_golden(name, tag):
+    r = run_engine(cases.CASES[name](), tag)
+    assert r["steps"] == cases.CASES[name]()["steps"]
+    assert_same_run(r, golden(name), tag, name)
+
+
+VARIANTS = [dict(WV_STREAM_VARIANT=1)] + \
+    [dict(WV_STREAM_RY=ry, WV_STREAM_NW=nw, WV_STREAM_ZCHUNKS=zc)
+     for ry, nw, zc in ((2, 1, 1), (2, 4, 3), (4, 2, 5), (4, 4, 1), (8, 1, 2), (8, 4, 28))]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "-".join("%s%s" % (k[10:], v) for k, v in e.items()))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_every_stream_variant_matches_golden(env, tag):
+    _set_env(**env)
+    r = run_engine(cases.CASES["random"](), tag)
+    assert_same_run(r, golden("random"), tag, "random")
+
+
+def _random_case(dims, seed, steps, reentrant=True):
+    rng = np.random.default_rng(seed)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 4),
+                             np.array([M.rigid_coefficients(), M.flat_coefficients(0.2)],
+                                      dtype=M.coefficients_dtype)])
+    mesh = M.box_mesh(*dims, coefficients=coeffs, surface_of_face=[0, 1, 2, 3, 4, 5])
+    if reentrant:
+        mesh.nodes["boundary_type"][mesh.compute_index(3, 2, 2)] = M.ID_REENTRANT
+    live = mesh.nodes["boundary_type"] != 0
+    prev = np.zeros(mesh.num_nodes)
+    cur = np.zeros(mesh.num_nodes)
+    prev[live] = rng.uniform(-0.25, 0.25, int(live.sum()))
+    cur[live] = rng.uniform(-0.25, 0.25, int(live.sum()))
+    ci = mesh.compute_index
+    nx, ny, nz = dims
+    recv = [ci(nx // 2, ny // 2, nz // 2), ci(1, 2, 2), ci(nx - 2, ny - 2, nz - 2), ci(nx - 1, 0, 0)]
+    return dict(mesh=mesh, steps=steps, source_kind=2, source_node=ci(nx // 3, ny // 2, nz // 2),
+                signal=rng.uniform(-0.1, 0.1, steps), recv=recv, init=(prev, cur))
+
+
+# ragged shapes: partial x tiles (nx % 128, nx % 256), odd nx (unaligned rows), several x tiles,
+# ny not a multiple of the tile height, minimum box
+RAGGED = [(5, 5, 5), (131, 9, 7), (300, 21, 13), (257, 6, 9), (64, 64, 17), (513, 7, 5)]
+
+
+@pytest.mark.parametrize("dims", RAGGED, ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_ragged_meshes_match_oracle(oracle, dims, tag):
+    dtype = np.float32 if tag == "f32" else np.float64
+    case = _random_case(dims, seed=sum(dims), steps=12, reentrant=min(dims) > 5)
+    want = run_oracle(oracle, case, dtype, threads=4)
+    got = run_engine(case, tag)
+    assert want["flag"] == 0 and got["steps"] == want["steps"]
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    for a, b in zip(got["bd"], want["bd"]):
+        assert a.tobytes() == b.tobytes()
+
+
+def test_wide_mesh_all_xcd_tiles(oracle):
+    """1024-wide rows (the bench geometry: 8 x-tiles, XCD-mapped workgroups) on a thin box."""
+    case = _random_case((1024, 1024, 6), seed=3, steps=3, reentrant=False)
+    want = run_oracle(oracle, case, np.float64, threads=os.cpu_count() or 8)
+    got = run_engine(case, "f64")
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+
+
+def test_config1_256cubed_matches_oracle_and_is_mirror_symmetric(oracle):
+    """BASELINE configs[1] geometry (256^3, fp64): a few steps against the threaded oracle, plus a
+    size-independent property -- an x-mirror-symmetric start stays bit-exactly mirror symmetric
+    (a+b == b+a makes the nx/px swap exact)."""
+    from wayverb_amd import engine as E
+    n = 256
+    mesh = M.box_mesh(n, n, n)
+    rng = np.random.default_rng(11)
+    half = rng.uniform(-0.25, 0.25, (n, n, n // 2))
+    field = np.concatenate([half, half[:, :, ::-1]], axis=2)            # [z, y, x], symmetric in x
+    live = (mesh.nodes["boundary_type"] != 0).reshape(n, n, n)
+    cur = np.where(live, field, 0.0).reshape(-1)
+    prev = np.where(live, 0.5 * field, 0.0).reshape(-1)
+    eng = E.Engine(mesh, precision="f64")
+    eng.write_field(prev, E.BUF_PREVIOUS)
+    eng.write_field(cur, E.BUF_CURRENT)
+    steps = 6
+    done, flag = eng.run_steps(steps)
+    assert (done, flag) == (steps, 0)
+    got = eng.read_field(E.BUF_CURRENT)
+    eng.close()
+    g3 = got.reshape(n, n, n)
+    assert np.array_equal(g3, g3[:, :, ::-1])
+    o_prev, o_cur = prev.copy(), cur.copy()
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    for _ in range(steps):
+        assert oracle.step(o_prev, o_cur, mesh, bd, threads=os.cpu_count() or 8) == 0
+        o_prev, o_cur = o_cur, o_prev
+    assert got.tobytes() == o_cur.tobytes()
+
+
+def test_runs_are_bit_deterministic():
+    """verify_compensation_signal.cpp:24-31,50-92: repeated runs give identical floats."""
+    a = run_engine(cases.CASES["random"](), "f32")
+    b = run_engine(cases.CASES["random"](), "f32")
+    assert a["trace"].tobytes() == b["trace"].tobytes() and a["current"].tobytes() == b["current"].tobytes()
+
+
+def test_impulse_response_known_answer():
+    """(1/3)^3 three nodes away after three updates (SURVEY.md 8(c) probe)."""
+    from wayverb_amd import engine as E
+    mesh = M.box_mesh(16, 16, 16)
+    eng = E.Engine(mesh, precision="f64")
+    sig = np.zeros(8)
+    sig[0] = 1.0
+    steps, out = E.run_fast(eng, E.SOURCE_HARD, mesh.compute_index(8, 8, 8), sig, [mesh.compute_index(11, 8, 8)])
+    eng.close()
+    assert steps == 8
+    assert out[3, 0] == pytest.approx((1.0 / 3.0) ** 3, rel=1e-15)
+    assert np.all(out[:3, 0] == 0)

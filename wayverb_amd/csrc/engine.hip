@@ -74,6 +74,7 @@ struct wv_engine {
     virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
     virtual int kernel_time(double* mean_ms, uint64_t* launches) = 0;
     virtual int synchronize() = 0;
+    virtual int set_tuning(int variant, int ry, int nw, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
     virtual int comm_destroy() = 0;
     uint64_t steps_done = 0;
@@ -239,14 +240,23 @@ public:
     }
 
     // -------------------------------------------------------------------------------------------
+    int set_tuning(int variant, int ry, int nw, int zchunks) override {
+        if (variant != 0 && variant != 1) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
+        tune_variant_ = variant;
+        tune_ry_ = ry;
+        tune_nw_ = nw;
+        tune_zchunks_ = zchunks;
+        plan_stream();
+        return WV_OK;
+    }
+
     void plan_stream() {
         StreamPlan& p = plan_;
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
-        p.variant = opt_.stream_variant == 1 ? 1 : 0;
-        p.variant = env_int("WV_STREAM_VARIANT", p.variant);
-        p.ry = env_int("WV_STREAM_RY", 4);
-        p.nw = env_int("WV_STREAM_NW", 4);
+        p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant == 1 ? 1 : 0);
+        p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 4);
+        p.nw = tune_nw_ > 0 ? tune_nw_ : env_int("WV_STREAM_NW", 4);
         if (p.ry != 2 && p.ry != 4 && p.ry != 8) p.ry = 4;
         if (p.nw != 1 && p.nw != 2 && p.nw != 4) p.nw = 4;
         p.tiles_x = (nx_ + WX - 1) / WX;
@@ -254,7 +264,7 @@ public:
         const int owned = z_end_ - z_begin_;
         // enough workgroups to fill 256 CUs a few times over; otherwise march the whole column
         const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nw;
-        int64_t want = env_int("WV_STREAM_ZCHUNKS", 0);
+        int64_t want = tune_zchunks_ > 0 ? tune_zchunks_ : env_int("WV_STREAM_ZCHUNKS", 0);
         if (want <= 0) want = (8192 + wave_tiles - 1) / wave_tiles;
         want = std::max<int64_t>(1, std::min<int64_t>(want, owned));
         p.zc = (int)((owned + want - 1) / want);
@@ -696,6 +706,7 @@ private:
     Real courant_ = 0, courant_sq_ = 0;
     hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
     StreamPlan plan_;
+    int tune_variant_ = -1, tune_ry_ = 0, tune_nw_ = 0, tune_zchunks_ = 0;
     std::vector<hipEvent_t> events_;
     int ev_used_ = 0;
     double time_ms_ = 0;
@@ -830,6 +841,10 @@ int wv_enable_kernel_timing(wv_engine* e, int enable) {
 int wv_synchronize(wv_engine* e) {
     WV_NEED(e);
     return e->synchronize();
+}
+int wv_set_stream_tuning(wv_engine* e, int variant, int ry, int nw, int zchunks) {
+    WV_NEED(e);
+    return e->set_tuning(variant, ry, nw, zchunks);
 }
 int wv_comm_unique_id(void* id_bytes) {
     std::string err;

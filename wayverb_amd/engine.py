@@ -28,7 +28,7 @@ EXPORTS = [
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_make_box_nodes",
+    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
     lib.wv_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.wv_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.wv_synchronize.argtypes = [C.c_void_p]
+    lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.wv_comm_unique_id.argtypes = [C.c_void_p]
     lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.wv_comm_destroy.argtypes = [C.c_void_p]
@@ -274,6 +275,9 @@ class Engine:
 
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
+
+    def set_stream_tuning(self, variant=0, rows_per_wave=0, waves_per_group=0, z_chunks=0):
+        _check(self.lib.wv_set_stream_tuning(self.h, variant, rows_per_wave, waves_per_group, z_chunks))
 
     # ---- slab communicator ------------------------------------------------------------------
     @staticmethod

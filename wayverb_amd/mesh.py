@@ -72,7 +72,7 @@ class Mesh:
 
     @property
     def num_nodes(self):
-        return self.nodes.shape[0]
+        return self.dims[0] * self.dims[1] * self.dims[2]
 
     def set_coefficients(self, c):
         """mesh::set_coefficients (setup.cpp:38-50): one for all, or a same-sized vector."""
