@@ -174,9 +174,9 @@ int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches);
 int wv_enable_kernel_timing(wv_engine* e, int enable);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);
-/* Tuning hook for the streaming kernel: variant 0 = z-march (rows_per_wave in {2,4,8},
- * waves_per_group in {1,2,4}, z_chunks = workgroups along z, 0 = automatic), 1 = naive. */
-int wv_set_stream_tuning(wv_engine* e, int variant, int rows_per_wave, int waves_per_group, int z_chunks);
+/* Tuning hook for the streaming kernel: variant 0 = z-march (rows_per_wave in {2,4}; a workgroup
+ * is waves_x by waves_y waves; z_chunks = workgroups along z; 0 = automatic), 1 = naive. */
+int wv_set_stream_tuning(wv_engine* e, int variant, int rows_per_wave, int waves_x, int waves_y, int z_chunks);
 
 /* ---- z-slab halo exchange over RCCL (multi-GPU) ---------------------------- */
 #define WV_UNIQUE_ID_BYTES 128

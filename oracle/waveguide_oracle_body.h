@@ -163,13 +163,14 @@ int FN(wvo_step_range)(REAL* previous, const REAL* current, const wvo_condensed_
                        wvo_boundary_data* b3, const wvo_coefficients* coeffs, int z_begin, int z_end,
                        int threads) {
     const wvo_dims d = {nx, ny, nz};
-    const int64_t plane = (int64_t)nx * ny;
     int flag = 0;
     if (threads < 1) threads = 1;
+    /* static partition over x-rows (z-major), so thin slabs still use every thread */
+    const int64_t row0 = (int64_t)z_begin * ny, row1 = (int64_t)z_end * ny;
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(| : flag)
-    for (int z = z_begin; z < z_end; ++z) {
+    for (int64_t row = row0; row < row1; ++row) {
         int local = 0;
-        for (int64_t i = z * plane; i < (z + 1) * plane; ++i) {
+        for (int64_t i = row * nx; i < (row + 1) * nx; ++i) {
             FN(node)(i, previous, current, nodes, &d, b1, b2, b3, coeffs, &local);
         }
         flag |= local;

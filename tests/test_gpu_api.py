@@ -88,7 +88,8 @@ def test_malformed_meshes(built_library):
     eng.close()
     edge = M.box_mesh(8, 8, 8)
     edge.nodes["boundary_type"][edge.compute_index(0, 3, 3)] = M.ID_NX      # inner node would be off-grid
-    edge.nodes["boundary_index"][edge.compute_index(0, 3, 3)] = 0
+    edge.nodes["boundary_index"][edge.compute_index(0, 3, 3)] = edge.bidx[0].shape[0]
+    edge.bidx[0] = np.vstack([edge.bidx[0], np.zeros((1, 1), dtype=np.uint32)])
     eng = E.Engine(edge, precision="f32")
     assert eng.step() & M.ERR_OUTSIDE_MESH
     eng.close()

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _set_env(**kw):
-    for k in ("WV_STREAM_RY", "WV_STREAM_NW", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS"):
+    for k in ("WV_STREAM_RY", "WV_STREAM_NWX", "WV_STREAM_NWY", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -50,8 +50,9 @@ def test_engine_matches_golden(name, tag):
 
 
 VARIANTS = [dict(WV_STREAM_VARIANT=1)] + \
-    [dict(WV_STREAM_RY=ry, WV_STREAM_NW=nw, WV_STREAM_ZCHUNKS=zc)
-     for ry, nw, zc in ((2, 1, 1), (2, 4, 3), (4, 2, 5), (4, 4, 1), (8, 1, 2), (8, 4, 28))]
+    [dict(WV_STREAM_RY=ry, WV_STREAM_NWX=nwx, WV_STREAM_NWY=nwy, WV_STREAM_ZCHUNKS=zc)
+     for ry, nwx, nwy, zc in ((2, 1, 1, 1), (2, 1, 4, 3), (4, 2, 2, 5), (4, 1, 4, 1), (2, 8, 1, 2), (4, 4, 2, 28),
+                              (2, 2, 4, 4), (4, 2, 1, 7), (2, 4, 1, 1), (4, 1, 2, 2))]
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "-".join("%s%s" % (k[10:], v) for k, v in e.items()))

@@ -58,6 +58,16 @@ __device__ __forceinline__ double lane_from_above(double edge, double v) {
     return __hiloint2double(hi, lo);
 }
 
+// value of `v` in lane `src` (a compile-time constant), broadcast to the whole wave
+__device__ __forceinline__ float read_lane(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double read_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename Real>
 __device__ __forceinline__ int bad_bits(Real v) {
     return (isinf(v) ? FLAG_INF : 0) | (isnan(v) ? FLAG_NAN : 0);

@@ -43,7 +43,7 @@ constexpr int kRing = 1024;  // steps per device batch (flag words / receiver ro
 
 struct StreamPlan {
     int variant = 0;  // 0 = march, 1 = naive
-    int ry = 4, nw = 4;
+    int ry = 2, nwx = 1, nwy = 4;
     int zc = 0, tiles_x = 0, tiles_y = 0, chunks_z = 0, total_tiles = 0, tiles_per_xcd = 0;
     unsigned grid = 0, block = 0;
 };
@@ -74,7 +74,7 @@ struct wv_engine {
     virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
     virtual int kernel_time(double* mean_ms, uint64_t* launches) = 0;
     virtual int synchronize() = 0;
-    virtual int set_tuning(int variant, int ry, int nw, int zchunks) = 0;
+    virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
     virtual int comm_destroy() = 0;
     uint64_t steps_done = 0;
@@ -240,11 +240,12 @@ public:
     }
 
     // -------------------------------------------------------------------------------------------
-    int set_tuning(int variant, int ry, int nw, int zchunks) override {
+    int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) override {
         if (variant != 0 && variant != 1) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
         tune_variant_ = variant;
         tune_ry_ = ry;
-        tune_nw_ = nw;
+        tune_nwx_ = nwx;
+        tune_nwy_ = nwy;
         tune_zchunks_ = zchunks;
         plan_stream();
         return WV_OK;
@@ -255,15 +256,25 @@ public:
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
         p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant == 1 ? 1 : 0);
-        p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 4);
-        p.nw = tune_nw_ > 0 ? tune_nw_ : env_int("WV_STREAM_NW", 4);
-        if (p.ry != 2 && p.ry != 4 && p.ry != 8) p.ry = 4;
-        if (p.nw != 1 && p.nw != 2 && p.nw != 4) p.nw = 4;
-        p.tiles_x = (nx_ + WX - 1) / WX;
-        p.tiles_y = (ny_ + p.ry * p.nw - 1) / (p.ry * p.nw);
+        p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 2);
+        p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", 1);
+        p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", 4);
+        if (p.ry != 2 && p.ry != 4) p.ry = 2;
+        {
+            const int key = p.nwx * 10 + p.nwy;
+            const int ok[] = {11, 12, 14, 21, 22, 24, 41, 42, 81};
+            bool found = false;
+            for (int k : ok) found = found || k == key;
+            if (!found) {
+                p.nwx = 1;
+                p.nwy = 4;
+            }
+        }
+        p.tiles_x = (nx_ + WX * p.nwx - 1) / (WX * p.nwx);
+        p.tiles_y = (ny_ + p.ry * p.nwy - 1) / (p.ry * p.nwy);
         const int owned = z_end_ - z_begin_;
         // enough workgroups to fill 256 CUs a few times over; otherwise march the whole column
-        const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nw;
+        const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nwx * p.nwy;
         int64_t want = tune_zchunks_ > 0 ? tune_zchunks_ : env_int("WV_STREAM_ZCHUNKS", 0);
         if (want <= 0) want = (8192 + wave_tiles - 1) / wave_tiles;
         want = std::max<int64_t>(1, std::min<int64_t>(want, owned));
@@ -272,23 +283,32 @@ public:
         p.total_tiles = p.tiles_x * p.tiles_y * p.chunks_z;
         p.tiles_per_xcd = (p.total_tiles + 7) / 8;
         p.grid = (unsigned)p.tiles_per_xcd * 8u;
-        p.block = 64u * (unsigned)p.nw;
+        p.block = 64u * (unsigned)(p.nwx * p.nwy);
         if (p.variant == 1) {
             p.block = 256;
             p.grid = (unsigned)std::min<uint64_t>((n_nodes_ + 255) / 256, 256ull * 64);
         }
     }
 
-    template <int RY, int NW>
+    template <int RY, int NWX, int NWY>
     void launch_march(const wv::StreamArgs<Real>& a, unsigned grid) {
-        hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NW>), dim3(grid), dim3(plan_.block), 0, stream_, a);
+        hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                           stream_, a);
     }
     template <int RY>
-    void launch_march_nw(const wv::StreamArgs<Real>& a, unsigned grid) {
-        switch (plan_.nw) {
-            case 1: launch_march<RY, 1>(a, grid); break;
-            case 2: launch_march<RY, 2>(a, grid); break;
-            default: launch_march<RY, 4>(a, grid); break;
+    void launch_march_shape(const wv::StreamArgs<Real>& a, unsigned grid) {
+        const int key = plan_.nwx * 10 + plan_.nwy;
+        switch (key) {
+            case 11: launch_march<RY, 1, 1>(a, grid); break;
+            case 12: launch_march<RY, 1, 2>(a, grid); break;
+            case 14: launch_march<RY, 1, 4>(a, grid); break;
+            case 21: launch_march<RY, 2, 1>(a, grid); break;
+            case 22: launch_march<RY, 2, 2>(a, grid); break;
+            case 24: launch_march<RY, 2, 4>(a, grid); break;
+            case 41: launch_march<RY, 4, 1>(a, grid); break;
+            case 42: launch_march<RY, 4, 2>(a, grid); break;
+            case 81: launch_march<RY, 8, 1>(a, grid); break;
+            default: launch_march<RY, 1, 4>(a, grid); break;
         }
     }
 
@@ -309,7 +329,7 @@ public:
         a.z_end = z1;
         // z-chunking of this launch: the plan's chunk length, clipped to the range
         a.zc = std::min(plan_.zc, z1 - z0);
-        a.tiles_x = (nx_ + WX - 1) / WX;
+        a.tiles_x = plan_.tiles_x;
         a.tiles_y = plan_.tiles_y;
         a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
         a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
@@ -321,9 +341,8 @@ public:
             hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
         } else {
             switch (plan_.ry) {
-                case 2: launch_march_nw<2>(a, grid); break;
-                case 8: launch_march_nw<8>(a, grid); break;
-                default: launch_march_nw<4>(a, grid); break;
+                case 2: launch_march_shape<2>(a, grid); break;
+                default: launch_march_shape<4>(a, grid); break;
             }
         }
         if (timed) {
@@ -706,7 +725,7 @@ private:
     Real courant_ = 0, courant_sq_ = 0;
     hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
     StreamPlan plan_;
-    int tune_variant_ = -1, tune_ry_ = 0, tune_nw_ = 0, tune_zchunks_ = 0;
+    int tune_variant_ = -1, tune_ry_ = 0, tune_nwx_ = 0, tune_nwy_ = 0, tune_zchunks_ = 0;
     std::vector<hipEvent_t> events_;
     int ev_used_ = 0;
     double time_ms_ = 0;
@@ -842,9 +861,9 @@ int wv_synchronize(wv_engine* e) {
     WV_NEED(e);
     return e->synchronize();
 }
-int wv_set_stream_tuning(wv_engine* e, int variant, int ry, int nw, int zchunks) {
+int wv_set_stream_tuning(wv_engine* e, int variant, int ry, int nwx, int nwy, int zchunks) {
     WV_NEED(e);
-    return e->set_tuning(variant, ry, nw, zchunks);
+    return e->set_tuning(variant, ry, nwx, nwy, zchunks);
 }
 int wv_comm_unique_id(void* id_bytes) {
     std::string err;

@@ -70,28 +70,46 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
 // the block->tile map keeps each XCD's workgroups on y-adjacent tiles so the halo rows that
 // cross workgroups are served by that XCD's L2 instead of HBM.
 // ---------------------------------------------------------------------------------------------
-template <typename Real, int RY, int NW>
-__global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<Real> a) {
+// Experiment switches (tools/stream_bench.hip only; the engine always uses 0).  The first three
+// change results and exist to price a piece of the kernel; the nt ones are result-neutral.
+enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
+             X_NO_HALO_ROWS = 64, X_TX_FAST = 128 };
+// what the engine runs: x-fastest tile order, non-temporal prev loads and next stores (both are
+// touched exactly once per step, so they should not displace the re-used `cur` lines from L2)
+constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
+
+template <typename Real, int RY, int NWX, int NWY, int X = X_PRODUCT>
+__global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const StreamArgs<Real> a) {
     using V = typename Vec16<Real>::type;
     constexpr int VX = Vec16<Real>::N;
     constexpr int WX = 64 * VX;
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // wave id as a scalar: everything derived from it (tile origin, row addresses) stays in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wx = wave % NWX, wy = wave / NWX;
 
     // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch, used for locality only)
     const int b = blockIdx.x;
     const int slot = b >> 3;
     const int t = (b & 7) * a.tiles_per_xcd + slot;
     if (slot >= a.tiles_per_xcd || t >= a.total_tiles) return;
-    const int ty = t % a.tiles_y;
-    const int rem = t / a.tiles_y;
-    const int tx = rem % a.tiles_x;
-    const int cz = rem / a.tiles_x;
+    int tx, ty, cz;
+    if (X & X_TX_FAST) {  // x-adjacent tiles consecutive: an XCD's resident set is a tx-by-ty patch
+        tx = t % a.tiles_x;
+        const int rem = t / a.tiles_x;
+        ty = rem % a.tiles_y;
+        cz = rem / a.tiles_y;
+    } else {
+        ty = t % a.tiles_y;
+        const int rem = t / a.tiles_y;
+        tx = rem % a.tiles_x;
+        cz = rem / a.tiles_x;
+    }
 
-    const int x0 = tx * WX;
-    const int y0 = (ty * NW + wave) * RY;
-    if (y0 >= a.ny) return;
+    const int x0 = (tx * NWX + wx) * WX;
+    const int y0 = (ty * NWY + wy) * RY;
+    if (y0 >= a.ny || x0 >= a.nx) return;
     const int zb = a.z_begin + cz * a.zc;
     const int ze = min(zb + a.zc, a.z_end);
     if (zb >= ze) return;
@@ -106,7 +124,8 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
         if (y >= 0 && y < a.ny && z >= 0 && z < a.nz) {
             const Real* p = a.cur + (z * plane + (int64_t)y * a.nx + xl);
             if (full) {
-                v = *reinterpret_cast<const V*>(p);
+                v = (X & X_NT_CUR) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
+                                   : *reinterpret_cast<const V*>(p);
             } else {
 #pragma unroll
                 for (int j = 0; j < VX; ++j)
@@ -115,10 +134,13 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
         }
         return v;
     };
-    // x-edge halo of a row: lanes 0..31 fetch cur[x0-1], lanes 32..63 fetch cur[x0+WX]
-    auto load_edge = [&](int y, int z) -> Real {
+    // x-edge halo of all RY rows of a plane in ONE load: lane r (< RY) fetches cur[x0-1] of row
+    // y0+r, lane 32+r fetches cur[x0+WX] of that row; read_lane hands them to lanes 0 / 63 later.
+    auto load_edges = [&](int z) -> Real {
         Real e = 0;
-        if (y >= 0 && y < a.ny && z >= 0 && z < a.nz) {
+        const int r = lane & 31;
+        const int y = y0 + r;
+        if (!(X & X_NO_EDGE) && r < RY && y < a.ny && z >= 0 && z < a.nz) {
             const int xe = (lane < 32) ? x0 - 1 : x0 + WX;
             if (xe >= 0 && xe < a.nx) e = a.cur[z * plane + (int64_t)y * a.nx + xe];
         }
@@ -129,7 +151,8 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
         if (y < a.ny && z < ze) {
             const Real* p = a.prev + (z * plane + (int64_t)y * a.nx + xl);
             if (full) {
-                v = *reinterpret_cast<const V*>(p);
+                v = (X & X_NT_PREV) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
+                                    : *reinterpret_cast<const V*>(p);
             } else {
 #pragma unroll
                 for (int j = 0; j < VX; ++j)
@@ -141,6 +164,7 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
     // 2 class bits per element of this lane (all "boundary" = never stored when off-grid)
     auto load_cls = [&](int y, int z) -> uint32_t {
         uint32_t c = 0xAAu;
+        if (X & X_NO_CLS) return 0x55u;
         if (y < a.ny && z < ze && xl < a.nx) {
             const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
             c = (VX == 4) ? byte : ((byte >> ((lane & 1) * 4)) & 0xFu);
@@ -150,22 +174,20 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
 
     V below[RY];        // cur(z-1), rows y0 .. y0+RY-1
     V mid[RY + 2];      // cur(z),   rows y0-1 .. y0+RY
-    Real mid_e[RY];     // x-edge halo of cur(z) rows y0 .. y0+RY-1
+    Real mid_e;         // x-edge halos of cur(z): lanes r / 32+r hold row y0+r's left / right value
     V above[RY + 2];    // cur(z+1)
-    Real above_e[RY];
+    Real above_e;
     V pv[RY];           // prev(z)
     uint32_t cl[RY];
 
 #pragma unroll
     for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, zb - 1);
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) mid[r] = load_cur(y0 - 1 + r, zb);
+    for (int r = 0; r < RY + 2; ++r) mid[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, zb);
+    mid_e = load_edges(zb);
 #pragma unroll
-    for (int r = 0; r < RY; ++r) mid_e[r] = load_edge(y0 + r, zb);
-#pragma unroll
-    for (int r = 0; r < RY + 2; ++r) above[r] = load_cur(y0 - 1 + r, zb + 1);
-#pragma unroll
-    for (int r = 0; r < RY; ++r) above_e[r] = load_edge(y0 + r, zb + 1);
+    for (int r = 0; r < RY + 2; ++r) above[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, zb + 1);
+    above_e = load_edges(zb + 1);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         pv[r] = load_prev(y0 + r, zb);
@@ -176,13 +198,12 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
     for (int z = zb; z < ze; ++z) {
         // ---- issue the loads of the next iteration first: plane z+2 of cur, plane z+1 of prev
         V nxt[RY + 2];
-        Real nxt_e[RY];
+        Real nxt_e;
         V pv_n[RY];
         uint32_t cl_n[RY];
 #pragma unroll
-        for (int r = 0; r < RY + 2; ++r) nxt[r] = load_cur(y0 - 1 + r, z + 2);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) nxt_e[r] = load_edge(y0 + r, z + 2);
+        for (int r = 0; r < RY + 2; ++r) nxt[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, z + 2);
+        nxt_e = load_edges(z + 2);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             pv_n[r] = load_prev(y0 + r, z + 1);
@@ -195,19 +216,20 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
             const int y = y0 + r;
             if (y < a.ny) {
                 const V c0 = mid[r + 1];
+                const Real edge_l = read_lane(mid_e, r), edge_r = read_lane(mid_e, 32 + r);
                 V out;
                 bool skip_any = false;
 #pragma unroll
                 for (int j = 0; j < VX; ++j) {
-                    const Real left = (j == 0) ? lane_from_below(mid_e[r], c0[VX - 1]) : c0[j - 1];
-                    const Real right = (j == VX - 1) ? lane_from_above(mid_e[r], c0[0]) : c0[j + 1];
+                    const Real left = (j == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[j - 1];
+                    const Real right = (j == VX - 1) ? lane_from_above(edge_r, c0[0]) : c0[j + 1];
                     Real s = Real(0) + left;
                     s += right;
                     s += mid[r][j];
                     s += mid[r + 2][j];
                     s += below[r][j];
                     s += above[r + 1][j];
-                    s = s / Real(3);
+                    s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
                     s -= pv[r][j];
                     const uint32_t c = (cl[r] >> (2 * j)) & 3u;
                     const Real o = (c & 1u) ? s : Real(0);
@@ -217,7 +239,8 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
                 }
                 Real* q = a.prev + (z * plane + (int64_t)y * a.nx + xl);
                 if (full && !__any(skip_any)) {
-                    *reinterpret_cast<V*>(q) = out;
+                    if (X & X_NT_STORE) __builtin_nontemporal_store(out, reinterpret_cast<V*>(q));
+                    else *reinterpret_cast<V*>(q) = out;
                 } else {
 #pragma unroll
                     for (int j = 0; j < VX; ++j) {
@@ -229,6 +252,8 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
         }
 
         // ---- rotate the register planes
+        mid_e = above_e;
+        above_e = nxt_e;
 #pragma unroll
         for (int r = 0; r < RY; ++r) below[r] = mid[r + 1];
 #pragma unroll
@@ -238,8 +263,6 @@ __global__ void __launch_bounds__(64 * NW) stream_march_kernel(const StreamArgs<
         }
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            mid_e[r] = above_e[r];
-            above_e[r] = nxt_e[r];
             pv[r] = pv_n[r];
             cl[r] = cl_n[r];
         }

@@ -100,7 +100,7 @@ def load_library():
     lib.wv_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.wv_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.wv_synchronize.argtypes = [C.c_void_p]
-    lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.wv_comm_unique_id.argtypes = [C.c_void_p]
     lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.wv_comm_destroy.argtypes = [C.c_void_p]
@@ -276,8 +276,8 @@ class Engine:
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
 
-    def set_stream_tuning(self, variant=0, rows_per_wave=0, waves_per_group=0, z_chunks=0):
-        _check(self.lib.wv_set_stream_tuning(self.h, variant, rows_per_wave, waves_per_group, z_chunks))
+    def set_stream_tuning(self, variant=0, rows_per_wave=0, waves_x=0, waves_y=0, z_chunks=0):
+        _check(self.lib.wv_set_stream_tuning(self.h, variant, rows_per_wave, waves_x, waves_y, z_chunks))
 
     # ---- slab communicator ------------------------------------------------------------------
     @staticmethod
