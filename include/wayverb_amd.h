@@ -105,7 +105,7 @@ typedef struct wv_options {
     /* the error flag is brought to the host every `flag_interval` steps of wv_run
      * (1 = after every step, like waveguide.h:100-101; 0 = once per wv_run call) */
     int32_t flag_interval;
-    int32_t stream_variant; /* 0 = default kernel; other values select tuning variants */
+    int32_t stream_variant; /* 2 = plane sweep (default), 0 = register z-march, 1 = naive */
     int32_t reserved_[9];
 } wv_options;
 
@@ -174,9 +174,10 @@ int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches);
 int wv_enable_kernel_timing(wv_engine* e, int enable);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);
-/* Tuning hook for the streaming kernel: variant 0 = z-march (rows_per_wave in {2,4}; a workgroup
- * is waves_x by waves_y waves; z_chunks = workgroups along z; 0 = automatic), 1 = naive. */
-int wv_set_stream_tuning(wv_engine* e, int variant, int rows_per_wave, int waves_x, int waves_y, int z_chunks);
+/* Tuning hook for the streaming kernel.  variant 2 = plane sweep, 0 = register z-march, 1 = naive.
+ * rows_per_wave in {2,4}; a workgroup is waves_x by waves_y waves; `knob` = rows per XCD stripe
+ * (variant 2) or workgroups along z (variant 0); 0 = automatic everywhere. */
+int wv_set_stream_tuning(wv_engine* e, int variant, int rows_per_wave, int waves_x, int waves_y, int knob);
 
 /* ---- z-slab halo exchange over RCCL (multi-GPU) ---------------------------- */
 #define WV_UNIQUE_ID_BYTES 128

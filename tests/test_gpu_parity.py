@@ -50,9 +50,10 @@ def test_engine_matches_golden(name, tag):
 
 
 VARIANTS = [dict(WV_STREAM_VARIANT=1)] + \
-    [dict(WV_STREAM_RY=ry, WV_STREAM_NWX=nwx, WV_STREAM_NWY=nwy, WV_STREAM_ZCHUNKS=zc)
-     for ry, nwx, nwy, zc in ((2, 1, 1, 1), (2, 1, 4, 3), (4, 2, 2, 5), (4, 1, 4, 1), (2, 8, 1, 2), (4, 4, 2, 28),
-                              (2, 2, 4, 4), (4, 2, 1, 7), (2, 4, 1, 1), (4, 1, 2, 2))]
+    [dict(WV_STREAM_VARIANT=v, WV_STREAM_RY=ry, WV_STREAM_NWX=nwx, WV_STREAM_NWY=nwy, WV_STREAM_ZCHUNKS=knob)
+     for v in (0, 2)
+     for ry, nwx, nwy, knob in ((2, 1, 1, 1), (2, 1, 4, 3), (4, 2, 2, 5), (4, 1, 4, 0), (2, 8, 1, 2), (4, 4, 2, 28),
+                                (2, 4, 1, 8), (4, 1, 1, 16))]
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "-".join("%s%s" % (k[10:], v) for k, v in e.items()))

@@ -97,6 +97,66 @@ __global__ void __launch_bounds__(256) triad_chunk_kernel(v2d* __restrict__ prev
     }
 }
 
+// pattern probes: one 4 KB chunk (256 lanes x 16 B) per block-iteration, same bytes as the triad
+//   MODE 0: block b -> chunk b                       (linear order; = triad_chunk<1>)
+//   MODE 1: block b -> chunk permuted plane-major    (consecutive blocks are `stride` chunks apart)
+//   MODE 2: block handles LOOP consecutive chunks one after the other (serial, no prefetch)
+//   MODE 3: like 2 but software-pipelined (next chunk's loads issued before this chunk's store)
+//   MODE 4: like 0 but prev[i] is read one chunk-plane (8 MB) ahead of where the block stores
+template <int MODE, int LOOP>
+__global__ void __launch_bounds__(256) probe_kernel(v2d* __restrict__ prev, const v2d* __restrict__ cur, int64_t n,
+                                                    int64_t stride) {
+    const int64_t chunks = n / 256;
+    if (MODE == 0 || MODE == 1) {
+        int64_t ch = blockIdx.x;
+        if (MODE == 1) ch = (ch % stride) * (chunks / stride) + ch / stride;
+        const int64_t i = ch * 256 + threadIdx.x;
+        v2d c = cur[i];
+        v2d p = __builtin_nontemporal_load(prev + i);
+        __builtin_nontemporal_store(c - p, prev + i);
+    } else if (MODE == 2) {
+        for (int k = 0; k < LOOP; ++k) {
+            const int64_t i = ((int64_t)blockIdx.x * LOOP + k) * 256 + threadIdx.x;
+            v2d c = cur[i];
+            v2d p = __builtin_nontemporal_load(prev + i);
+            __builtin_nontemporal_store(c - p, prev + i);
+        }
+    } else if (MODE == 3) {
+        int64_t i = ((int64_t)blockIdx.x * LOOP) * 256 + threadIdx.x;
+        v2d c = cur[i];
+        v2d p = __builtin_nontemporal_load(prev + i);
+        for (int k = 0; k < LOOP; ++k) {
+            v2d cn = c, pn = p;
+            if (k + 1 < LOOP) {
+                cn = cur[i + 256];
+                pn = __builtin_nontemporal_load(prev + i + 256);
+            }
+            __builtin_nontemporal_store(c - p, prev + i);
+            c = cn;
+            p = pn;
+            i += 256;
+        }
+    }
+}
+
+// stride probe: one wave per block; the wave touches U pieces of 1 KB that are `stride_vec` 16-byte
+// vectors apart (all issued together), pieces tile memory exactly once over the grid.
+template <int U>
+__global__ void __launch_bounds__(64) stride_probe_kernel(v2d* __restrict__ prev, const v2d* __restrict__ cur,
+                                                          int64_t stride_vec) {
+    const int64_t per = stride_vec / 64;                 // 1 KB pieces per stride
+    const int64_t b = blockIdx.x;
+    const int64_t base = (b / per) * (U * stride_vec) + (b % per) * 64 + threadIdx.x;
+    v2d c[U], p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        c[u] = cur[base + u * stride_vec];
+        p[u] = __builtin_nontemporal_load(prev + base + u * stride_vec);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(c[u] - p[u], prev + base + u * stride_vec);
+}
+
 struct Ctx {
     double *a, *b;
     uint8_t* cls;
@@ -162,6 +222,36 @@ static void run_march(Ctx& c, const char* name, int zchunks, int lds_bytes = 0) 
     fflush(stdout);
 }
 
+template <int RY, int NWX, int NWY, int X>
+static void run_sweep(Ctx& c, const char* name, int stripe_rows) {
+    constexpr int WX = 128;
+    wv::StreamArgs<double> a{};
+    a.cls = c.cls;
+    a.flag = c.flag;
+    a.nx = c.nx;
+    a.ny = c.ny;
+    a.nz = c.nz;
+    a.cls_pitch = c.pitch;
+    a.z_begin = 0;
+    a.z_end = c.nz;
+    a.tiles_x = (c.nx + WX * NWX - 1) / (WX * NWX);
+    a.stripe_rows = stripe_rows;
+    a.tiles_y_stripe = (stripe_rows + RY * NWY - 1) / (RY * NWY);
+    const int stripes = (c.ny + stripe_rows - 1) / stripe_rows;
+    a.passes = (stripes + 7) / 8;
+    const unsigned grid = 8u * (unsigned)a.passes * (unsigned)c.nz * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+    const double ms = time_ms(c, [&](double* prev, double* cur) {
+        wv::StreamArgs<double> b = a;
+        b.prev = prev;
+        b.cur = cur;
+        hipLaunchKernelGGL((wv::stream_sweep_kernel<double, RY, NWX, NWY, X>), dim3(grid), dim3(64 * NWX * NWY), 0, c.s, b);
+    });
+    const double bytes = 24.0 * c.nx * c.ny * c.nz;
+    printf("{\"kernel\": \"sweep\", \"name\": \"%s\", \"ry\": %d, \"nwx\": %d, \"nwy\": %d, \"x\": %d, \"stripe_rows\": %d, \"ms\": %.4f, \"alg_gbs\": %.1f}\n",
+           name, RY, NWX, NWY, X, stripe_rows, ms, bytes / ms / 1e6);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1024;
     Ctx c{};
@@ -192,6 +282,9 @@ int main(int argc, char** argv) {
         run_march<2, 4, 1, P>(c, "product", 32);
         run_march<2, 8, 1, P>(c, "product", 32);
         run_march<2, 4, 2, P>(c, "product", 32);
+        run_sweep<4, 1, 4, X_NT_STORE | X_NT_PREV>(c, "sweep", 64);
+        run_sweep<4, 1, 4, X_NT_STORE | X_NT_PREV>(c, "sweep", 128);
+        run_sweep<4, 4, 1, X_NT_STORE | X_NT_PREV>(c, "sweep", 32);
         return 0;
     }
 
@@ -224,19 +317,20 @@ int main(int argc, char** argv) {
         chunk(triad_chunk_kernel<6>, 6, "triad_chunk_nt");
     }
 
-    // ---- (b) z-chunk count with everything resident / single front
-    for (int zc : {1, 2, 4, 8, 16, 32}) {
-        run_march<2, 1, 4, P>(c, "zc", zc);
-        run_march<4, 1, 4, P>(c, "zc", zc);
-        run_march<1, 1, 4, P>(c, "zc", zc);
+    constexpr int S = X_NT_STORE | X_NT_PREV;
+    for (int sr : {16, 32, 64, 128}) {
+        run_sweep<2, 1, 1, S>(c, "sweep", sr);
+        run_sweep<4, 1, 1, S>(c, "sweep", sr);
+        run_sweep<2, 1, 4, S>(c, "sweep", sr);
+        run_sweep<4, 1, 4, S>(c, "sweep", sr);
+        run_sweep<2, 4, 1, S>(c, "sweep", sr);
+        run_sweep<4, 4, 1, S>(c, "sweep", sr);
+        run_sweep<4, 8, 1, S>(c, "sweep", sr);
+        run_sweep<8, 1, 1, S>(c, "sweep", sr);
+        run_sweep<8, 4, 1, S>(c, "sweep", sr);
     }
-    // ---- (c) occupancy sensitivity: dummy dynamic LDS limits workgroups per CU (4 waves each)
-    for (int lds : {0, 39 * 1024, 52 * 1024, 79 * 1024, 159 * 1024}) {
-        run_march<2, 1, 4, P>(c, "occupancy", 32, lds);
-    }
-    for (int lds : {0, 79 * 1024, 159 * 1024}) {
-        run_march<4, 1, 4, P>(c, "occupancy", 16, lds);
-    }
+    run_sweep<4, 1, 4, 0>(c, "sweep_no_nt", 64);
+    run_sweep<4, 1, 4, S | X_NT_CUR>(c, "sweep_nt_cur", 64);
     // ---- (d) does the relative placement of the two fields matter (DRAM bank aliasing)?
     for (int64_t off : {65536LL}) {
         Ctx d = c;

@@ -42,9 +42,11 @@ def main():
     rows = []
     variants = [(1, 0, 0, 0, 0)]
     for ry in (2, 4):
-        for nwx, nwy in ((1, 4), (2, 2), (4, 1), (4, 2), (8, 1), (2, 4)):
-            for zc in (8, 16, 32):
-                variants.append((0, ry, nwx, nwy, zc))
+        for nwx, nwy in ((1, 4), (2, 2), (4, 1), (4, 2), (8, 1), (1, 1)):
+            for knob in (16, 32):
+                variants.append((0, ry, nwx, nwy, knob))
+            for knob in (16, 32, 64, 128):
+                variants.append((2, ry, nwx, nwy, knob))
     eng.enable_kernel_timing(True)
     for v in variants:
         eng.set_stream_tuning(*v)
@@ -56,7 +58,7 @@ def main():
         ms, cnt = eng.kernel_time_ms()
         assert flag == 0 and done == args.steps
         gbs = alg / (ms * 1e-3) / 1e9
-        rec = dict(variant=v[0], ry=v[1], nwx=v[2], nwy=v[3], zchunks=v[4], kernel_ms=round(ms, 4), step_ms=round(wall, 4),
+        rec = dict(variant=v[0], ry=v[1], nwx=v[2], nwy=v[3], knob=v[4], kernel_ms=round(ms, 4), step_ms=round(wall, 4),
                    alg_gbs=round(gbs, 1), frac_of_8TBs=round(gbs / 8000, 4))
         rows.append(rec)
         print(json.dumps(rec), flush=True)

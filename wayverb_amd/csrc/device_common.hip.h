@@ -86,6 +86,8 @@ struct StreamArgs {
     int zc;              // planes marched by one workgroup
     int tiles_x, tiles_y, chunks_z;
     int total_tiles, tiles_per_xcd;
+    // plane-sweep kernel only: rows per XCD stripe, tiles per stripe-plane, passes over z
+    int stripe_rows, tiles_y_stripe, passes;
 };
 
 template <typename Real>

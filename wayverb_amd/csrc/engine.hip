@@ -42,9 +42,10 @@ int fail(int code, const std::string& msg) {
 constexpr int kRing = 1024;  // steps per device batch (flag words / receiver rows kept on device)
 
 struct StreamPlan {
-    int variant = 0;  // 0 = march, 1 = naive
-    int ry = 2, nwx = 1, nwy = 4;
-    int zc = 0, tiles_x = 0, tiles_y = 0, chunks_z = 0, total_tiles = 0, tiles_per_xcd = 0;
+    int variant = 2;  // 2 = plane sweep (default), 0 = z-march, 1 = naive
+    int ry = 4, nwx = 1, nwy = 4;
+    int zc = 0, tiles_x = 0, tiles_y = 0;
+    int stripe_rows = 0, tiles_y_stripe = 0, passes = 0;
     unsigned grid = 0, block = 0;
 };
 
@@ -241,7 +242,7 @@ public:
 
     // -------------------------------------------------------------------------------------------
     int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) override {
-        if (variant != 0 && variant != 1) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
+        if (variant < 0 || variant > 2) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
         tune_variant_ = variant;
         tune_ry_ = ry;
         tune_nwx_ = nwx;
@@ -251,18 +252,20 @@ public:
         return WV_OK;
     }
 
+    // variant 2 (default): plane sweep, L2-resident z reuse; 0: register z-march; 1: naive
     void plan_stream() {
         StreamPlan& p = plan_;
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
-        p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant == 1 ? 1 : 0);
-        p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 2);
+        p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant);
+        if (p.variant < 0 || p.variant > 2) p.variant = 2;
+        p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 4);
         p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", 1);
         p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", 4);
-        if (p.ry != 2 && p.ry != 4) p.ry = 2;
+        if (p.ry != 2 && p.ry != 4) p.ry = 4;
         {
             const int key = p.nwx * 10 + p.nwy;
-            const int ok[] = {11, 12, 14, 21, 22, 24, 41, 42, 81};
+            const int ok[] = {11, 14, 22, 41, 42, 81};
             bool found = false;
             for (int k : ok) found = found || k == key;
             if (!found) {
@@ -272,50 +275,64 @@ public:
         }
         p.tiles_x = (nx_ + WX * p.nwx - 1) / (WX * p.nwx);
         p.tiles_y = (ny_ + p.ry * p.nwy - 1) / (p.ry * p.nwy);
-        const int owned = z_end_ - z_begin_;
-        // enough workgroups to fill 256 CUs a few times over; otherwise march the whole column
-        const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nwx * p.nwy;
-        int64_t want = tune_zchunks_ > 0 ? tune_zchunks_ : env_int("WV_STREAM_ZCHUNKS", 0);
-        if (want <= 0) want = (8192 + wave_tiles - 1) / wave_tiles;
-        want = std::max<int64_t>(1, std::min<int64_t>(want, owned));
-        p.zc = (int)((owned + want - 1) / want);
-        p.chunks_z = (owned + p.zc - 1) / p.zc;
-        p.total_tiles = p.tiles_x * p.tiles_y * p.chunks_z;
-        p.tiles_per_xcd = (p.total_tiles + 7) / 8;
-        p.grid = (unsigned)p.tiles_per_xcd * 8u;
         p.block = 64u * (unsigned)(p.nwx * p.nwy);
+        const int owned = z_end_ - z_begin_;
+        const int64_t knob = tune_zchunks_ > 0 ? tune_zchunks_ : env_int("WV_STREAM_ZCHUNKS", 0);
+        if (p.variant == 2) {
+            // stripe height: three `cur` planes of a stripe should sit comfortably in one XCD's
+            // 4 MiB L2 (measured best at 0.75-1.5 MiB), at least 8 stripes so every XCD has one
+            const int tile_rows = p.ry * p.nwy;
+            int64_t rows = knob > 0 ? knob : (int64_t)(1600 * 1024) / (3ll * nx_ * (int64_t)sizeof(Real));
+            int pow2 = tile_rows;
+            while (pow2 * 2 <= rows) pow2 *= 2;
+            rows = pow2;
+            const int per_xcd = (((ny_ + 7) / 8) + tile_rows - 1) / tile_rows * tile_rows;
+            if (knob <= 0) rows = std::min<int64_t>(rows, per_xcd);
+            rows = std::max<int64_t>(rows, 1);
+            p.stripe_rows = (int)rows;
+            p.tiles_y_stripe = (p.stripe_rows + tile_rows - 1) / tile_rows;
+            const int stripes = (ny_ + p.stripe_rows - 1) / p.stripe_rows;
+            p.passes = (stripes + 7) / 8;
+            return;
+        }
         if (p.variant == 1) {
             p.block = 256;
             p.grid = (unsigned)std::min<uint64_t>((n_nodes_ + 255) / 256, 256ull * 64);
+            return;
         }
+        // variant 0: enough workgroups to fill 256 CUs a few times over
+        const int64_t wave_tiles = (int64_t)p.tiles_x * p.tiles_y * p.nwx * p.nwy;
+        int64_t want = knob;
+        if (want <= 0) want = (65536 + wave_tiles - 1) / wave_tiles;
+        want = std::max<int64_t>(1, std::min<int64_t>(want, owned));
+        p.zc = (int)((owned + want - 1) / want);
     }
 
     template <int RY, int NWX, int NWY>
-    void launch_march(const wv::StreamArgs<Real>& a, unsigned grid) {
-        hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
-                           stream_, a);
+    void launch_shape(const wv::StreamArgs<Real>& a, unsigned grid) {
+        if (plan_.variant == 2) {
+            hipLaunchKernelGGL((wv::stream_sweep_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                               stream_, a);
+        } else {
+            hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                               stream_, a);
+        }
     }
     template <int RY>
-    void launch_march_shape(const wv::StreamArgs<Real>& a, unsigned grid) {
-        const int key = plan_.nwx * 10 + plan_.nwy;
-        switch (key) {
-            case 11: launch_march<RY, 1, 1>(a, grid); break;
-            case 12: launch_march<RY, 1, 2>(a, grid); break;
-            case 14: launch_march<RY, 1, 4>(a, grid); break;
-            case 21: launch_march<RY, 2, 1>(a, grid); break;
-            case 22: launch_march<RY, 2, 2>(a, grid); break;
-            case 24: launch_march<RY, 2, 4>(a, grid); break;
-            case 41: launch_march<RY, 4, 1>(a, grid); break;
-            case 42: launch_march<RY, 4, 2>(a, grid); break;
-            case 81: launch_march<RY, 8, 1>(a, grid); break;
-            default: launch_march<RY, 1, 4>(a, grid); break;
+    void launch_ry(const wv::StreamArgs<Real>& a, unsigned grid) {
+        switch (plan_.nwx * 10 + plan_.nwy) {
+            case 11: launch_shape<RY, 1, 1>(a, grid); break;
+            case 22: launch_shape<RY, 2, 2>(a, grid); break;
+            case 41: launch_shape<RY, 4, 1>(a, grid); break;
+            case 42: launch_shape<RY, 4, 2>(a, grid); break;
+            case 81: launch_shape<RY, 8, 1>(a, grid); break;
+            default: launch_shape<RY, 1, 4>(a, grid); break;
         }
     }
 
+    // the pressure update of planes [z0, z1)
     int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed) {
         if (z0 >= z1) return WV_OK;
-        constexpr int VX = 16 / (int)sizeof(Real);
-        constexpr int WX = 64 * VX;
         wv::StreamArgs<Real> a{};
         a.prev = prev;
         a.cur = cur;
@@ -327,23 +344,29 @@ public:
         a.cls_pitch = cls_pitch_;
         a.z_begin = z0;
         a.z_end = z1;
-        // z-chunking of this launch: the plan's chunk length, clipped to the range
-        a.zc = std::min(plan_.zc, z1 - z0);
         a.tiles_x = plan_.tiles_x;
         a.tiles_y = plan_.tiles_y;
-        a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
-        a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
-        a.tiles_per_xcd = (a.total_tiles + 7) / 8;
-        const unsigned grid = plan_.variant == 1 ? plan_.grid : (unsigned)a.tiles_per_xcd * 8u;
+        unsigned grid = plan_.grid;
+        if (plan_.variant == 2) {
+            a.stripe_rows = plan_.stripe_rows;
+            a.tiles_y_stripe = plan_.tiles_y_stripe;
+            a.passes = plan_.passes;
+            grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+        } else if (plan_.variant == 0) {
+            a.zc = std::min(plan_.zc, z1 - z0);
+            a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
+            a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
+            a.tiles_per_xcd = (a.total_tiles + 7) / 8;
+            grid = (unsigned)a.tiles_per_xcd * 8u;
+        }
         timed = timed && timing && ev_used_ + 2 <= (int)events_.size();
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
         if (plan_.variant == 1) {
             hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
+        } else if (plan_.ry == 2) {
+            launch_ry<2>(a, grid);
         } else {
-            switch (plan_.ry) {
-                case 2: launch_march_shape<2>(a, grid); break;
-                default: launch_march_shape<4>(a, grid); break;
-            }
+            launch_ry<4>(a, grid);
         }
         if (timed) {
             WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
@@ -756,6 +779,7 @@ void wv_default_options(wv_options* o) {
     o->precision = WV_PRECISION_F64;
     o->device = -1;
     o->flag_interval = 0;
+    o->stream_variant = 2;
 }
 
 int wv_create(const wv_mesh* mesh, const wv_options* options, wv_engine** out) {

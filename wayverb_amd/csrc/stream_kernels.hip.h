@@ -272,4 +272,152 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant 2: plane sweep with L2-resident z-reuse.
+//
+// Measured on MI355X (tools/stream_bench.hip, profiles/): HBM delivers ~6.5 TB/s to short-lived
+// workgroups that are dispatched in address order (the chip-wide set of in-flight addresses is
+// a few long contiguous runs), but only ~5.3 TB/s to thousands of long-lived waves that each
+// own a private stream -- which is what the z-march is.  This variant keeps the march's lane
+// layout (16 B per lane, DPP x-neighbours, one-load x-edges) but makes every wave short-lived:
+// a wave updates its WX x RY tile of ONE plane and exits.  The z-reuse of `cur` then has to
+// come from cache, so the work is laid out for the per-XCD L2 (4 MiB, private):
+//   - XCD k (= blockIdx % 8) owns y-stripe s = pass*8 + k, `stripe_rows` rows tall, and sweeps it
+//     through all planes; the three `cur` planes of a stripe (3 * stripe_rows * nx * 8 B) stay in
+//     that XCD's L2 while prev/next stream through it with the non-temporal hint;
+//   - all 8 XCDs advance through z together, so the chip-wide access front is 8 short runs
+//     per stream inside one plane.
+// `cur` is then fetched from HBM once per step (plus 2 halo rows per stripe).
+// ---------------------------------------------------------------------------------------------
+template <typename Real, int RY, int NWX, int NWY, int X = X_NT_STORE | X_NT_PREV>
+__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
+    using V = typename Vec16<Real>::type;
+    constexpr int VX = Vec16<Real>::N;
+    constexpr int WX = 64 * VX;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wx = wave % NWX, wy = wave / NWX;
+
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int per_plane = a.tiles_x * a.tiles_y_stripe;
+    const int tl = j % per_plane;
+    j /= per_plane;
+    const int nzr = a.z_end - a.z_begin;
+    const int z = a.z_begin + j % nzr;
+    const int pass = j / nzr;
+    const int stripe = pass * 8 + xcd;
+    const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
+
+    const int y_lo = stripe * a.stripe_rows;
+    const int y_hi = min(y_lo + a.stripe_rows, a.ny);
+    const int x0 = (tx * NWX + wx) * WX;
+    const int y0 = y_lo + (tyl * NWY + wy) * RY;
+    if (y0 >= y_hi || x0 >= a.nx) return;
+
+    const int xl = x0 + lane * VX;
+    const bool full = (x0 + WX <= a.nx);
+    const int64_t plane = (int64_t)a.nx * a.ny;
+
+    auto load_cur = [&](int y, int zz) -> V {
+        V v = (V)(Real(0));
+        if (y >= 0 && y < a.ny && zz >= 0 && zz < a.nz) {
+            const Real* p = a.cur + (zz * plane + (int64_t)y * a.nx + xl);
+            if (full) {
+                v = *reinterpret_cast<const V*>(p);
+            } else {
+#pragma unroll
+                for (int jx = 0; jx < VX; ++jx)
+                    if (xl + jx < a.nx) v[jx] = p[jx];
+            }
+        }
+        return v;
+    };
+
+    // ---- everything this tile needs, issued back to back
+    V below[RY], mid[RY + 2], above[RY], pv[RY];
+    uint32_t cl[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) above[r] = load_cur(y0 + r, z + 1);   // first touch: HBM
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        pv[r] = (V)(Real(0));
+        cl[r] = 0xAAu;
+        const int y = y0 + r;
+        if (y < y_hi) {
+            const Real* p = a.prev + (z * plane + (int64_t)y * a.nx + xl);
+            if (full) {
+                pv[r] = (X & X_NT_PREV) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
+                                        : *reinterpret_cast<const V*>(p);
+            } else {
+#pragma unroll
+                for (int jx = 0; jx < VX; ++jx)
+                    if (xl + jx < a.nx) pv[r][jx] = p[jx];
+            }
+            if (xl < a.nx) {
+                const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
+                cl[r] = (VX == 4) ? byte : ((byte >> ((lane & 1) * 4)) & 0xFu);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RY + 2; ++r) mid[r] = load_cur(y0 - 1 + r, z);  // L2 (loaded as z+1 one plane ago)
+    Real mid_e = 0;
+    {
+        const int r = lane & 31;
+        const int y = y0 + r;
+        if (r < RY && y < a.ny) {
+            const int xe = (lane < 32) ? x0 - 1 : x0 + WX;
+            if (xe >= 0 && xe < a.nx) mid_e = a.cur[z * plane + (int64_t)y * a.nx + xe];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, z - 1);     // L2 (two planes ago)
+
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int y = y0 + r;
+        if (y < y_hi) {
+            const V c0 = mid[r + 1];
+            const Real edge_l = read_lane(mid_e, r), edge_r = read_lane(mid_e, 32 + r);
+            V out;
+            bool skip_any = false;
+#pragma unroll
+            for (int jx = 0; jx < VX; ++jx) {
+                const Real left = (jx == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[jx - 1];
+                const Real right = (jx == VX - 1) ? lane_from_above(edge_r, c0[0]) : c0[jx + 1];
+                Real s = Real(0) + left;
+                s += right;
+                s += mid[r][jx];
+                s += mid[r + 2][jx];
+                s += below[r][jx];
+                s += above[r][jx];
+                s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
+                s -= pv[r][jx];
+                const uint32_t c = (cl[r] >> (2 * jx)) & 3u;
+                const Real o = (c & 1u) ? s : Real(0);
+                bad |= bad_bits(o);
+                out[jx] = o;
+                skip_any |= (c == CLS_BOUNDARY);
+            }
+            Real* q = a.prev + (z * plane + (int64_t)y * a.nx + xl);
+            if (full && !__any(skip_any)) {
+                if (X & X_NT_STORE) __builtin_nontemporal_store(out, reinterpret_cast<V*>(q));
+                else *reinterpret_cast<V*>(q) = out;
+            } else {
+#pragma unroll
+                for (int jx = 0; jx < VX; ++jx) {
+                    const uint32_t c = (cl[r] >> (2 * jx)) & 3u;
+                    if (xl + jx < a.nx && c != CLS_BOUNDARY) q[jx] = out[jx];
+                }
+            }
+        }
+    }
+    if (__any(bad != 0)) {
+        if (bad) atomicOr(a.flag, bad);
+    }
+}
+
 }  // namespace wv

@@ -146,7 +146,7 @@ class Engine:
     """One `run` worth of device state: the buffers of waveguide.h:43-76."""
 
     def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
-                 flag_interval=0, stream_variant=0):
+                 flag_interval=0, stream_variant=2):
         self.lib = load_library()
         self.mesh = mesh
         self.precision = precision
@@ -276,8 +276,8 @@ class Engine:
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
 
-    def set_stream_tuning(self, variant=0, rows_per_wave=0, waves_x=0, waves_y=0, z_chunks=0):
-        _check(self.lib.wv_set_stream_tuning(self.h, variant, rows_per_wave, waves_x, waves_y, z_chunks))
+    def set_stream_tuning(self, variant=2, rows_per_wave=0, waves_x=0, waves_y=0, knob=0):
+        _check(self.lib.wv_set_stream_tuning(self.h, variant, rows_per_wave, waves_x, waves_y, knob))
 
     # ---- slab communicator ------------------------------------------------------------------
     @staticmethod
