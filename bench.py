@@ -65,19 +65,29 @@ def cpu_baseline(args, elem):
     o = Oracle()
     o.step(prev, cur, mesh, bd, threads=cores)  # first touch
     prev, cur = cur, prev
+    # pick the thread count that is actually fastest on this host (SMT / NUMA make "all" a guess)
+    best = None
+    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+        t0 = time.perf_counter()
+        o.step(prev, cur, mesh, bd, threads=t)
+        prev, cur = cur, prev
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (t, dt)
+    threads = best[0]
     steps = 0
     t0 = time.perf_counter()
     while True:
-        assert o.step(prev, cur, mesh, bd, threads=cores) == 0
+        assert o.step(prev, cur, mesh, bd, threads=threads) == 0
         prev, cur = cur, prev
         steps += 1
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds and steps >= 2:
             break
     rate = mesh.num_nodes * steps / dt / 1e9
-    return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": cores, "kind": "port",
-            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d OpenMP threads (z-chunks)"
-                      % (nx, ny, nz, args.precision, steps, dt, cores)}
+    return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": threads, "kind": "port",
+            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d OpenMP threads over x-rows (host has %d logical cores)"
+                      % (nx, ny, nz, args.precision, steps, dt, threads, cores)}
 
 
 def main():
@@ -193,7 +203,7 @@ def main():
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "stream_march_kernel", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                     "kernel": "stream_sweep_kernel", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                      "alg_bytes_per_launch": alg_bytes,
                      "whole_step_frac": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }

@@ -130,13 +130,14 @@ bool SlabComm::wait_ghosts(hipStream_t compute, std::string* err) {
     return hip_ok(hipStreamWaitEvent(compute, ghosts_ready_, 0), "hipStreamWaitEvent", err);
 }
 
-bool SlabComm::exchange_faces(hipStream_t compute, void* field, size_t elem_size, int nx, int ny, int nz,
-                              std::string* err) {
+bool SlabComm::exchange_faces(hipStream_t compute, hipEvent_t also, void* field, size_t elem_size, int nx, int ny,
+                              int nz, std::string* err) {
     Rccl& r = rccl();
     const size_t plane_bytes = (size_t)nx * ny * elem_size;
     char* base = static_cast<char*>(field);
     if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
     if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
+    if (also && !hip_ok(hipStreamWaitEvent(stream_, also, 0), "hipStreamWaitEvent", err)) return false;
     if (has_lo_ || has_hi_) {
         if (!nccl_ok(r.group_start(), "ncclGroupStart", err)) return false;
         if (has_lo_) {

@@ -33,7 +33,8 @@ public:
     bool wait_ghosts(hipStream_t compute, std::string* err);
     // Faces of `field` (planes 1 and nz-2 when the matching ghost exists) are final on `compute`:
     // exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
-    bool exchange_faces(hipStream_t compute, void* field, size_t elem_size, int nx, int ny, int nz,
+    // `also` (may be null): a second event the exchange has to wait for (boundary-node stream).
+    bool exchange_faces(hipStream_t compute, hipEvent_t also, void* field, size_t elem_size, int nx, int ny, int nz,
                         std::string* err);
 
     int rank() const { return rank_; }

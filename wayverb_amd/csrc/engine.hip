@@ -112,6 +112,10 @@ public:
         WV_HIP(hipGetDevice(&device_));
         WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        WV_HIP(hipStreamCreateWithFlags(&bnd_stream_, hipStreamNonBlocking));
+        WV_HIP(hipEventCreateWithFlags(&ev_inputs_ready_, hipEventDisableTiming));
+        WV_HIP(hipEventCreateWithFlags(&ev_boundary_done_, hipEventDisableTiming));
+        overlap_boundary_ = env_int("WV_BOUNDARY_OVERLAP", 0) != 0;  // measured: concurrency costs the sweep more than it hides
 
         // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
         field_bytes_ = n_nodes_ * sizeof(Real);
@@ -375,7 +379,7 @@ public:
         return WV_OK;
     }
 
-    int launch_boundary(Real* prev, const Real* cur, int* flag) {
+    int launch_boundary(Real* prev, const Real* cur, int* flag, hipStream_t on) {
         if (!n_entries_) return WV_OK;
         wv::BoundaryArgs<Real> b{};
         b.prev = prev;
@@ -397,7 +401,7 @@ public:
         b.z_end = z_end_;
         b.courant = courant_;
         b.courant_sq = courant_sq_;
-        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n_entries_ + 255) / 256), dim3(256), 0, stream_, b);
+        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n_entries_ + 255) / 256), dim3(256), 0, on, b);
         return WV_OK;
     }
 
@@ -428,20 +432,34 @@ public:
             pp.n_recv = n_recv_;
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
+        // The boundary kernel and the streaming kernel write disjoint nodes of `prev` and only read
+        // `cur`, so they run concurrently: boundary nodes on their own stream, fenced by two events
+        // per step (inputs ready -> boundary; boundary done -> next step / halo exchange).
+        hipStream_t bstream = overlap_boundary_ && n_entries_ ? bnd_stream_ : stream_;
+        if (bstream != stream_) {
+            WV_HIP(hipEventRecord(ev_inputs_ready_, stream_));
+            WV_HIP(hipStreamWaitEvent(bstream, ev_inputs_ready_, 0));
+        }
         if (comm_) {
             // slab faces first, so that their exchange overlaps the interior update
             const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
             const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+            if ((rc = launch_boundary(prev, cur, flag, bstream))) return rc;
+            if (bstream != stream_) WV_HIP(hipEventRecord(ev_boundary_done_, bstream));
             if ((rc = launch_stream(prev, cur, flag, z_begin_, zi0, false))) return rc;
             if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
-            if ((rc = launch_boundary(prev, cur, flag))) return rc;
             WV_HIP(hipGetLastError());
-            if (!comm_->exchange_faces(stream_, prev, sizeof(Real), nx_, ny_, nz_, &cerr)) return fail(WV_E_COMM, cerr);
+            if (!comm_->exchange_faces(stream_, bstream != stream_ ? ev_boundary_done_ : nullptr, prev, sizeof(Real),
+                                       nx_, ny_, nz_, &cerr))
+                return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
         } else {
+            if ((rc = launch_boundary(prev, cur, flag, bstream))) return rc;
+            if (bstream != stream_) WV_HIP(hipEventRecord(ev_boundary_done_, bstream));
             if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
-            if ((rc = launch_boundary(prev, cur, flag))) return rc;
         }
+        // whatever follows on the main stream (next step, flag copy, field reads) sees both kernels
+        if (bstream != stream_) WV_HIP(hipStreamWaitEvent(stream_, ev_boundary_done_, 0));
         WV_HIP(hipGetLastError());
         return WV_OK;
     }
@@ -692,6 +710,7 @@ public:
 
     int synchronize() override {
         WV_HIP(hipStreamSynchronize(stream_));
+        WV_HIP(hipStreamSynchronize(bnd_stream_));
         WV_HIP(hipStreamSynchronize(comm_stream_));
         return WV_OK;
     }
@@ -714,6 +733,7 @@ private:
     void release() {
         comm_.reset();
         if (stream_) (void)hipStreamSynchronize(stream_);
+        if (bnd_stream_) (void)hipStreamSynchronize(bnd_stream_);
         for (auto& e : events_) (void)hipEventDestroy(e);
         events_.clear();
         for (int i = 0; i < 2; ++i)
@@ -724,6 +744,9 @@ private:
         if (flags_host_) (void)hipHostFree(flags_host_);
         if (stream_) (void)hipStreamDestroy(stream_);
         if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+        if (bnd_stream_) (void)hipStreamDestroy(bnd_stream_);
+        if (ev_inputs_ready_) (void)hipEventDestroy(ev_inputs_ready_);
+        if (ev_boundary_done_) (void)hipEventDestroy(ev_boundary_done_);
     }
 
     wv_options opt_{};
@@ -746,7 +769,9 @@ private:
     int* flags_host_ = nullptr;
     void* scratch_ = nullptr;
     Real courant_ = 0, courant_sq_ = 0;
-    hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
+    hipStream_t stream_ = nullptr, comm_stream_ = nullptr, bnd_stream_ = nullptr;
+    hipEvent_t ev_inputs_ready_ = nullptr, ev_boundary_done_ = nullptr;
+    bool overlap_boundary_ = false;
     StreamPlan plan_;
     int tune_variant_ = -1, tune_ry_ = 0, tune_nwx_ = 0, tune_nwy_ = 0, tune_zchunks_ = 0;
     std::vector<hipEvent_t> events_;
