@@ -1,0 +1,671 @@
+// wayverb_amd/waveguide.h -- C++14 host mirror of wayverb's `waveguide::run` interface over the
+// C ABI of wayverb_amd.h.  Header only; link against libwayverb_amd.so.
+//
+// Same names, argument meaning and error behaviour as the reference (paths relative to the
+// reference repository root):
+//   waveguide::run<pre, post>                 src/waveguide/include/waveguide/waveguide.h:36-126
+//   preprocessor::hard_source / soft_source   include/waveguide/preprocessor/{hard,soft}_source.h
+//   preprocessor::gaussian                    src/waveguide/src/preprocessor/gaussian.cpp:12-53
+//   postprocessor::node / directional_receiver  src/waveguide/src/postprocessor/*.cpp
+//   detail::canonical_impl / canonical        include/waveguide/canonical.h:29-88,100-127
+//   mesh / vectors / mesh_descriptor          include/waveguide/{mesh,setup,mesh_descriptor}.h
+//   core::read_value / write_value / ...      src/core/include/core/cl/common.h:24-57
+//   core::exceptions::value_is_nan / _inf     src/core/include/core/exceptions.h:9-30
+//
+// What differs, deliberately:
+//   - step callbacks receive `waveguide::queue&` / `waveguide::buffer&` handles instead of
+//     cl::CommandQueue / cl::Buffer.  Callers written with generic lambdas
+//     (`[](auto& queue, const auto& buffer, auto step)`, as every call site in the reference is)
+//     compile unchanged; the core:: helper overloads below accept the handles.
+//   - `compute_context` carries a HIP device ordinal.  `run` is templated on the context type and
+//     ignores any other context (e.g. the OpenCL one the ray tracer keeps using).
+//   - `run_device` / `canonical` keep the source and the receivers on the GPU: no per-step PCIe
+//     round trip.  `run` with arbitrary callbacks synchronises every step, like the
+//     reference does.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <experimental/optional>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../wayverb_amd.h"
+
+namespace wayverb {
+namespace core {
+
+namespace exceptions {  // src/core/include/core/exceptions.h:9-30
+class exception : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+class suspicious_value : public exception {
+public:
+    using exception::exception;
+};
+class value_is_nan final : public suspicious_value {
+public:
+    using suspicious_value::suspicious_value;
+};
+class value_is_inf final : public suspicious_value {
+public:
+    using suspicious_value::suspicious_value;
+};
+}  // namespace exceptions
+
+struct environment final {  // src/core/include/core/environment.h:6-13
+    double speed_of_sound{340.0};
+    double acoustic_impedance{400.0};
+};
+constexpr double get_ambient_density(const environment& s) { return s.acoustic_impedance / s.speed_of_sound; }
+
+/// Stand-in for core::compute_context (src/core/include/core/cl/common.h:13-22): which HIP device.
+struct compute_context final {
+    int device{-1};
+};
+
+template <typename T, typename Ret = typename T::return_type>
+class callback_accumulator final {  // src/core/include/core/callback_accumulator.h:8-28
+public:
+    callback_accumulator(T t) : postprocessor_{std::move(t)} {}
+    template <typename... Ts>
+    callback_accumulator(Ts&&... ts) : postprocessor_{std::forward<Ts>(ts)...} {}
+    template <typename... Ts>
+    void operator()(Ts&&... ts) {
+        output_.emplace_back(postprocessor_(std::forward<Ts>(ts)...));
+    }
+    const std::vector<Ret>& get_output() const { return output_; }
+
+private:
+    std::vector<Ret> output_;
+    T postprocessor_;
+};
+template <typename T>
+auto make_callback_accumulator(T t) {
+    return callback_accumulator<T>{std::move(t)};
+}
+
+}  // namespace core
+
+namespace waveguide {
+
+// ---- engine plumbing ----------------------------------------------------------------------------
+class engine_error : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
+namespace detail {
+inline void check(int rc) {
+    if (rc != WV_OK) throw engine_error(std::string("wayverb_amd: ") + wv_last_error());
+}
+struct engine_deleter {
+    void operator()(wv_engine* e) const { wv_destroy(e); }
+};
+using engine_ptr = std::unique_ptr<wv_engine, engine_deleter>;
+
+/// waveguide.h:102-118 -- the same exception types and messages
+inline void throw_for_flag(int flag) {
+    if (flag & WV_FLAG_INF) throw core::exceptions::value_is_inf("Pressure value is inf, check filter coefficients.");
+    if (flag & WV_FLAG_NAN) throw core::exceptions::value_is_nan("Pressure value is nan, check filter coefficients.");
+    if (flag & WV_FLAG_OUTSIDE_MESH) throw std::runtime_error("Tried to read non-existant node.");
+    if (flag & WV_FLAG_SUSPICIOUS_BOUNDARY) throw std::runtime_error("Suspicious boundary read.");
+}
+}  // namespace detail
+
+/// What a step callback sees instead of cl::CommandQueue (hard_source.h:17, directional_receiver.h:36).
+class queue final {
+public:
+    explicit queue(wv_engine* e) : e_{e} {}
+    wv_engine* engine() const { return e_; }
+
+private:
+    wv_engine* e_;
+};
+/// What a step callback sees instead of cl::Buffer: one of the engine's two pressure fields.
+class buffer final {
+public:
+    buffer(wv_engine* e, int which, size_t items) : e_{e}, which_{which}, items_{items} {}
+    wv_engine* engine() const { return e_; }
+    int which() const { return which_; }
+    size_t items() const { return items_; }
+
+private:
+    wv_engine* e_;
+    int which_;
+    size_t items_;
+};
+
+}  // namespace waveguide
+
+namespace core {  // the buffer helpers of src/core/include/core/cl/common.h:29-57, on the handles
+
+template <typename T>
+size_t items_in_buffer(const waveguide::buffer& b) {
+    return b.items();
+}
+template <typename T>
+T read_value(waveguide::queue&, const waveguide::buffer& b, size_t index) {
+    double v = 0;
+    waveguide::detail::check(wv_read_value(b.engine(), b.which(), index, &v));
+    return static_cast<T>(v);
+}
+template <typename T>
+void write_value(waveguide::queue&, waveguide::buffer& b, size_t index, T val) {
+    waveguide::detail::check(wv_write_value(b.engine(), b.which(), index, static_cast<double>(val)));
+}
+inline void read_buffer_into(const waveguide::buffer& b, float* dst) {
+    waveguide::detail::check(wv_read_field(b.engine(), b.which(), dst, 4));
+}
+inline void read_buffer_into(const waveguide::buffer& b, double* dst) {
+    waveguide::detail::check(wv_read_field(b.engine(), b.which(), dst, 8));
+}
+template <typename T>
+std::vector<T> read_from_buffer(waveguide::queue&, const waveguide::buffer& b) {
+    std::vector<T> ret(b.items());
+    read_buffer_into(b, ret.data());
+    return ret;
+}
+/// cl::copy(queue, begin, end, buffer) as preprocessor/gaussian.cpp:50 uses it
+template <typename It>
+void copy(waveguide::queue&, It begin, It end, waveguide::buffer& b) {
+    using T = typename std::iterator_traits<It>::value_type;
+    std::vector<T> tmp(begin, end);
+    if (tmp.size() != b.items()) throw std::runtime_error("copy: size does not match the buffer");
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "float or double field");
+    waveguide::detail::check(wv_write_field(b.engine(), b.which(), tmp.data(), (int)sizeof(T)));
+}
+
+}  // namespace core
+
+namespace waveguide {
+
+// ---- mesh containers ----------------------------------------------------------------------------
+using condensed_node = wv_condensed_node;                  // cl/structs.h:19-22
+using coefficients_canonical = wv_coefficients_canonical;  // cl/filter_structs.h:65-66
+constexpr uint32_t no_neighbor = ~uint32_t{0};             // cl/utils.h:29
+
+template <size_t N>
+struct boundary_index_array final {  // cl/boundary_index_array.h:8-11
+    uint32_t array[N];
+};
+struct boundary_index_data final {  // boundary_coefficient_finder.h:36-40
+    std::vector<boundary_index_array<1>> b1;
+    std::vector<boundary_index_array<2>> b2;
+    std::vector<boundary_index_array<3>> b3;
+};
+
+struct vec3 final {
+    float x, y, z;
+};
+struct dvec3 final {
+    double x, y, z;
+};
+struct ivec3 final {
+    int x, y, z;
+};
+
+struct mesh_descriptor final {  // mesh_descriptor.h:14-20
+    vec3 min_corner;
+    ivec3 dimensions;
+    float spacing;
+};
+
+inline size_t compute_index(const mesh_descriptor& d, const ivec3& pos) {  // mesh_descriptor.cpp:7-10
+    return (size_t)pos.x + (size_t)pos.y * d.dimensions.x + (size_t)pos.z * d.dimensions.x * d.dimensions.y;
+}
+inline ivec3 compute_locator(const mesh_descriptor& d, size_t index) {  // mesh_descriptor.cpp:16-20
+    const size_t x = index % d.dimensions.x, q = index / d.dimensions.x;
+    return ivec3{(int)x, (int)(q % d.dimensions.y), (int)((q / d.dimensions.y) % d.dimensions.z)};
+}
+inline ivec3 compute_locator(const mesh_descriptor& d, const vec3& v) {  // :22-25, glm::round
+    return ivec3{(int)std::round((v.x - d.min_corner.x) / d.spacing), (int)std::round((v.y - d.min_corner.y) / d.spacing),
+                 (int)std::round((v.z - d.min_corner.z) / d.spacing)};
+}
+inline size_t compute_index(const mesh_descriptor& d, const vec3& pos) {
+    return compute_index(d, compute_locator(d, pos));
+}
+inline vec3 compute_position(const mesh_descriptor& d, const ivec3& l) {  // :27-30
+    return vec3{d.min_corner.x + l.x * d.spacing, d.min_corner.y + l.y * d.spacing, d.min_corner.z + l.z * d.spacing};
+}
+inline vec3 compute_position(const mesh_descriptor& d, size_t index) {
+    return compute_position(d, compute_locator(d, index));
+}
+inline std::array<uint32_t, 6> compute_neighbors(const mesh_descriptor& d, size_t index) {  // :36-63
+    const ivec3 l = compute_locator(d, index);
+    const ivec3 n[6] = {{l.x - 1, l.y, l.z}, {l.x + 1, l.y, l.z}, {l.x, l.y - 1, l.z},
+                        {l.x, l.y + 1, l.z}, {l.x, l.y, l.z - 1}, {l.x, l.y, l.z + 1}};
+    std::array<uint32_t, 6> ret;
+    for (int i = 0; i < 6; ++i) {
+        const bool inside = n[i].x >= 0 && n[i].y >= 0 && n[i].z >= 0 && n[i].x < d.dimensions.x &&
+                            n[i].y < d.dimensions.y && n[i].z < d.dimensions.z;
+        ret[i] = inside ? (uint32_t)compute_index(d, n[i]) : no_neighbor;
+    }
+    return ret;
+}
+inline double compute_sample_rate(const mesh_descriptor& d, double speed_of_sound) {  // :72-74, config.cpp:19-21
+    return 1.0 / (d.spacing / (speed_of_sound * std::sqrt(3.0)));
+}
+inline size_t compute_num_nodes(const mesh_descriptor& d) {
+    return (size_t)d.dimensions.x * d.dimensions.y * d.dimensions.z;
+}
+
+constexpr bool is_inside(const condensed_node& c) { return c.boundary_type & WV_ID_INSIDE; }  // setup.h:21-23
+
+class vectors final {  // setup.h:27-48, setup.cpp:7-50
+public:
+    vectors(std::vector<condensed_node> nodes, std::vector<coefficients_canonical> coefficients,
+            boundary_index_data boundary_index_data)
+            : condensed_nodes_(std::move(nodes)),
+              coefficients_(std::move(coefficients)),
+              boundary_index_data_(std::move(boundary_index_data)) {}
+
+    const std::vector<condensed_node>& get_condensed_nodes() const { return condensed_nodes_; }
+    const std::vector<coefficients_canonical>& get_coefficients() const { return coefficients_; }
+    const boundary_index_data& get_boundary_index_data() const { return boundary_index_data_; }
+
+    void set_coefficients(coefficients_canonical c) { std::fill(coefficients_.begin(), coefficients_.end(), c); }
+    void set_coefficients(std::vector<coefficients_canonical> c) {
+        if (c.size() != coefficients_.size())
+            throw std::runtime_error(
+                    "Size of new coefficients vector must be equal to the existing one in order to maintain object "
+                    "invariants.");
+        coefficients_ = std::move(c);
+    }
+
+private:
+    std::vector<condensed_node> condensed_nodes_;
+    std::vector<coefficients_canonical> coefficients_;
+    boundary_index_data boundary_index_data_;
+};
+
+class mesh final {  // mesh.h:12-26
+public:
+    mesh(mesh_descriptor descriptor, vectors vectors) : descriptor_(descriptor), vectors_(std::move(vectors)) {}
+    const mesh_descriptor& get_descriptor() const { return descriptor_; }
+    const vectors& get_structure() const { return vectors_; }
+    void set_coefficients(coefficients_canonical c) { vectors_.set_coefficients(c); }
+    void set_coefficients(std::vector<coefficients_canonical> c) { vectors_.set_coefficients(std::move(c)); }
+
+private:
+    mesh_descriptor descriptor_;
+    vectors vectors_;
+};
+inline bool is_inside(const mesh& m, size_t node_index) {
+    return is_inside(m.get_structure().get_condensed_nodes()[node_index]);
+}
+
+/// fitted_boundary.h:21-48
+inline coefficients_canonical to_impedance_coefficients(const coefficients_canonical& c) {
+    coefficients_canonical ret{};
+    for (int i = 0; i < 7; ++i) {
+        ret.b[i] = c.a[i] + c.b[i];
+        ret.a[i] = c.a[i] - c.b[i];
+    }
+    if (ret.a[0] != 0) {
+        const double norm = 1.0 / ret.a[0];
+        for (int i = 0; i < 7; ++i) {
+            ret.b[i] *= norm;
+            ret.a[i] *= norm;
+        }
+    }
+    return ret;
+}
+/// fitted_boundary.h:72-75 (core/surfaces.h:25-33: reflectance = sqrt(1 - absorption))
+inline coefficients_canonical to_flat_coefficients(double absorption) {
+    coefficients_canonical c{};
+    c.b[0] = std::sqrt(1.0 - absorption);
+    c.a[0] = 1.0;
+    return to_impedance_coefficients(c);
+}
+
+/// calibration.h:20-31
+inline double rectilinear_calibration_factor(double grid_spacing, double acoustic_impedance) {
+    return std::sqrt(acoustic_impedance / (4 * M_PI)) / (0.3405 * grid_spacing);
+}
+
+/// Synthetic box mesh: every wall takes coefficient 0.
+inline mesh make_box_mesh(int nx, int ny, int nz, float spacing, coefficients_canonical wall) {
+    std::vector<condensed_node> nodes((size_t)nx * ny * nz);
+    uint64_t counts[3] = {0, 0, 0};
+    if (wv_make_box_nodes(nx, ny, nz, 0, nz, 0, nz, nodes.data(), counts) != WV_OK)
+        throw std::runtime_error("box needs at least 5 nodes per axis");
+    boundary_index_data bid;
+    bid.b1.assign(counts[0], boundary_index_array<1>{{0}});
+    bid.b2.assign(counts[1], boundary_index_array<2>{{0, 0}});
+    bid.b3.assign(counts[2], boundary_index_array<3>{{0, 0, 0}});
+    return mesh{mesh_descriptor{vec3{0, 0, 0}, ivec3{nx, ny, nz}, spacing},
+                vectors{std::move(nodes), std::vector<coefficients_canonical>{wall}, std::move(bid)}};
+}
+
+// ---- engine construction ------------------------------------------------------------------------
+namespace detail {
+template <typename Context>
+int device_of(const Context&) {
+    return -1;
+}
+inline int device_of(const core::compute_context& cc) { return cc.device; }
+
+template <typename Context>
+engine_ptr make_engine(const Context& cc, const mesh& m, int precision) {
+    const auto& s = m.get_structure();
+    const auto& bid = s.get_boundary_index_data();
+    wv_mesh wm{};
+    wm.nx = m.get_descriptor().dimensions.x;
+    wm.ny = m.get_descriptor().dimensions.y;
+    wm.nz = m.get_descriptor().dimensions.z;
+    wm.nodes = s.get_condensed_nodes().data();
+    wm.coefficients = s.get_coefficients().data();
+    wm.num_coefficients = (uint32_t)s.get_coefficients().size();
+    wm.boundary_indices_1 = bid.b1.empty() ? nullptr : bid.b1.front().array;
+    wm.boundary_indices_2 = bid.b2.empty() ? nullptr : bid.b2.front().array;
+    wm.boundary_indices_3 = bid.b3.empty() ? nullptr : bid.b3.front().array;
+    wm.num_boundary_1 = bid.b1.size();
+    wm.num_boundary_2 = bid.b2.size();
+    wm.num_boundary_3 = bid.b3.size();
+    wv_options opt;
+    wv_default_options(&opt);
+    opt.precision = precision;
+    opt.device = device_of(cc);
+    wv_engine* raw = nullptr;
+    check(wv_create(&wm, &opt, &raw));
+    return engine_ptr(raw);
+}
+}  // namespace detail
+
+/// Pressure storage: WV_PRECISION_F32 reproduces the reference's cl_float fields bit for bit,
+/// WV_PRECISION_F64 is the double-precision engine of the north star.  Process-wide default.
+inline int& default_precision() {
+    static int p = WV_PRECISION_F32;
+    return p;
+}
+
+// ---- run: arbitrary step callbacks (waveguide.h:36-126) -------------------------------------------
+template <typename Context, typename step_preprocessor, typename step_postprocessor>
+size_t run(const Context& cc, const mesh& mesh, step_preprocessor&& pre, step_postprocessor&& post,
+           const std::atomic_bool& keep_going) {
+    auto engine = detail::make_engine(cc, mesh, default_precision());
+    const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
+    queue q{engine.get()};
+    buffer current{engine.get(), WV_BUF_CURRENT, num_nodes};  // the handle follows the swaps
+    size_t step = 0;
+    for (; pre(q, current, step) && keep_going; ++step) {
+        int32_t flag = 0;
+        detail::check(wv_step(engine.get(), &flag));
+        detail::throw_for_flag(flag);
+        post(q, current, step);
+        detail::check(wv_swap(engine.get()));
+    }
+    return step;
+}
+
+// ---- step pre-processors --------------------------------------------------------------------------
+namespace preprocessor {
+
+template <typename It>
+class hard_source final {  // preprocessor/hard_source.h:9-29
+public:
+    hard_source(size_t node, It begin, It end) : node_{node}, begin_{begin}, end_{end} {}
+    template <typename Q, typename B>
+    bool operator()(Q& q, B& b, size_t) {
+        if (begin_ == end_) return false;
+        core::write_value(q, b, node_, *begin_++);
+        return true;
+    }
+    size_t get_node() const { return node_; }
+    It begin() const { return begin_; }
+    It end() const { return end_; }
+
+private:
+    size_t node_;
+    It begin_, end_;
+};
+template <typename It>
+auto make_hard_source(size_t node, It begin, It end) {
+    return hard_source<It>{node, begin, end};
+}
+
+template <typename It>
+class soft_source final {  // preprocessor/soft_source.h:9-31
+public:
+    soft_source(size_t node, It begin, It end) : node_{node}, begin_{begin}, end_{end} {}
+    template <typename Q, typename B>
+    bool operator()(Q& q, B& b, size_t) {
+        if (begin_ == end_) return false;
+        const auto current_pressure = core::read_value<float>(q, b, node_);
+        core::write_value(q, b, node_, current_pressure + *begin_++);
+        return true;
+    }
+    size_t get_node() const { return node_; }
+    It begin() const { return begin_; }
+    It end() const { return end_; }
+
+private:
+    size_t node_;
+    It begin_, end_;
+};
+template <typename It>
+auto make_soft_source(size_t node, It begin, It end) {
+    return soft_source<It>{node, begin, end};
+}
+
+class gaussian final {  // src/preprocessor/gaussian.cpp:12-53
+public:
+    static float compute(const vec3& x, float sdev) {
+        const double len2 = (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z;
+        return (float)(std::exp(-len2 / (2 * std::pow(sdev, 2))) / std::pow(sdev * std::sqrt(2 * M_PI), 3));
+    }
+    gaussian(const mesh_descriptor& descriptor, const vec3& centre_pos, float sdev, size_t steps)
+            : descriptor_(descriptor), centre_pos_(centre_pos), sdev_{sdev}, steps_{steps} {}
+    template <typename Q, typename B>
+    bool operator()(Q& q, B& b, size_t step) const {
+        if (step == steps_) return false;
+        if (step == 0) {
+            const size_t nodes = core::items_in_buffer<float>(b);
+            std::vector<float> pressures;
+            pressures.reserve(nodes);
+            for (size_t i = 0; i != nodes; ++i) {
+                const vec3 p = compute_position(descriptor_, i);
+                pressures.emplace_back(compute(vec3{p.x - centre_pos_.x, p.y - centre_pos_.y, p.z - centre_pos_.z}, sdev_));
+            }
+            core::copy(q, pressures.begin(), pressures.end(), b);
+        }
+        return true;
+    }
+
+private:
+    mesh_descriptor descriptor_;
+    vec3 centre_pos_;
+    float sdev_;
+    size_t steps_;
+};
+
+}  // namespace preprocessor
+
+// ---- step post-processors -------------------------------------------------------------------------
+namespace postprocessor {
+
+class node final {  // src/postprocessor/node.cpp:11-20
+public:
+    explicit node(size_t output_node) : output_node_{output_node} {}
+    using return_type = float;
+    template <typename Q, typename B>
+    return_type operator()(Q& q, const B& b, size_t) const {
+        return core::read_value<float>(q, b, output_node_);
+    }
+    size_t get_output_node() const { return output_node_; }
+
+private:
+    size_t output_node_;
+};
+
+class directional_receiver final {  // src/postprocessor/directional_receiver.cpp:10-69
+public:
+    directional_receiver(const mesh_descriptor& md, double sample_rate, double ambient_density, size_t output_node)
+            : mesh_spacing_{md.spacing},
+              sample_rate_{sample_rate},
+              ambient_density_{ambient_density},
+              output_node_{output_node},
+              surrounding_nodes_(compute_neighbors(md, output_node)) {
+        for (const auto& i : surrounding_nodes_)
+            if (i == no_neighbor)
+                throw std::runtime_error(
+                        "Can't place directional_receiver at this node as it is adjacent to a boundary.");
+    }
+    struct output final {
+        vec3 intensity;
+        float pressure;
+    };
+    using return_type = output;
+
+    /// the arithmetic of directional_receiver.cpp:29-67 on 7 already-read float pressures
+    return_type accumulate(float pressure, const float* neighbours6) {
+        float surrounding[6];
+        for (int i = 0; i < 6; ++i) surrounding[i] = (float)((neighbours6[i] - pressure) / mesh_spacing_);
+        const dvec3 m{(surrounding[1] - surrounding[0]) * 0.5, (surrounding[3] - surrounding[2]) * 0.5,
+                      (surrounding[5] - surrounding[4]) * 0.5};
+        const double k = ambient_density_ * sample_rate_;
+        velocity_.x -= m.x / k;
+        velocity_.y -= m.y / k;
+        velocity_.z -= m.z / k;
+        const double p = static_cast<double>(pressure);
+        return {vec3{(float)(velocity_.x * p), (float)(velocity_.y * p), (float)(velocity_.z * p)}, pressure};
+    }
+    template <typename Q, typename B>
+    return_type operator()(Q& q, const B& b, size_t) {
+        const auto pressure = core::read_value<float>(q, b, output_node_);
+        float n[6];
+        for (int i = 0; i < 6; ++i) n[i] = core::read_value<float>(q, b, surrounding_nodes_[i]);
+        return accumulate(pressure, n);
+    }
+    size_t get_output_node() const { return output_node_; }
+    const std::array<uint32_t, 6>& get_surrounding_nodes() const { return surrounding_nodes_; }
+
+private:
+    double mesh_spacing_, sample_rate_, ambient_density_;
+    size_t output_node_;
+    std::array<uint32_t, 6> surrounding_nodes_;
+    dvec3 velocity_{0, 0, 0};
+};
+
+}  // namespace postprocessor
+
+// ---- run_device: single-node source + node receivers, device resident -----------------------------
+/// Equivalent to `run(cc, mesh, hard/soft_source(node, begin, end), <read `receivers` each step>,
+/// keep_going)`, without a host round trip per step.  `on_batch(first_step, n_steps, samples)` is
+/// called with samples[n_steps][receivers.size()] (doubles holding the field's own precision)
+/// every `batch` steps; keep_going is polled at the same cadence.  Returns completed steps.
+enum class source_kind { hard = WV_SOURCE_HARD, soft = WV_SOURCE_SOFT };
+
+template <typename Context, typename It, typename OnBatch>
+size_t run_device(const Context& cc, const mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
+                  const std::vector<uint64_t>& receivers, OnBatch&& on_batch, const std::atomic_bool& keep_going,
+                  size_t batch = 256) {
+    auto engine = detail::make_engine(cc, mesh, default_precision());
+    std::vector<double> signal(begin, end);
+    detail::check(wv_set_source(engine.get(), (int)kind, source_node, signal.data(), signal.size()));
+    detail::check(wv_set_receivers(engine.get(), receivers.data(), (uint32_t)receivers.size()));
+    size_t done_total = 0;
+    std::vector<double> samples;
+    while (done_total < signal.size() && keep_going) {
+        const uint64_t want = std::min<uint64_t>(batch, signal.size() - done_total);
+        uint64_t done = 0;
+        int32_t flag = 0;
+        detail::check(wv_run(engine.get(), want, &done, &flag));
+        if (done) {
+            samples.resize((size_t)done * receivers.size());
+            detail::check(wv_fetch_receivers(engine.get(), done_total, done, samples.data()));
+            on_batch(done_total, (size_t)done, samples);
+        }
+        done_total += (size_t)done;
+        detail::throw_for_flag(flag);
+        if (done < want) break;
+    }
+    return done_total;
+}
+
+// ---- canonical (canonical.h:29-88, 100-127) --------------------------------------------------------
+struct band final {  // bandpass_band.h:11-15
+    std::vector<postprocessor::directional_receiver::output> directional;
+    double sample_rate;
+};
+struct bandpass_band final {  // bandpass_band.h:17-20
+    waveguide::band band;
+    double valid_hz_min, valid_hz_max;
+};
+struct single_band_parameters final {  // simulation_parameters.h:9-16
+    double cutoff;
+    double usable_portion;
+};
+constexpr double compute_sampling_frequency(double cutoff, double usable_portion) {  // :65-68
+    return cutoff / (0.25 * usable_portion);
+}
+
+namespace detail {
+/// callback(step, ideal_steps) fires once per completed step, in order.
+template <typename Context, typename Callback>
+std::experimental::optional<band> canonical_impl(const Context& cc, const mesh& mesh, double simulation_time,
+                                                 const vec3& source, const vec3& receiver,
+                                                 const core::environment& environment,
+                                                 const std::atomic_bool& keep_going, Callback&& callback) {
+    const auto sample_rate = compute_sample_rate(mesh.get_descriptor(), environment.speed_of_sound);
+    const auto compute_mesh_index = [&](const vec3& pt) {
+        const auto ret = compute_index(mesh.get_descriptor(), pt);
+        if (ret >= mesh.get_structure().get_condensed_nodes().size() || !waveguide::is_inside(mesh, ret))
+            throw std::runtime_error{"Source/receiver node position appears to be outside mesh."};
+        return ret;
+    };
+    const size_t ideal_steps = (size_t)std::ceil(sample_rate * simulation_time);
+    std::vector<float> input(ideal_steps, 0.0f);
+    if (!input.empty())
+        input.front() = (float)rectilinear_calibration_factor(mesh.get_descriptor().spacing,
+                                                              environment.acoustic_impedance);
+    const size_t receiver_index = compute_mesh_index(receiver);
+    postprocessor::directional_receiver dr{mesh.get_descriptor(), sample_rate, get_ambient_density(environment),
+                                           receiver_index};
+    std::vector<uint64_t> nodes{receiver_index};
+    for (auto n : dr.get_surrounding_nodes()) nodes.push_back(n);
+
+    band ret{{}, sample_rate};
+    ret.directional.reserve(ideal_steps);
+    const size_t steps = run_device(
+            cc, mesh, source_kind::hard, compute_mesh_index(source), input.begin(), input.end(), nodes,
+            [&](size_t first, size_t n, const std::vector<double>& s) {
+                for (size_t i = 0; i < n; ++i) {
+                    float nb[6];
+                    for (int k = 0; k < 6; ++k) nb[k] = (float)s[i * 7 + 1 + k];
+                    ret.directional.emplace_back(dr.accumulate((float)s[i * 7], nb));
+                    callback(first + i, ideal_steps);
+                }
+            },
+            keep_going);
+    if (steps != ideal_steps) return std::experimental::nullopt;
+    return ret;
+}
+}  // namespace detail
+
+/// canonical.h:100-127 for an already-built mesh (the reference passes voxels_and_mesh and uses
+/// only its .mesh member here).
+template <typename Context, typename PressureCallback>
+std::experimental::optional<std::vector<bandpass_band>> canonical(
+        const Context& cc, const mesh& mesh, const vec3& source, const vec3& receiver,
+        const core::environment& environment, const single_band_parameters& sim_params, double simulation_time,
+        const std::atomic_bool& keep_going, PressureCallback&& pressure_callback) {
+    if (auto ret = detail::canonical_impl(cc, mesh, simulation_time, source, receiver, environment, keep_going,
+                                          pressure_callback)) {
+        return std::vector<bandpass_band>{bandpass_band{std::move(*ret), 0.0, sim_params.cutoff}};
+    }
+    return std::experimental::nullopt;
+}
+
+}  // namespace waveguide
+}  // namespace wayverb
