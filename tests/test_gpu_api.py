@@ -136,3 +136,49 @@ def test_exhausted_source_ends_the_run(built_library):
     done, flag = eng.run_steps(100)
     assert (done, flag) == (5, 0)
     eng.close()
+
+
+def test_rccl_halo_exchange_loopback_on_one_gpu(built_library):
+    """The RCCL path on real hardware, as far as one GPU allows: a communicator of one rank whose
+    slab is its own neighbour on both sides (periodic in z).  Exercises dlopen'd RCCL, grouped
+    ncclSend/ncclRecv on the halo stream, the faces-first / interior-overlapped step and its
+    events.  Reference: a second engine without a communicator whose ghost planes are filled by
+    host copies before every step."""
+    nx, ny, nz = 160, 24, 12                     # planes 0 and nz-1 are ghosts
+    rng = np.random.default_rng(8)
+    nodes, counts = E.make_box_nodes(nx, ny, 64, z_begin=20, z_count=nz, number_from=21, number_to=20 + nz - 1)
+    coeffs = M.passive_peak_filter_coefficients(rng, 1)
+    mesh = M.Mesh((nx, ny, nz), nodes, coeffs, *[np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)])
+    live = (mesh.nodes["boundary_type"] != 0)
+    plane = nx * ny
+    f0 = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    f1 = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+
+    def periodic(f):
+        f = f.copy()
+        f[:plane] = f[(nz - 2) * plane:(nz - 1) * plane]
+        f[(nz - 1) * plane:] = f[plane:2 * plane]
+        return f
+
+    f0, f1 = periodic(f0), periodic(f1)
+    steps = 9
+    a = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True)
+    a.comm_init(E.Engine.comm_unique_id(), 0, 1)
+    a.write_field(f0, E.BUF_PREVIOUS)
+    a.write_field(f1, E.BUF_CURRENT)
+    done, flag = a.run_steps(steps)
+    assert (done, flag) == (steps, 0)
+    got = a.read_field(E.BUF_CURRENT)
+    a.close()
+
+    b = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True)
+    b.write_field(f0, E.BUF_PREVIOUS)
+    b.write_field(f1, E.BUF_CURRENT)
+    for _ in range(steps):
+        assert b.step() == 0
+        nxt = periodic(b.read_field(E.BUF_PREVIOUS))   # the freshly written field
+        b.write_field(nxt, E.BUF_PREVIOUS)
+        b.swap()
+    want = b.read_field(E.BUF_CURRENT)
+    b.close()
+    assert got.tobytes() == want.tobytes()

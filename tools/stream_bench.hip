@@ -272,6 +272,24 @@ int main(int argc, char** argv) {
 
     using namespace wv;
     constexpr int P = X_PRODUCT;
+    if (argc > 3 && std::string(argv[3]) == "prof2") {
+        constexpr int S2 = X_NT_STORE | X_NT_PREV;
+        run_sweep<4, 1, 4, S2>(c, "sweep", 16);
+        run_sweep<4, 1, 4, S2>(c, "sweep", 32);
+        run_sweep<4, 1, 4, S2>(c, "sweep", 64);
+        run_sweep<4, 1, 4, S2>(c, "sweep", 128);
+        run_sweep<4, 1, 4, S2 | X_NT_BELOW>(c, "nt_below", 32);
+        run_sweep<4, 1, 4, S2 | X_NT_BELOW>(c, "nt_below", 64);
+        run_sweep<4, 1, 4, S2 | X_NT_BELOW | X_NT_MID>(c, "nt_below_mid", 64);
+        run_sweep<4, 1, 4, S2 | X_NT_CUR>(c, "nt_above", 64);
+        run_sweep<4, 1, 4, 0>(c, "no_nt", 64);
+        run_sweep<4, 1, 4, X_NT_STORE>(c, "nt_store_only", 64);
+        run_sweep<4, 1, 4, X_NT_PREV>(c, "nt_prev_only", 64);
+        run_sweep<2, 1, 4, S2>(c, "sweep", 64);
+        run_sweep<4, 4, 1, S2>(c, "sweep", 64);
+        run_sweep<4, 8, 1, S2>(c, "sweep", 64);
+        return 0;
+    }
     if (argc > 3 && std::string(argv[3]) == "prof") {
         // short list for rocprofv3 --pmc passes
         double ms = time_ms(c, [&](double* p, double* q) {

@@ -180,6 +180,7 @@ struct SetupArgs {
     uint8_t* btype;
     uint32_t n1, n2, n3;
     int* status;                 // bit0: invalid boundary type, bit1: boundary_index out of range
+    int64_t owned_first, owned_end;  // node range of the planes this engine updates (ghosts excluded)
 };
 
 __device__ __forceinline__ uint32_t classify(int32_t t, int* dim_out) {
@@ -220,6 +221,9 @@ __global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) 
                     atomicOr(a.status, 1);
                     continue;
                 }
+                // ghost-plane boundary nodes belong to the neighbouring slab: classified (their
+                // type matters to the static checks) but never entered in this engine's lists
+                if (a.first + local < a.owned_first || a.first + local >= a.owned_end) continue;
                 const uint32_t n_d = dim == 1 ? a.n1 : (dim == 2 ? a.n2 : a.n3);
                 const uint32_t off = dim == 1 ? 0u : (dim == 2 ? a.n1 : a.n1 + a.n2);
                 const uint32_t k = rec.boundary_index;

@@ -100,7 +100,11 @@ bool SlabComm::init(const void* id_bytes128, int rank, int nranks, int device, h
         *err = "rank outside [0, nranks)";
         return false;
     }
-    if (has_lo != (rank > 0) || has_hi != (rank + 1 < nranks)) {
+    // nranks == 1 with both ghosts = loopback: the slab is its own neighbour on both sides
+    // (periodic in z).  Exists so that the RCCL send/recv + stream/event choreography can be
+    // exercised on a single GPU; the multi-rank chain is open-ended.
+    loopback_ = (nranks == 1 && has_lo && has_hi);
+    if (!loopback_ && (has_lo != (rank > 0) || has_hi != (rank + 1 < nranks))) {
         *err = "ghost_lo/ghost_hi of the engine do not match its position in the slab chain";
         return false;
     }
@@ -138,7 +142,17 @@ bool SlabComm::exchange_faces(hipStream_t compute, hipEvent_t also, void* field,
     if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
     if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
     if (also && !hip_ok(hipStreamWaitEvent(stream_, also, 0), "hipStreamWaitEvent", err)) return false;
-    if (has_lo_ || has_hi_) {
+    if (loopback_) {
+        // sends and receives to the same peer pair up in issue order
+        if (!nccl_ok(r.group_start(), "ncclGroupStart", err)) return false;
+        if (!nccl_ok(r.send(base + plane_bytes, plane_bytes, kNcclInt8, 0, comm_, stream_), "ncclSend", err)) return false;
+        if (!nccl_ok(r.recv(base + (size_t)(nz - 1) * plane_bytes, plane_bytes, kNcclInt8, 0, comm_, stream_), "ncclRecv", err))
+            return false;
+        if (!nccl_ok(r.send(base + (size_t)(nz - 2) * plane_bytes, plane_bytes, kNcclInt8, 0, comm_, stream_), "ncclSend", err))
+            return false;
+        if (!nccl_ok(r.recv(base, plane_bytes, kNcclInt8, 0, comm_, stream_), "ncclRecv", err)) return false;
+        if (!nccl_ok(r.group_end(), "ncclGroupEnd", err)) return false;
+    } else if (has_lo_ || has_hi_) {
         if (!nccl_ok(r.group_start(), "ncclGroupStart", err)) return false;
         if (has_lo_) {
             // my first owned plane (z=1) -> lower neighbour's top ghost; its top owned plane -> my z=0

@@ -43,7 +43,7 @@ public:
 private:
     void* comm_ = nullptr;
     int rank_ = 0, nranks_ = 1;
-    bool has_lo_ = false, has_hi_ = false;
+    bool has_lo_ = false, has_hi_ = false, loopback_ = false;
     hipStream_t stream_ = nullptr;
     hipEvent_t faces_ready_ = nullptr;
     hipEvent_t ghosts_ready_ = nullptr;

@@ -172,6 +172,8 @@ public:
                 a.n2 = n2_;
                 a.n3 = n3_;
                 a.status = status_;
+                a.owned_first = (int64_t)z_begin_ * nx_ * ny_;
+                a.owned_end = (int64_t)z_end_ * nx_ * ny_;
                 const int64_t n_bytes = rows * cls_pitch_;
                 const unsigned grid = (unsigned)std::min<int64_t>((n_bytes + 255) / 256, 65536);
                 hipLaunchKernelGGL(wv::setup_classify_kernel, dim3(grid), dim3(256), 0, stream_, a);

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
 // Experiment switches (tools/stream_bench.hip only; the engine always uses 0).  The first three
 // change results and exist to price a piece of the kernel; the nt ones are result-neutral.
 enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
-             X_NO_HALO_ROWS = 64, X_TX_FAST = 128 };
+             X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512 };
 // what the engine runs: x-fastest tile order, non-temporal prev loads and next stores (both are
 // touched exactly once per step, so they should not displace the re-used `cur` lines from L2)
 constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
@@ -320,12 +320,12 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     const bool full = (x0 + WX <= a.nx);
     const int64_t plane = (int64_t)a.nx * a.ny;
 
-    auto load_cur = [&](int y, int zz) -> V {
+    auto load_cur = [&](int y, int zz, bool nt) -> V {
         V v = (V)(Real(0));
         if (y >= 0 && y < a.ny && zz >= 0 && zz < a.nz) {
             const Real* p = a.cur + (zz * plane + (int64_t)y * a.nx + xl);
             if (full) {
-                v = *reinterpret_cast<const V*>(p);
+                v = nt ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p)) : *reinterpret_cast<const V*>(p);
             } else {
 #pragma unroll
                 for (int jx = 0; jx < VX; ++jx)
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     V below[RY], mid[RY + 2], above[RY], pv[RY];
     uint32_t cl[RY];
 #pragma unroll
-    for (int r = 0; r < RY; ++r) above[r] = load_cur(y0 + r, z + 1);   // first touch: HBM
+    for (int r = 0; r < RY; ++r) above[r] = load_cur(y0 + r, z + 1, (X & X_NT_CUR) != 0);   // first touch: HBM
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         pv[r] = (V)(Real(0));
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
         }
     }
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) mid[r] = load_cur(y0 - 1 + r, z);  // L2 (loaded as z+1 one plane ago)
+    for (int r = 0; r < RY + 2; ++r) mid[r] = load_cur(y0 - 1 + r, z, (X & X_NT_MID) != 0);  // L2 (loaded as z+1 one plane ago)
     Real mid_e = 0;
     {
         const int r = lane & 31;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
         }
     }
 #pragma unroll
-    for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, z - 1);     // L2 (two planes ago)
+    for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, z - 1, (X & X_NT_BELOW) != 0);  // L2 (two planes ago): last use
 
     int bad = 0;
 #pragma unroll
