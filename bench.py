@@ -62,14 +62,25 @@ def cpu_baseline(args, elem):
     cur = np.zeros(mesh.num_nodes, dtype=dtype)
     cur[mesh.compute_index(nx // 2, ny // 2, nz // 2)] = 1.0
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
-    o = Oracle()
-    o.step(prev, cur, mesh, bd, threads=cores)  # first touch
+    # prefer the reference's own kernel (oracle/_ref: its OpenCL C text compiled for the host,
+    # pressure type promoted to double for the fp64 bench) over the repo's C restatement
+    from oracle.oracle import Reference, reference_available
+    if reference_available():
+        impl = Reference("f32" if args.precision == "f32" else "f64")
+        kind = "reference"
+        what = "reference OpenCL C kernel compiled for the host (clang -x cl%s), std::thread node chunks" % (
+            "" if args.precision == "f32" else ", pressures promoted to double")
+    else:
+        impl = Oracle()
+        kind = "port"
+        what = "C restatement (oracle/), OpenMP over x-rows"
+    impl.step(prev, cur, mesh, bd, threads=cores)  # first touch
     prev, cur = cur, prev
     # pick the thread count that is actually fastest on this host (SMT / NUMA make "all" a guess)
     best = None
     for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
         t0 = time.perf_counter()
-        o.step(prev, cur, mesh, bd, threads=t)
+        impl.step(prev, cur, mesh, bd, threads=t)
         prev, cur = cur, prev
         dt = time.perf_counter() - t0
         if best is None or dt < best[1]:
@@ -78,16 +89,16 @@ def cpu_baseline(args, elem):
     steps = 0
     t0 = time.perf_counter()
     while True:
-        assert o.step(prev, cur, mesh, bd, threads=threads) == 0
+        assert impl.step(prev, cur, mesh, bd, threads=threads) == 0
         prev, cur = cur, prev
         steps += 1
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds and steps >= 2:
             break
     rate = mesh.num_nodes * steps / dt / 1e9
-    return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": threads, "kind": "port",
-            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d OpenMP threads over x-rows (host has %d logical cores)"
-                      % (nx, ny, nz, args.precision, steps, dt, threads, cores)}
+    return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": threads, "kind": kind,
+            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d threads (host has %d logical cores); %s"
+                      % (nx, ny, nz, args.precision, steps, dt, threads, cores, what)}
 
 
 def main():
@@ -108,6 +119,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    local_rank %= max(1, torch.cuda.device_count())  # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

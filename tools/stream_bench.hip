@@ -199,6 +199,7 @@ static void run_march(Ctx& c, const char* name, int zchunks, int lds_bytes = 0) 
     a.nx = c.nx;
     a.ny = c.ny;
     a.nz = c.nz;
+    a.pitch = c.nx;
     a.cls_pitch = c.pitch;
     a.z_begin = 0;
     a.z_end = c.nz;
@@ -231,6 +232,7 @@ static void run_sweep(Ctx& c, const char* name, int stripe_rows) {
     a.nx = c.nx;
     a.ny = c.ny;
     a.nz = c.nz;
+    a.pitch = c.nx;
     a.cls_pitch = c.pitch;
     a.z_begin = 0;
     a.z_end = c.nz;

@@ -41,14 +41,14 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint3
     const uint32_t idx = a.bnode[entry];
     if (idx == INVALID_NODE) return;
     const uint32_t dirs = a.btype[entry];  // bit p set: inner node through port p (nx,px,ny,py,nz,pz)
-    const int x = (int)(idx % (uint32_t)a.nx);
-    const uint32_t q = idx / (uint32_t)a.nx;
+    const int x = (int)(idx % (uint32_t)a.pitch);
+    const uint32_t q = idx / (uint32_t)a.pitch;
     const int y = (int)(q % (uint32_t)a.ny);
     const int z = (int)(q / (uint32_t)a.ny);
     if (z < a.z_begin || z >= a.z_end) return;
 
-    const int64_t plane = (int64_t)a.nx * a.ny;
-    const int64_t stride[3] = {1, a.nx, plane};
+    const int64_t plane = (int64_t)a.pitch * a.ny;
+    const int64_t stride[3] = {1, a.pitch, plane};
     const int pos[3] = {x, y, z};
     const int lim[3] = {a.nx, a.ny, a.nz};
     const Real* cur = a.cur;
@@ -171,16 +171,17 @@ struct NodeRec {                 // condensed_node, cl/structs.h:19-22
 };
 
 struct SetupArgs {
-    const NodeRec* nodes;        // staged chunk: nodes [first, first+count)
-    int64_t first, count;        // chunk = whole x-rows
-    int nx;
+    const NodeRec* nodes;        // staged chunk (compact, nx per row): rows [first_row, first_row+rows)
+    int64_t first_row, rows;
+    int nx, ny;
+    int pitch;                   // stored row length of the fields
     int cls_pitch;
     uint8_t* cls;
     uint32_t* bnode;
     uint8_t* btype;
     uint32_t n1, n2, n3;
     int* status;                 // bit0: invalid boundary type, bit1: boundary_index out of range
-    int64_t owned_first, owned_end;  // node range of the planes this engine updates (ghosts excluded)
+    int z_begin, z_end;          // planes this engine updates (ghost planes excluded)
 };
 
 __device__ __forceinline__ uint32_t classify(int32_t t, int* dim_out) {
@@ -195,19 +196,18 @@ __device__ __forceinline__ uint32_t classify(int32_t t, int* dim_out) {
 
 // one thread per class byte (4 nodes of one row)
 __global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) {
-    const int64_t rows = a.count / a.nx;
-    const int64_t n_bytes = rows * a.cls_pitch;
-    const int64_t first_row = a.first / a.nx;
+    const int64_t n_bytes = a.rows * a.cls_pitch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / a.cls_pitch;
         const int xb = (int)(i % a.cls_pitch);
+        const int64_t grow = a.first_row + row;      // global row = z*ny + y
+        const int z = (int)(grow / a.ny);
         uint32_t byte = 0;
         for (int j = 0; j < 4; ++j) {
             const int x = xb * 4 + j;
-            if (x >= a.nx) break;
-            const int64_t local = row * a.nx + x;
-            const NodeRec rec = a.nodes[local];
+            if (x >= a.nx) break;                    // pad columns stay class "none"
+            const NodeRec rec = a.nodes[row * a.nx + x];
             const int32_t t = rec.boundary_type;
             int dim;
             const uint32_t c = classify(t, &dim);
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) 
                 }
                 // ghost-plane boundary nodes belong to the neighbouring slab: classified (their
                 // type matters to the static checks) but never entered in this engine's lists
-                if (a.first + local < a.owned_first || a.first + local >= a.owned_end) continue;
+                if (z < a.z_begin || z >= a.z_end) continue;
                 const uint32_t n_d = dim == 1 ? a.n1 : (dim == 2 ? a.n2 : a.n3);
                 const uint32_t off = dim == 1 ? 0u : (dim == 2 ? a.n1 : a.n1 + a.n2);
                 const uint32_t k = rec.boundary_index;
@@ -231,11 +231,11 @@ __global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) 
                     atomicOr(a.status, 2);
                     continue;
                 }
-                a.bnode[off + k] = (uint32_t)(a.first + local);
+                a.bnode[off + k] = (uint32_t)(grow * a.pitch + x);
                 a.btype[off + k] = (uint8_t)dirs;
             }
         }
-        a.cls[(first_row + row) * a.cls_pitch + xb] = (uint8_t)byte;
+        a.cls[grow * a.cls_pitch + xb] = (uint8_t)byte;
     }
 }
 
@@ -247,7 +247,7 @@ struct ValidateArgs {
     const uint8_t* btype;
     const uint8_t* cls;
     uint32_t n_entries;
-    int nx, ny, nz, cls_pitch;
+    int nx, ny, nz, pitch, cls_pitch;
     int* static_flag;
 };
 
@@ -257,8 +257,8 @@ __global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs 
     const uint32_t idx = a.bnode[e];
     if (idx == INVALID_NODE) return;
     const uint32_t dirs = a.btype[e];
-    const int pos[3] = {(int)(idx % (uint32_t)a.nx), (int)((idx / (uint32_t)a.nx) % (uint32_t)a.ny),
-                        (int)(idx / ((uint32_t)a.nx * (uint32_t)a.ny))};
+    const int pos[3] = {(int)(idx % (uint32_t)a.pitch), (int)((idx / (uint32_t)a.pitch) % (uint32_t)a.ny),
+                        (int)(idx / ((uint32_t)a.pitch * (uint32_t)a.ny))};
     const int lim[3] = {a.nx, a.ny, a.nz};
     int flag = 0;
     int dim = __popc(dirs);
@@ -285,11 +285,17 @@ __global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs 
     if (flag) atomicOr(a.static_flag, flag);
 }
 
-// ---- field conversion for wv_read_field / wv_write_field ---------------------------------------
+// ---- field I/O for wv_read_field / wv_write_field: compact host layout (nx per row) <-> stored
+// layout (pitch per row), with f32 <-> f64 conversion when the element types differ
 template <typename Dst, typename Src>
-__global__ void __launch_bounds__(256) convert_kernel(Dst* dst, const Src* src, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = (Dst)src[i];
+__global__ void __launch_bounds__(256) pack_rows_kernel(Dst* dst, int dst_pitch, const Src* src, int src_pitch, int nx,
+                                                        int64_t rows) {
+    const int64_t n = rows * nx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / nx;
+        const int x = (int)(i % nx);
+        dst[row * dst_pitch + x] = (Dst)src[row * src_pitch + x];
+    }
 }
 
 // AoS <-> SoA transposition of the boundary filter state (cl/structs.h:38-58)

@@ -25,14 +25,12 @@ template <typename Real>
 struct Vec16;
 template <>
 struct Vec16<double> {
-    typedef double aligned_t __attribute__((ext_vector_type(2)));
-    typedef aligned_t type __attribute__((aligned(8)));
+    typedef double type __attribute__((ext_vector_type(2)));
     static constexpr int N = 2;
 };
 template <>
 struct Vec16<float> {
-    typedef float aligned_t __attribute__((ext_vector_type(4)));
-    typedef aligned_t type __attribute__((aligned(4)));
+    typedef float type __attribute__((ext_vector_type(4)));
     static constexpr int N = 4;
 };
 
@@ -78,9 +76,10 @@ template <typename Real>
 struct StreamArgs {
     Real* prev;          // previous field, overwritten in place with the next field
     const Real* cur;     // current field (read only)
-    const uint8_t* cls;  // class map, cls_pitch bytes per x-row
+    const uint8_t* cls;  // class map, cls_pitch = pitch/4 bytes per x-row
     int* flag;           // error_code word of this step
     int nx, ny, nz;
+    int pitch;           // elements per stored row: nx rounded up to 64 lanes x 16 B
     int cls_pitch;
     int z_begin, z_end;  // planes this engine updates (ghost planes excluded)
     int zc;              // planes marched by one workgroup
@@ -103,6 +102,7 @@ struct BoundaryArgs {
     uint32_t n1, n2, n3;     // entries per dimensionality; entry order: all 1D, all 2D, all 3D
     uint32_t n_slots;        // n1 + 2 n2 + 3 n3
     int nx, ny, nz;
+    int pitch;               // stored row length (see stream_kernels.hip.h)
     int z_begin, z_end;
     Real courant, courant_sq;
 };

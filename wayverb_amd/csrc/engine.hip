@@ -96,9 +96,13 @@ public:
         nz_ = m.nz;
         if (nx_ < 1 || ny_ < 1 || nz_ < 1) return fail(WV_E_INVALID_ARGUMENT, "mesh dimensions must be positive");
         n_nodes_ = (uint64_t)nx_ * ny_ * nz_;
-        if (n_nodes_ >= 0xFFFFFFFEull)
+        // stored rows are padded to the wave tile width (64 lanes x 16 B), see stream_kernels.hip.h
+        constexpr int kTile = 64 * (16 / (int)sizeof(Real));
+        pitch_ = (nx_ + kTile - 1) / kTile * kTile;
+        stored_nodes_ = (uint64_t)pitch_ * ny_ * nz_;
+        if (stored_nodes_ >= 0xFFFFFFFEull)
             return fail(WV_E_INVALID_ARGUMENT,
-                        "more than 2^32-2 nodes in one engine: decompose into z-slabs (32-bit local node indices)");
+                        "more than 2^32-2 stored nodes in one engine: decompose into z-slabs (32-bit local node indices)");
         if (!m.nodes || (!m.coefficients && m.num_coefficients))
             return fail(WV_E_INVALID_ARGUMENT, "mesh arrays missing");
         z_begin_ = opt.ghost_lo ? 1 : 0;
@@ -118,7 +122,7 @@ public:
         overlap_boundary_ = env_int("WV_BOUNDARY_OVERLAP", 0) != 0;  // measured: concurrency costs the sweep more than it hides
 
         // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
-        field_bytes_ = n_nodes_ * sizeof(Real);
+        field_bytes_ = stored_nodes_ * sizeof(Real);
         for (int i = 0; i < 2; ++i) {
             WV_HIP(hipMalloc((void**)&field_[i], field_bytes_ + 256));
             WV_HIP(hipMemsetAsync(field_[i], 0, field_bytes_ + 256, stream_));
@@ -126,7 +130,7 @@ public:
         cur_ = 1;  // field_[0] = previous, field_[1] = current
 
         // ---- class map + compact boundary lists ------------------------------------------------
-        cls_pitch_ = (nx_ + 3) / 4;
+        cls_pitch_ = pitch_ / 4;
         const uint64_t cls_bytes = (uint64_t)cls_pitch_ * ny_ * nz_;
         WV_HIP(hipMalloc((void**)&cls_, cls_bytes + 16));
         n1_ = (uint32_t)m.num_boundary_1;
@@ -161,9 +165,11 @@ public:
                                       hipMemcpyHostToDevice, stream_));
                 wv::SetupArgs a{};
                 a.nodes = stage;
-                a.first = first;
-                a.count = cnt;
+                a.first_row = row;
+                a.rows = rows;
                 a.nx = nx_;
+                a.ny = ny_;
+                a.pitch = pitch_;
                 a.cls_pitch = cls_pitch_;
                 a.cls = cls_;
                 a.bnode = bnode_;
@@ -172,8 +178,8 @@ public:
                 a.n2 = n2_;
                 a.n3 = n3_;
                 a.status = status_;
-                a.owned_first = (int64_t)z_begin_ * nx_ * ny_;
-                a.owned_end = (int64_t)z_end_ * nx_ * ny_;
+                a.z_begin = z_begin_;
+                a.z_end = z_end_;
                 const int64_t n_bytes = rows * cls_pitch_;
                 const unsigned grid = (unsigned)std::min<int64_t>((n_bytes + 255) / 256, 65536);
                 hipLaunchKernelGGL(wv::setup_classify_kernel, dim3(grid), dim3(256), 0, stream_, a);
@@ -191,6 +197,7 @@ public:
             v.nx = nx_;
             v.ny = ny_;
             v.nz = nz_;
+            v.pitch = pitch_;
             v.cls_pitch = cls_pitch_;
             v.static_flag = static_flag_dev_;
             hipLaunchKernelGGL(wv::setup_validate_kernel, dim3((n_entries_ + 255) / 256), dim3(256), 0, stream_, v);
@@ -279,7 +286,7 @@ public:
                 p.nwy = 4;
             }
         }
-        p.tiles_x = (nx_ + WX * p.nwx - 1) / (WX * p.nwx);
+        p.tiles_x = (pitch_ + WX * p.nwx - 1) / (WX * p.nwx);
         p.tiles_y = (ny_ + p.ry * p.nwy - 1) / (p.ry * p.nwy);
         p.block = 64u * (unsigned)(p.nwx * p.nwy);
         const int owned = z_end_ - z_begin_;
@@ -288,7 +295,7 @@ public:
             // stripe height: three `cur` planes of a stripe should sit comfortably in one XCD's
             // 4 MiB L2 (measured best at 0.75-1.5 MiB), at least 8 stripes so every XCD has one
             const int tile_rows = p.ry * p.nwy;
-            int64_t rows = knob > 0 ? knob : (int64_t)(1600 * 1024) / (3ll * nx_ * (int64_t)sizeof(Real));
+            int64_t rows = knob > 0 ? knob : (int64_t)(1600 * 1024) / (3ll * pitch_ * (int64_t)sizeof(Real));
             int pow2 = tile_rows;
             while (pow2 * 2 <= rows) pow2 *= 2;
             rows = pow2;
@@ -347,6 +354,7 @@ public:
         a.nx = nx_;
         a.ny = ny_;
         a.nz = nz_;
+        a.pitch = pitch_;
         a.cls_pitch = cls_pitch_;
         a.z_begin = z0;
         a.z_end = z1;
@@ -399,6 +407,7 @@ public:
         b.nx = nx_;
         b.ny = ny_;
         b.nz = nz_;
+        b.pitch = pitch_;
         b.z_begin = z_begin_;
         b.z_end = z_end_;
         b.courant = courant_;
@@ -452,7 +461,7 @@ public:
             if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
             WV_HIP(hipGetLastError());
             if (!comm_->exchange_faces(stream_, bstream != stream_ ? ev_boundary_done_ : nullptr, prev, sizeof(Real),
-                                       nx_, ny_, nz_, &cerr))
+                                       pitch_, ny_, nz_, &cerr))
                 return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
         } else {
@@ -559,7 +568,7 @@ public:
         if (kind == WV_SOURCE_NONE) return WV_OK;
         if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
         if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
-        source_node_ = node;
+        source_node_ = stored_index(node);
         signal_len_ = n;
         WV_HIP(hipMalloc((void**)&signal_, std::max<uint64_t>(n, 1) * sizeof(double)));
         if (n) WV_HIP(hipMemcpy(signal_, signal, n * sizeof(double), hipMemcpyHostToDevice));
@@ -582,8 +591,10 @@ public:
         for (uint32_t i = 0; i < n; ++i)
             if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
                 return fail(WV_E_INVALID_ARGUMENT, "receiver node outside the mesh");
+        std::vector<uint64_t> stored(n);
+        for (uint32_t i = 0; i < n; ++i) stored[i] = nodes[i] == ~0ull ? ~0ull : stored_index(nodes[i]);
         WV_HIP(hipMalloc((void**)&recv_nodes_, n * sizeof(uint64_t)));
-        WV_HIP(hipMemcpy(recv_nodes_, nodes, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        WV_HIP(hipMemcpy(recv_nodes_, stored.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
         WV_HIP(hipMalloc((void**)&recv_out_, (size_t)kRing * n * sizeof(Real)));
         return WV_OK;
     }
@@ -598,11 +609,16 @@ public:
 
     // -------------------------------------------------------------------------------------------
     Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[cur_ ^ 1]; }
+    // caller's node index (x + y*nx + z*nx*ny) -> position in the stored (row-padded) field
+    uint64_t stored_index(uint64_t node) const {
+        const uint64_t x = node % (uint64_t)nx_, row = node / (uint64_t)nx_;
+        return row * (uint64_t)pitch_ + x;
+    }
 
     int read_value(int buffer_id, uint64_t index, double* v) override {
         if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
         Real tmp;
-        WV_HIP(hipMemcpyAsync(&tmp, buffer(buffer_id) + index, sizeof(Real), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipMemcpyAsync(&tmp, buffer(buffer_id) + stored_index(index), sizeof(Real), hipMemcpyDeviceToHost, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
         *v = (double)tmp;
         return WV_OK;
@@ -610,28 +626,33 @@ public:
     int write_value(int buffer_id, uint64_t index, double v) override {
         if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
         const Real tmp = (Real)v;
-        WV_HIP(hipMemcpyAsync(buffer(buffer_id) + index, &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
+        WV_HIP(hipMemcpyAsync(buffer(buffer_id) + stored_index(index), &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
         return WV_OK;
     }
 
+    // host field (compact: nx per row, element type Other) <-> stored field (pitch per row, Real),
+    // staged through a bounded device buffer in whole rows
     template <typename Other>
-    int copy_converted(void* dst, const void* src, bool to_device) {
-        // stage through a device buffer of the foreign element type
+    int copy_field(Real* stored, void* host, bool to_device) {
+        const int64_t rows_total = (int64_t)ny_ * nz_;
+        const int64_t rows_per_chunk = std::max<int64_t>(1, (64ll << 20) / nx_);
         Other* tmp = nullptr;
-        const int64_t chunk = std::min<int64_t>((int64_t)n_nodes_, 64ll << 20);
-        WV_HIP(hipMalloc((void**)&tmp, (size_t)chunk * sizeof(Other)));
-        for (int64_t off = 0; off < (int64_t)n_nodes_; off += chunk) {
-            const int64_t n = std::min<int64_t>(chunk, (int64_t)n_nodes_ - off);
+        WV_HIP(hipMalloc((void**)&tmp, (size_t)std::min(rows_per_chunk, rows_total) * nx_ * sizeof(Other)));
+        for (int64_t row = 0; row < rows_total; row += rows_per_chunk) {
+            const int64_t rows = std::min(rows_per_chunk, rows_total - row);
+            const int64_t n = rows * nx_;
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+            Other* h = static_cast<Other*>(host) + row * nx_;
+            Real* d = stored + row * pitch_;
             if (to_device) {
-                WV_HIP(hipMemcpyAsync(tmp, (const Other*)src + off, (size_t)n * sizeof(Other), hipMemcpyHostToDevice, stream_));
-                hipLaunchKernelGGL((wv::convert_kernel<Real, Other>), dim3(grid), dim3(256), 0, stream_,
-                                   (Real*)dst + off, (const Other*)tmp, n);
+                WV_HIP(hipMemcpyAsync(tmp, h, (size_t)n * sizeof(Other), hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL((wv::pack_rows_kernel<Real, Other>), dim3(grid), dim3(256), 0, stream_, d, pitch_,
+                                   (const Other*)tmp, nx_, nx_, rows);
             } else {
-                hipLaunchKernelGGL((wv::convert_kernel<Other, Real>), dim3(grid), dim3(256), 0, stream_, tmp,
-                                   (const Real*)src + off, n);
-                WV_HIP(hipMemcpyAsync((Other*)dst + off, tmp, (size_t)n * sizeof(Other), hipMemcpyDeviceToHost, stream_));
+                hipLaunchKernelGGL((wv::pack_rows_kernel<Other, Real>), dim3(grid), dim3(256), 0, stream_, tmp, nx_,
+                                   (const Real*)d, pitch_, nx_, rows);
+                WV_HIP(hipMemcpyAsync(h, tmp, (size_t)n * sizeof(Other), hipMemcpyDeviceToHost, stream_));
             }
             WV_HIP(hipStreamSynchronize(stream_));
         }
@@ -640,23 +661,13 @@ public:
     }
 
     int read_field(int buffer_id, void* dst, int elem_size) override {
-        if (elem_size == (int)sizeof(Real)) {
-            WV_HIP(hipMemcpyAsync(dst, buffer(buffer_id), field_bytes_, hipMemcpyDeviceToHost, stream_));
-            WV_HIP(hipStreamSynchronize(stream_));
-            return WV_OK;
-        }
-        if (elem_size == 4) return copy_converted<float>(dst, buffer(buffer_id), false);
-        if (elem_size == 8) return copy_converted<double>(dst, buffer(buffer_id), false);
+        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), dst, false);
+        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), dst, false);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
     int write_field(int buffer_id, const void* src, int elem_size) override {
-        if (elem_size == (int)sizeof(Real)) {
-            WV_HIP(hipMemcpyAsync(buffer(buffer_id), src, field_bytes_, hipMemcpyHostToDevice, stream_));
-            WV_HIP(hipStreamSynchronize(stream_));
-            return WV_OK;
-        }
-        if (elem_size == 4) return copy_converted<float>(buffer(buffer_id), src, true);
-        if (elem_size == 8) return copy_converted<double>(buffer(buffer_id), src, true);
+        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true);
+        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
 
@@ -753,7 +764,8 @@ private:
 
     wv_options opt_{};
     int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = 0;
-    uint64_t n_nodes_ = 0, field_bytes_ = 0;
+    uint64_t n_nodes_ = 0, stored_nodes_ = 0, field_bytes_ = 0;
+    int pitch_ = 0;
     Real* field_[2] = {nullptr, nullptr};
     int cur_ = 1;
     uint8_t* cls_ = nullptr;

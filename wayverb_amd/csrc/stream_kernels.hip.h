@@ -9,38 +9,109 @@
 //     s = 0; s += nx; s += px; s += ny; s += py; s += nz; s += pz   (off-grid ports contribute +0,
 //     s = s / 3;  next = s - prev                                    which equals skipping them)
 //
+// Field layout: Real[nz][ny][pitch], pitch = nx rounded up to the wave tile width (64 lanes x
+// 16 B); the pad columns are class "none", so they hold 0 forever: every row access is a full,
+// 16-byte-aligned, 1 KiB wave transaction with no ragged-edge code, and x = nx reads as the
+// off-grid zero it stands for.
+//
 // Bound: HBM.  Algorithmic traffic per node = read prev + read cur + write next = 3*sizeof(Real).
 #pragma once
 #include "device_common.hip.h"
 
 namespace wv {
 
+// Experiment switches (tools/stream_bench.hip only).  The first group changes results and exists
+// to price a piece of the kernel; the nt ones are result-neutral cache hints.
+enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
+             X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512 };
+// what the engine runs: `prev` and `next` are touched exactly once per step, so they carry the
+// non-temporal hint and do not displace the re-used `cur` lines from L2
+constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
+
+template <typename V, bool NT>
+__device__ __forceinline__ V load_vec(const V* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <typename V, bool NT>
+__device__ __forceinline__ void store_vec(V* p, V v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// The 7-point update of one lane's VX nodes of one row.  c0 = this row of `cur`; ym / yp / zm / zp
+// the rows at y-1, y+1, z-1, z+1; edges = x-edge halos (see load_edges); r = row slot in `edges`.
+// Returns the values to store; `skip` is set if any of the lane's nodes is a boundary node.
+template <typename Real, int X>
+__device__ __forceinline__ typename Vec16<Real>::type update_row(
+        typename Vec16<Real>::type c0, typename Vec16<Real>::type ym, typename Vec16<Real>::type yp,
+        typename Vec16<Real>::type zm, typename Vec16<Real>::type zp, typename Vec16<Real>::type pv, Real edges, int r,
+        uint32_t cls_bits, int& bad, bool& skip) {
+    constexpr int VX = Vec16<Real>::N;
+    const Real edge_l = read_lane(edges, r), edge_r = read_lane(edges, 32 + r);
+    typename Vec16<Real>::type out;
+#pragma unroll
+    for (int j = 0; j < VX; ++j) {
+        const Real left = (j == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[j - 1];
+        const Real right = (j == VX - 1) ? lane_from_above(edge_r, c0[0]) : c0[j + 1];
+        Real s = Real(0) + left;
+        s += right;
+        s += ym[j];
+        s += yp[j];
+        s += zm[j];
+        s += zp[j];
+        s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
+        s -= pv[j];
+        const uint32_t c = (cls_bits >> (2 * j)) & 3u;
+        const Real o = (c & 1u) ? s : Real(0);
+        bad |= bad_bits(o);
+        out[j] = o;
+        skip |= (c == CLS_BOUNDARY);
+    }
+    return out;
+}
+
+// Store one lane's VX results; per-element only where the wave holds a boundary node.
+template <typename Real, int X>
+__device__ __forceinline__ void store_row(Real* q, typename Vec16<Real>::type out, uint32_t cls_bits, bool skip) {
+    using V = typename Vec16<Real>::type;
+    constexpr int VX = Vec16<Real>::N;
+    if (!__any(skip)) {
+        store_vec<V, (X & X_NT_STORE) != 0>(reinterpret_cast<V*>(q), out);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VX; ++j)
+            if (((cls_bits >> (2 * j)) & 3u) != CLS_BOUNDARY) q[j] = out[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// Variant 0: one node per lane, neighbours straight from global memory (caches do the reuse).
-// Kept as the simple baseline the tuned kernel is checked and timed against.
+// Variant 1 ("naive"): one node per lane, neighbours straight from global memory (the caches do
+// the reuse).  The simple baseline the tuned kernels are checked and timed against.
 // ---------------------------------------------------------------------------------------------
 template <typename Real>
 __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real> a) {
-    const int64_t plane = (int64_t)a.nx * a.ny;
-    const int64_t first = (int64_t)a.z_begin * plane;
-    const int64_t count = (int64_t)(a.z_end - a.z_begin) * plane;
+    const int64_t row_nodes = a.nx;
+    const int64_t plane_nodes = row_nodes * a.ny;
+    const int64_t count = (int64_t)(a.z_end - a.z_begin) * plane_nodes;
+    const int64_t plane = (int64_t)a.pitch * a.ny;
     int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t idx = first + i;
-        const int x = (int)(idx % a.nx);
-        const int64_t q = idx / a.nx;
+        const int x = (int)(i % a.nx);
+        const int64_t q = i / a.nx;
         const int y = (int)(q % a.ny);
-        const int z = (int)(q / a.ny);
-        const uint32_t c = (a.cls[(q * a.cls_pitch) + (x >> 2)] >> ((x & 3) * 2)) & 3u;
+        const int z = a.z_begin + (int)(q / a.ny);
+        const int64_t row = (int64_t)z * a.ny + y;
+        const int64_t idx = row * a.pitch + x;
+        const uint32_t c = (a.cls[row * a.cls_pitch + (x >> 2)] >> ((x & 3) * 2)) & 3u;
         if (c == CLS_BOUNDARY) continue;
         Real out = 0;
         if (c & 1u) {
             Real s = 0;
             s += (x > 0) ? a.cur[idx - 1] : Real(0);
             s += (x + 1 < a.nx) ? a.cur[idx + 1] : Real(0);
-            s += (y > 0) ? a.cur[idx - a.nx] : Real(0);
-            s += (y + 1 < a.ny) ? a.cur[idx + a.nx] : Real(0);
+            s += (y > 0) ? a.cur[idx - a.pitch] : Real(0);
+            s += (y + 1 < a.ny) ? a.cur[idx + a.pitch] : Real(0);
             s += (z > 0) ? a.cur[idx - plane] : Real(0);
             s += (z + 1 < a.nz) ? a.cur[idx + plane] : Real(0);
             s = s / Real(3);
@@ -53,36 +124,63 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
     if (bad) atomicOr(a.flag, bad);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Variant 1: wave-autonomous 2.5-D march.
-//
-// One wave owns a tile of WX = 64*VX contiguous x (VX = 16 B / sizeof(Real) elements per lane,
-// so every row access is one fully coalesced 1 KiB wave transaction) by RY rows of y, and
-// marches it through `zc` planes of z.  The three z-planes of `cur` it needs live in registers
-// and rotate as it advances, so each `cur` value is fetched from HBM once; +-x neighbours
-// come from the adjacent lane through DPP wave shifts, +-y from the lane's own registers
-// (rows y0-1 and y0+RY are loaded as halo rows), and the two x-edge halo values of each row
-// arrive in one 2-address load (lanes 0-31 fetch the left one, 32-63 the right one).  No LDS, no
-// barrier: waves of a workgroup are independent, which lets every wave keep a full plane of
-// loads (z+2) in flight while it computes plane z.
-//
-// NW waves stack along y in a workgroup purely for locality (shared halo rows hit L1/L2), and
-// the block->tile map keeps each XCD's workgroups on y-adjacent tiles so the halo rows that
-// cross workgroups are served by that XCD's L2 instead of HBM.
-// ---------------------------------------------------------------------------------------------
-// Experiment switches (tools/stream_bench.hip only; the engine always uses 0).  The first three
-// change results and exist to price a piece of the kernel; the nt ones are result-neutral.
-enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
-             X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512 };
-// what the engine runs: x-fastest tile order, non-temporal prev loads and next stores (both are
-// touched exactly once per step, so they should not displace the re-used `cur` lines from L2)
-constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
+// Shared lane-level accessors of the two tiled kernels.
+template <typename Real>
+struct TileIO {
+    using V = typename Vec16<Real>::type;
+    static constexpr int VX = Vec16<Real>::N;
+    static constexpr int WX = 64 * VX;
+    const StreamArgs<Real>& a;
+    int lane, x0, xl;
+    int64_t plane;
 
+    __device__ __forceinline__ TileIO(const StreamArgs<Real>& args, int lane_, int x0_)
+            : a(args), lane(lane_), x0(x0_), xl(x0_ + lane_ * VX), plane((int64_t)args.pitch * args.ny) {}
+    __device__ __forceinline__ int64_t at(int y, int z) const { return (int64_t)z * plane + (int64_t)y * a.pitch + xl; }
+
+    // a row of `cur`: zeros when the row or plane is off-grid (wave-uniform test)
+    template <bool NT>
+    __device__ __forceinline__ V cur_row(int y, int z) const {
+        if (y < 0 || y >= a.ny || z < 0 || z >= a.nz) return (V)(Real(0));
+        return load_vec<V, NT>(reinterpret_cast<const V*>(a.cur + at(y, z)));
+    }
+    template <bool NT>
+    __device__ __forceinline__ V prev_row(int y, int z) const {
+        return load_vec<V, NT>(reinterpret_cast<const V*>(a.prev + at(y, z)));
+    }
+    // x-edge halos of rows y0..y0+RY-1 of a plane in ONE load: lane r (< RY) fetches cur[x0-1] of
+    // row y0+r, lane 32+r fetches cur[x0+WX] of that row; read_lane hands them out later.
+    template <int RY>
+    __device__ __forceinline__ Real edges(int y0, int z) const {
+        Real e = 0;
+        const int r = lane & 31;
+        const int y = y0 + r;
+        if (r < RY && y < a.ny && z >= 0 && z < a.nz) {
+            const int xe = (lane < 32) ? x0 - 1 : x0 + WX;
+            if (xe >= 0 && xe < a.pitch) e = a.cur[(int64_t)z * plane + (int64_t)y * a.pitch + xe];
+        }
+        return e;
+    }
+    // 2 class bits for each of this lane's VX nodes
+    __device__ __forceinline__ uint32_t cls_row(int y, int z) const {
+        const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
+        return (VX == 4) ? (uint32_t)byte : (((uint32_t)byte >> ((lane & 1) * 4)) & 0xFu);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Variant 0 ("march"): wave-autonomous 2.5-D march, z-planes of `cur` rotate through registers.
+//
+// One wave owns a 64*VX by RY tile and marches it through `zc` planes, prefetching plane z+2 while
+// it computes plane z; every `cur` value is fetched from HBM once and nothing but halos is
+// re-read.  Measured ceiling on MI355X: ~66 % of peak -- thousands of long-lived private streams
+// make a DRAM-unfriendly access front.  Kept as a cross-check of variant 2.
+// ---------------------------------------------------------------------------------------------
 template <typename Real, int RY, int NWX, int NWY, int X = X_PRODUCT>
 __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const StreamArgs<Real> a) {
     using V = typename Vec16<Real>::type;
-    constexpr int VX = Vec16<Real>::N;
-    constexpr int WX = 64 * VX;
+    constexpr int WX = TileIO<Real>::WX;
+    constexpr bool NTP = (X & X_NT_PREV) != 0, NTC = (X & X_NT_CUR) != 0;
 
     const int lane = threadIdx.x & 63;
     // wave id as a scalar: everything derived from it (tile origin, row addresses) stays in SGPRs
@@ -106,151 +204,65 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
         tx = rem % a.tiles_x;
         cz = rem / a.tiles_x;
     }
-
     const int x0 = (tx * NWX + wx) * WX;
     const int y0 = (ty * NWY + wy) * RY;
-    if (y0 >= a.ny || x0 >= a.nx) return;
+    if (y0 >= a.ny || x0 >= a.pitch) return;
     const int zb = a.z_begin + cz * a.zc;
     const int ze = min(zb + a.zc, a.z_end);
     if (zb >= ze) return;
 
-    const int xl = x0 + lane * VX;            // first x of this lane
-    const bool full = (x0 + WX <= a.nx);      // wave-uniform: whole tile inside the row
-    const int64_t plane = (int64_t)a.nx * a.ny;
+    const TileIO<Real> io(a, lane, x0);
+    auto halo_or_cur = [&](int r, int z) -> V {  // r in [0, RY+2): rows y0-1 .. y0+RY
+        if ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) return (V)(Real(0));
+        return io.template cur_row<NTC>(y0 - 1 + r, z);
+    };
+    auto load_edges = [&](int z) -> Real { return (X & X_NO_EDGE) ? Real(0) : io.template edges<RY>(y0, z); };
 
-    // a row of `cur` (zeros when the row or plane is off-grid; lanes past nx read zeros)
-    auto load_cur = [&](int y, int z) -> V {
-        V v = (V)(Real(0));
-        if (y >= 0 && y < a.ny && z >= 0 && z < a.nz) {
-            const Real* p = a.cur + (z * plane + (int64_t)y * a.nx + xl);
-            if (full) {
-                v = (X & X_NT_CUR) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
-                                   : *reinterpret_cast<const V*>(p);
-            } else {
-#pragma unroll
-                for (int j = 0; j < VX; ++j)
-                    if (xl + j < a.nx) v[j] = p[j];
-            }
-        }
-        return v;
-    };
-    // x-edge halo of all RY rows of a plane in ONE load: lane r (< RY) fetches cur[x0-1] of row
-    // y0+r, lane 32+r fetches cur[x0+WX] of that row; read_lane hands them to lanes 0 / 63 later.
-    auto load_edges = [&](int z) -> Real {
-        Real e = 0;
-        const int r = lane & 31;
-        const int y = y0 + r;
-        if (!(X & X_NO_EDGE) && r < RY && y < a.ny && z >= 0 && z < a.nz) {
-            const int xe = (lane < 32) ? x0 - 1 : x0 + WX;
-            if (xe >= 0 && xe < a.nx) e = a.cur[z * plane + (int64_t)y * a.nx + xe];
-        }
-        return e;
-    };
-    auto load_prev = [&](int y, int z) -> V {
-        V v = (V)(Real(0));
-        if (y < a.ny && z < ze) {
-            const Real* p = a.prev + (z * plane + (int64_t)y * a.nx + xl);
-            if (full) {
-                v = (X & X_NT_PREV) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
-                                    : *reinterpret_cast<const V*>(p);
-            } else {
-#pragma unroll
-                for (int j = 0; j < VX; ++j)
-                    if (xl + j < a.nx) v[j] = p[j];
-            }
-        }
-        return v;
-    };
-    // 2 class bits per element of this lane (all "boundary" = never stored when off-grid)
-    auto load_cls = [&](int y, int z) -> uint32_t {
-        uint32_t c = 0xAAu;
-        if (X & X_NO_CLS) return 0x55u;
-        if (y < a.ny && z < ze && xl < a.nx) {
-            const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
-            c = (VX == 4) ? byte : ((byte >> ((lane & 1) * 4)) & 0xFu);
-        }
-        return c;
-    };
-
-    V below[RY];        // cur(z-1), rows y0 .. y0+RY-1
-    V mid[RY + 2];      // cur(z),   rows y0-1 .. y0+RY
-    Real mid_e;         // x-edge halos of cur(z): lanes r / 32+r hold row y0+r's left / right value
-    V above[RY + 2];    // cur(z+1)
-    Real above_e;
-    V pv[RY];           // prev(z)
+    V below[RY];      // cur(z-1), rows y0 .. y0+RY-1
+    V mid[RY + 2];    // cur(z),   rows y0-1 .. y0+RY
+    V above[RY + 2];  // cur(z+1)
+    Real mid_e, above_e;
+    V pv[RY];
     uint32_t cl[RY];
-
 #pragma unroll
-    for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, zb - 1);
+    for (int r = 0; r < RY; ++r) below[r] = io.template cur_row<NTC>(y0 + r, zb - 1);
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) mid[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, zb);
+    for (int r = 0; r < RY + 2; ++r) mid[r] = halo_or_cur(r, zb);
     mid_e = load_edges(zb);
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) above[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, zb + 1);
+    for (int r = 0; r < RY + 2; ++r) above[r] = halo_or_cur(r, zb + 1);
     above_e = load_edges(zb + 1);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        pv[r] = load_prev(y0 + r, zb);
-        cl[r] = load_cls(y0 + r, zb);
+        const bool live = y0 + r < a.ny;
+        pv[r] = live ? io.template prev_row<NTP>(y0 + r, zb) : (V)(Real(0));
+        cl[r] = (X & X_NO_CLS) ? 0x55u : (live ? io.cls_row(y0 + r, zb) : 0xAAu);
     }
 
     int bad = 0;
     for (int z = zb; z < ze; ++z) {
         // ---- issue the loads of the next iteration first: plane z+2 of cur, plane z+1 of prev
-        V nxt[RY + 2];
-        Real nxt_e;
-        V pv_n[RY];
+        V nxt[RY + 2], pv_n[RY];
         uint32_t cl_n[RY];
 #pragma unroll
-        for (int r = 0; r < RY + 2; ++r) nxt[r] = ((X & X_NO_HALO_ROWS) && (r == 0 || r == RY + 1)) ? (V)(Real(0)) : load_cur(y0 - 1 + r, z + 2);
-        nxt_e = load_edges(z + 2);
+        for (int r = 0; r < RY + 2; ++r) nxt[r] = halo_or_cur(r, z + 2);
+        const Real nxt_e = load_edges(z + 2);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            pv_n[r] = load_prev(y0 + r, z + 1);
-            cl_n[r] = load_cls(y0 + r, z + 1);
+            const bool live = y0 + r < a.ny && z + 1 < ze;
+            pv_n[r] = live ? io.template prev_row<NTP>(y0 + r, z + 1) : (V)(Real(0));
+            cl_n[r] = (X & X_NO_CLS) ? 0x55u : (live ? io.cls_row(y0 + r, z + 1) : 0xAAu);
         }
-
         // ---- update plane z
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const int y = y0 + r;
-            if (y < a.ny) {
-                const V c0 = mid[r + 1];
-                const Real edge_l = read_lane(mid_e, r), edge_r = read_lane(mid_e, 32 + r);
-                V out;
-                bool skip_any = false;
-#pragma unroll
-                for (int j = 0; j < VX; ++j) {
-                    const Real left = (j == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[j - 1];
-                    const Real right = (j == VX - 1) ? lane_from_above(edge_r, c0[0]) : c0[j + 1];
-                    Real s = Real(0) + left;
-                    s += right;
-                    s += mid[r][j];
-                    s += mid[r + 2][j];
-                    s += below[r][j];
-                    s += above[r + 1][j];
-                    s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
-                    s -= pv[r][j];
-                    const uint32_t c = (cl[r] >> (2 * j)) & 3u;
-                    const Real o = (c & 1u) ? s : Real(0);
-                    bad |= bad_bits(o);
-                    out[j] = o;
-                    skip_any |= (c == CLS_BOUNDARY);
-                }
-                Real* q = a.prev + (z * plane + (int64_t)y * a.nx + xl);
-                if (full && !__any(skip_any)) {
-                    if (X & X_NT_STORE) __builtin_nontemporal_store(out, reinterpret_cast<V*>(q));
-                    else *reinterpret_cast<V*>(q) = out;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < VX; ++j) {
-                        const uint32_t c = (cl[r] >> (2 * j)) & 3u;
-                        if (xl + j < a.nx && c != CLS_BOUNDARY) q[j] = out[j];
-                    }
-                }
+            if (y0 + r < a.ny) {
+                bool skip = false;
+                const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r + 1], pv[r], mid_e, r,
+                                                  cl[r], bad, skip);
+                store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
             }
         }
-
         // ---- rotate the register planes
         mid_e = above_e;
         above_e = nxt_e;
@@ -273,17 +285,17 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 2: plane sweep with L2-resident z-reuse.
+// Variant 2 ("sweep", the default): plane sweep with L2-resident z-reuse.
 //
 // Measured on MI355X (tools/stream_bench.hip, profiles/): HBM delivers ~6.5 TB/s to short-lived
 // workgroups that are dispatched in address order (the chip-wide set of in-flight addresses is
 // a few long contiguous runs), but only ~5.3 TB/s to thousands of long-lived waves that each
 // own a private stream -- which is what the z-march is.  This variant keeps the march's lane
 // layout (16 B per lane, DPP x-neighbours, one-load x-edges) but makes every wave short-lived:
-// a wave updates its WX x RY tile of ONE plane and exits.  The z-reuse of `cur` then has to
+// a wave updates its 64*VX by RY tile of ONE plane and exits.  The z-reuse of `cur` then has to
 // come from cache, so the work is laid out for the per-XCD L2 (4 MiB, private):
 //   - XCD k (= blockIdx % 8) owns y-stripe s = pass*8 + k, `stripe_rows` rows tall, and sweeps it
-//     through all planes; the three `cur` planes of a stripe (3 * stripe_rows * nx * 8 B) stay in
+//     through all planes; the three `cur` planes of a stripe (3 * stripe_rows * pitch * 8 B) stay in
 //     that XCD's L2 while prev/next stream through it with the non-temporal hint;
 //   - all 8 XCDs advance through z together, so the chip-wide access front is 8 short runs
 //     per stream inside one plane.
@@ -292,8 +304,8 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 template <typename Real, int RY, int NWX, int NWY, int X = X_NT_STORE | X_NT_PREV>
 __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
     using V = typename Vec16<Real>::type;
-    constexpr int VX = Vec16<Real>::N;
-    constexpr int WX = 64 * VX;
+    constexpr int WX = TileIO<Real>::WX;
+    constexpr bool NTP = (X & X_NT_PREV) != 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -314,105 +326,35 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     const int y_hi = min(y_lo + a.stripe_rows, a.ny);
     const int x0 = (tx * NWX + wx) * WX;
     const int y0 = y_lo + (tyl * NWY + wy) * RY;
-    if (y0 >= y_hi || x0 >= a.nx) return;
+    if (y0 >= y_hi || x0 >= a.pitch) return;
 
-    const int xl = x0 + lane * VX;
-    const bool full = (x0 + WX <= a.nx);
-    const int64_t plane = (int64_t)a.nx * a.ny;
-
-    auto load_cur = [&](int y, int zz, bool nt) -> V {
-        V v = (V)(Real(0));
-        if (y >= 0 && y < a.ny && zz >= 0 && zz < a.nz) {
-            const Real* p = a.cur + (zz * plane + (int64_t)y * a.nx + xl);
-            if (full) {
-                v = nt ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p)) : *reinterpret_cast<const V*>(p);
-            } else {
-#pragma unroll
-                for (int jx = 0; jx < VX; ++jx)
-                    if (xl + jx < a.nx) v[jx] = p[jx];
-            }
-        }
-        return v;
-    };
+    const TileIO<Real> io(a, lane, x0);
 
     // ---- everything this tile needs, issued back to back
     V below[RY], mid[RY + 2], above[RY], pv[RY];
     uint32_t cl[RY];
 #pragma unroll
-    for (int r = 0; r < RY; ++r) above[r] = load_cur(y0 + r, z + 1, (X & X_NT_CUR) != 0);   // first touch: HBM
+    for (int r = 0; r < RY; ++r) above[r] = io.template cur_row<(X & X_NT_CUR) != 0>(y0 + r, z + 1);  // first touch: HBM
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        pv[r] = (V)(Real(0));
-        cl[r] = 0xAAu;
-        const int y = y0 + r;
-        if (y < y_hi) {
-            const Real* p = a.prev + (z * plane + (int64_t)y * a.nx + xl);
-            if (full) {
-                pv[r] = (X & X_NT_PREV) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
-                                        : *reinterpret_cast<const V*>(p);
-            } else {
-#pragma unroll
-                for (int jx = 0; jx < VX; ++jx)
-                    if (xl + jx < a.nx) pv[r][jx] = p[jx];
-            }
-            if (xl < a.nx) {
-                const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
-                cl[r] = (VX == 4) ? byte : ((byte >> ((lane & 1) * 4)) & 0xFu);
-            }
-        }
+        const bool live = y0 + r < y_hi;
+        pv[r] = live ? io.template prev_row<NTP>(y0 + r, z) : (V)(Real(0));
+        cl[r] = live ? io.cls_row(y0 + r, z) : 0xAAu;
     }
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) mid[r] = load_cur(y0 - 1 + r, z, (X & X_NT_MID) != 0);  // L2 (loaded as z+1 one plane ago)
-    Real mid_e = 0;
-    {
-        const int r = lane & 31;
-        const int y = y0 + r;
-        if (r < RY && y < a.ny) {
-            const int xe = (lane < 32) ? x0 - 1 : x0 + WX;
-            if (xe >= 0 && xe < a.nx) mid_e = a.cur[z * plane + (int64_t)y * a.nx + xe];
-        }
-    }
+    for (int r = 0; r < RY + 2; ++r) mid[r] = io.template cur_row<(X & X_NT_MID) != 0>(y0 - 1 + r, z);  // L2: was z+1 a plane ago
+    const Real mid_e = io.template edges<RY>(y0, z);
 #pragma unroll
-    for (int r = 0; r < RY; ++r) below[r] = load_cur(y0 + r, z - 1, (X & X_NT_BELOW) != 0);  // L2 (two planes ago): last use
+    for (int r = 0; r < RY; ++r) below[r] = io.template cur_row<(X & X_NT_BELOW) != 0>(y0 + r, z - 1);  // L2: last use
 
     int bad = 0;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        const int y = y0 + r;
-        if (y < y_hi) {
-            const V c0 = mid[r + 1];
-            const Real edge_l = read_lane(mid_e, r), edge_r = read_lane(mid_e, 32 + r);
-            V out;
-            bool skip_any = false;
-#pragma unroll
-            for (int jx = 0; jx < VX; ++jx) {
-                const Real left = (jx == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[jx - 1];
-                const Real right = (jx == VX - 1) ? lane_from_above(edge_r, c0[0]) : c0[jx + 1];
-                Real s = Real(0) + left;
-                s += right;
-                s += mid[r][jx];
-                s += mid[r + 2][jx];
-                s += below[r][jx];
-                s += above[r][jx];
-                s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
-                s -= pv[r][jx];
-                const uint32_t c = (cl[r] >> (2 * jx)) & 3u;
-                const Real o = (c & 1u) ? s : Real(0);
-                bad |= bad_bits(o);
-                out[jx] = o;
-                skip_any |= (c == CLS_BOUNDARY);
-            }
-            Real* q = a.prev + (z * plane + (int64_t)y * a.nx + xl);
-            if (full && !__any(skip_any)) {
-                if (X & X_NT_STORE) __builtin_nontemporal_store(out, reinterpret_cast<V*>(q));
-                else *reinterpret_cast<V*>(q) = out;
-            } else {
-#pragma unroll
-                for (int jx = 0; jx < VX; ++jx) {
-                    const uint32_t c = (cl[r] >> (2 * jx)) & 3u;
-                    if (xl + jx < a.nx && c != CLS_BOUNDARY) q[jx] = out[jx];
-                }
-            }
+        if (y0 + r < y_hi) {
+            bool skip = false;
+            const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r],
+                                              bad, skip);
+            store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
         }
     }
     if (__any(bad != 0)) {
