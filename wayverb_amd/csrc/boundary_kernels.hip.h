@@ -127,16 +127,26 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint3
     a.prev[idx] = next;
 }
 
+// entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
 template <typename Real>
-__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    int bad = 0;
+__device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, uint32_t e, int& bad) {
     if (e < a.n1) {
         boundary_node<Real, 1>(a, e, e, 0u, a.n1, bad);
     } else if (e < a.n1 + a.n2) {
         boundary_node<Real, 2>(a, e - a.n1, e, a.n1, a.n2, bad);
     } else if (e < a.n1 + a.n2 + a.n3) {
         boundary_node<Real, 3>(a, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
+    }
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (a.order) {
+        if (t < a.n_order) boundary_entry<Real>(a, a.order[t], bad);
+    } else {
+        boundary_entry<Real>(a, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
 }
@@ -148,6 +158,7 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
 template <typename Real>
 __global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a) {
     const uint32_t t = threadIdx.x;
+    if (t == 0) *a.flag = a.flag_init;  // waveguide.h:82 (write_value(error_flag, id_success)) + static bits
     Real injected = 0;
     const bool has_source = a.source_kind != 0;
     if (has_source) {

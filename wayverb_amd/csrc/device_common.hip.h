@@ -73,23 +73,6 @@ __device__ __forceinline__ int bad_bits(Real v) {
 
 // ---- kernel argument blocks -----------------------------------------------------------------
 template <typename Real>
-struct StreamArgs {
-    Real* prev;          // previous field, overwritten in place with the next field
-    const Real* cur;     // current field (read only)
-    const uint8_t* cls;  // class map, cls_pitch = pitch/4 bytes per x-row
-    int* flag;           // error_code word of this step
-    int nx, ny, nz;
-    int pitch;           // elements per stored row: nx rounded up to 64 lanes x 16 B
-    int cls_pitch;
-    int z_begin, z_end;  // planes this engine updates (ghost planes excluded)
-    int zc;              // planes marched by one workgroup
-    int tiles_x, tiles_y, chunks_z;
-    int total_tiles, tiles_per_xcd;
-    // plane-sweep kernel only: rows per XCD stripe, tiles per stripe-plane, passes over z
-    int stripe_rows, tiles_y_stripe, passes;
-};
-
-template <typename Real>
 struct BoundaryArgs {
     Real* prev;
     const Real* cur;
@@ -105,6 +88,34 @@ struct BoundaryArgs {
     int pitch;               // stored row length (see stream_kernels.hip.h)
     int z_begin, z_end;
     Real courant, courant_sq;
+    const uint32_t* order;   // standalone kernel: entry ids to process (null = all, in list order)
+    uint32_t n_order;
+};
+
+template <typename Real>
+struct StreamArgs {
+    Real* prev;          // previous field, overwritten in place with the next field
+    const Real* cur;     // current field (read only)
+    const uint8_t* cls;  // class map, cls_pitch = pitch/4 bytes per x-row
+    int* flag;           // error_code word of this step
+    int nx, ny, nz;
+    int pitch;           // elements per stored row: nx rounded up to 64 lanes x 16 B
+    int cls_pitch;
+    int z_begin, z_end;  // planes this engine updates (ghost planes excluded)
+    int zc;              // planes marched by one workgroup
+    int tiles_x, tiles_y, chunks_z;
+    int total_tiles, tiles_per_xcd;
+    // plane-sweep kernel only: rows per XCD stripe, tiles per stripe-plane, passes over z
+    int stripe_rows, tiles_y_stripe, passes;
+    // boundary nodes fused into the sweep launch: `nb` extra workgroups per (pass, plane, XCD)
+    // group update that group's boundary nodes right after its tiles, while their lines are hot
+    // in that XCD's L2.  Group g = (pass*gz_count + z - gz_begin)*8 + xcd owns
+    // border[gstart[g] .. gstart[g]+gcount[g]) (entry ids); nb = 0 disables.
+    int nb, gz_begin, gz_count;
+    const uint32_t* border;
+    const uint32_t* gstart;
+    const uint32_t* gcount;
+    BoundaryArgs<Real> b;
 };
 
 template <typename Real>
@@ -117,6 +128,8 @@ struct PrePostArgs {
     const uint64_t* recv;    // [n_recv]
     Real* recv_out;          // row of this step: [n_recv]
     uint32_t n_recv;
+    int* flag;               // this step's error_code word, reset here ...
+    int flag_init;           // ... to the mesh-static bits (0 for a well-formed mesh)
 };
 
 }  // namespace wv

@@ -247,6 +247,10 @@ public:
         courant_sq_ = (Real)1 / (Real)3;
 
         plan_stream();
+        {
+            const int rc = build_boundary_schedule();
+            if (rc != WV_OK) return rc;
+        }
         const int n_ev = 2 * kRing;
         events_.resize(n_ev);
         for (auto& e : events_) WV_HIP(hipEventCreate(&e));
@@ -262,6 +266,77 @@ public:
         tune_nwy_ = nwy;
         tune_zchunks_ = zchunks;
         plan_stream();
+        return build_boundary_schedule();
+    }
+
+    // Boundary nodes in sweep order.  With the plane-sweep kernel, the boundary nodes of one
+    // (pass, plane, XCD-stripe) group are updated by `nb` extra workgroups of the same launch,
+    // dispatched right after the group's tiles to the same XCD (their `cur`/`prev` lines are then in
+    // that L2).  Groups too large for that (whole boundary planes / rows: coalesced anyway) stay
+    // with the stand-alone kernel, which then walks `dense_order_`.
+    int build_boundary_schedule() {
+        for (void** p : {(void**)&border_, (void**)&gstart_, (void**)&gcount_, (void**)&dense_order_}) {
+            if (*p) WV_HIP(hipFree(*p));
+            *p = nullptr;
+        }
+        n_dense_ = 0;
+        fused_nb_ = 0;
+        // Worth it only where a group has many tile workgroups to hide the (latency-bound) boundary
+        // ones behind.  Measured step time, fp64: 1024^3 (32 tiles/group) 4.85 ms unfused, 4.72 with
+        // 1 boundary workgroup per group, 4.76 with 2, 5.11 with 4; 512^3 (16 tiles/group) and 256^3
+        // (4) are slower fused (profiles/r01/fused_boundary.txt).
+        const int tiles_per_group = plan_.tiles_x * plan_.tiles_y_stripe;
+        const int want_nb = env_int("WV_FUSED_BOUNDARY_BLOCKS", tiles_per_group >= 32 ? 1 : 0);
+        if (plan_.variant != 2 || !n_entries_ || want_nb <= 0) return WV_OK;
+        if (bnode_host_.empty()) {
+            bnode_host_.resize(n_entries_);
+            WV_HIP(hipMemcpy(bnode_host_.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        const int gz = z_end_ - z_begin_;
+        const size_t n_groups = (size_t)plan_.passes * gz * 8;
+        std::vector<uint32_t> count(n_groups, 0), key(n_entries_);
+        const uint32_t plane = (uint32_t)pitch_ * (uint32_t)ny_;
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        for (uint32_t e = 0; e < n_entries_; ++e) {
+            const uint32_t idx = bnode_host_[e];
+            key[e] = kNone;
+            if (idx == wv::INVALID_NODE) continue;
+            const int z = (int)(idx / plane), y = (int)((idx / (uint32_t)pitch_) % (uint32_t)ny_);
+            if (z < z_begin_ || z >= z_end_) continue;
+            const int stripe = y / plan_.stripe_rows;
+            const size_t g = ((size_t)(stripe / 8) * gz + (size_t)(z - z_begin_)) * 8 + (size_t)(stripe % 8);
+            key[e] = (uint32_t)g;
+            ++count[g];
+        }
+        // groups beyond `limit` entries go to the stand-alone kernel
+        const uint32_t limit = (uint32_t)want_nb * plan_.block * 2u;
+        std::vector<uint32_t> start(n_groups, 0), fused_count(n_groups, 0);
+        uint32_t n_fused = 0;
+        for (size_t g = 0; g < n_groups; ++g) {
+            start[g] = n_fused;
+            if (count[g] <= limit) {
+                fused_count[g] = count[g];
+                n_fused += count[g];
+            }
+        }
+        std::vector<uint32_t> border(std::max<uint32_t>(n_fused, 1)), dense, cursor(start);
+        for (uint32_t e = 0; e < n_entries_; ++e) {  // stable: node order inside a group
+            if (key[e] == kNone) continue;
+            if (count[key[e]] <= limit) border[cursor[key[e]]++] = e;
+            else dense.push_back(e);
+        }
+        WV_HIP(hipMalloc((void**)&border_, border.size() * sizeof(uint32_t)));
+        WV_HIP(hipMemcpy(border_, border.data(), border.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        WV_HIP(hipMalloc((void**)&gstart_, n_groups * sizeof(uint32_t)));
+        WV_HIP(hipMemcpy(gstart_, start.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+        WV_HIP(hipMalloc((void**)&gcount_, n_groups * sizeof(uint32_t)));
+        WV_HIP(hipMemcpy(gcount_, fused_count.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+        n_dense_ = (uint32_t)dense.size();
+        if (n_dense_) {
+            WV_HIP(hipMalloc((void**)&dense_order_, dense.size() * sizeof(uint32_t)));
+            WV_HIP(hipMemcpy(dense_order_, dense.data(), dense.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        fused_nb_ = want_nb;
         return WV_OK;
     }
 
@@ -273,8 +348,9 @@ public:
         p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant);
         if (p.variant < 0 || p.variant > 2) p.variant = 2;
         p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 4);
-        p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", 1);
-        p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", 4);
+        // measured best shapes (profiles/r01/sweep_engine_*): fp64 1x4 waves, fp32 4x2
+        p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", sizeof(Real) == 4 ? 4 : 1);
+        p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", sizeof(Real) == 4 ? 2 : 4);
         if (p.ry != 2 && p.ry != 4) p.ry = 4;
         {
             const int key = p.nwx * 10 + p.nwy;
@@ -365,7 +441,14 @@ public:
             a.stripe_rows = plan_.stripe_rows;
             a.tiles_y_stripe = plan_.tiles_y_stripe;
             a.passes = plan_.passes;
-            grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+            a.nb = fused_nb_;
+            a.gz_begin = z_begin_;
+            a.gz_count = z_end_ - z_begin_;
+            a.border = border_;
+            a.gstart = gstart_;
+            a.gcount = gcount_;
+            if (fused_nb_ > 0) a.b = boundary_args(prev, cur, flag);
+            grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe + a.nb);
         } else if (plan_.variant == 0) {
             a.zc = std::min(plan_.zc, z1 - z0);
             a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
@@ -389,8 +472,7 @@ public:
         return WV_OK;
     }
 
-    int launch_boundary(Real* prev, const Real* cur, int* flag, hipStream_t on) {
-        if (!n_entries_) return WV_OK;
+    wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const {
         wv::BoundaryArgs<Real> b{};
         b.prev = prev;
         b.cur = cur;
@@ -412,7 +494,21 @@ public:
         b.z_end = z_end_;
         b.courant = courant_;
         b.courant_sq = courant_sq_;
-        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n_entries_ + 255) / 256), dim3(256), 0, on, b);
+        return b;
+    }
+
+    // the boundary nodes the streaming launch does not cover (all of them unless fused)
+    int launch_boundary(Real* prev, const Real* cur, int* flag, hipStream_t on) {
+        if (!n_entries_) return WV_OK;
+        wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
+        uint32_t n = n_entries_;
+        if (fused_nb_ > 0) {
+            if (!n_dense_) return WV_OK;
+            b.order = dense_order_;
+            b.n_order = n_dense_;
+            n = n_dense_;
+        }
+        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n + 255) / 256), dim3(256), 0, on, b);
         return WV_OK;
     }
 
@@ -422,25 +518,24 @@ public:
         Real* cur = field_[cur_];
         int* flag = flags_ + slot;
         int rc;
-        // the flag word starts from the mesh-static bits (see setup_validate_kernel)
-        if (static_flag_ == 0) {
-            WV_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream_));
-        } else {
-            WV_HIP(hipMemcpyAsync(flag, static_flag_dev_, sizeof(int), hipMemcpyDeviceToDevice, stream_));
-        }
         std::string cerr;
         // ghost planes of `cur` come from the exchange issued at the end of the previous step
         if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-        if (with_pre_post && (n_recv_ || source_live)) {
+        {
+            // one small launch: reset this step's flag word to the mesh-static bits
+            // (setup_validate_kernel), inject the source sample, gather the receivers
+            const bool io = with_pre_post && (n_recv_ || source_live);
             wv::PrePostArgs<Real> pp{};
             pp.cur = cur;
             pp.signal = signal_;
             pp.signal_pos = signal_pos;
             pp.source_node = source_node_;
-            pp.source_kind = source_live ? source_kind_ : 0;
+            pp.source_kind = io && source_live ? source_kind_ : 0;
             pp.recv = recv_nodes_;
             pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
-            pp.n_recv = n_recv_;
+            pp.n_recv = io ? n_recv_ : 0;
+            pp.flag = flag;
+            pp.flag_init = static_flag_;
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
         // The boundary kernel and the streaming kernel write disjoint nodes of `prev` and only read
@@ -751,7 +846,8 @@ private:
         events_.clear();
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
-        void* ptrs[] = {cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_};
+        void* ptrs[] = {cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
+                        border_, gstart_, gcount_, dense_order_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (flags_host_) (void)hipHostFree(flags_host_);
@@ -775,6 +871,11 @@ private:
     uint8_t* btype_ = nullptr;
     double* fmem_ = nullptr;
     uint32_t* cidx_ = nullptr;
+    // boundary schedule of the fused sweep launch (build_boundary_schedule)
+    uint32_t *border_ = nullptr, *gstart_ = nullptr, *gcount_ = nullptr, *dense_order_ = nullptr;
+    uint32_t n_dense_ = 0;
+    int fused_nb_ = 0;
+    std::vector<uint32_t> bnode_host_;
     int* status_ = nullptr;
     int* static_flag_dev_ = nullptr;
     int static_flag_ = 0;

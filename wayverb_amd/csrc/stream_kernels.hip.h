@@ -16,6 +16,7 @@
 //
 // Bound: HBM.  Algorithmic traffic per node = read prev + read cur + write next = 3*sizeof(Real).
 #pragma once
+#include "boundary_kernels.hip.h"
 #include "device_common.hip.h"
 
 namespace wv {
@@ -314,12 +315,24 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
     const int per_plane = a.tiles_x * a.tiles_y_stripe;
-    const int tl = j % per_plane;
-    j /= per_plane;
+    const int per_group = per_plane + a.nb;
+    const int tl = j % per_group;
+    j /= per_group;
     const int nzr = a.z_end - a.z_begin;
     const int z = a.z_begin + j % nzr;
     const int pass = j / nzr;
     const int stripe = pass * 8 + xcd;
+
+    if (tl >= per_plane) {
+        // ---- a boundary workgroup: this (pass, plane, XCD) group's boundary nodes
+        const int g = (pass * a.gz_count + (z - a.gz_begin)) * 8 + xcd;
+        const uint32_t start = a.gstart[g], count = a.gcount[g];
+        int bbad = 0;
+        for (uint32_t i = (uint32_t)(tl - per_plane) * blockDim.x + threadIdx.x; i < count; i += (uint32_t)a.nb * blockDim.x)
+            boundary_entry<Real>(a.b, a.border[start + i], bbad);
+        if (bbad) atomicOr(a.flag, bbad);
+        return;
+    }
     const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
 
     const int y_lo = stripe * a.stripe_rows;
