@@ -187,6 +187,18 @@ int wv_comm_unique_id(void* id_bytes /* [WV_UNIQUE_ID_BYTES] */);
 int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks);
 int wv_comm_destroy(wv_engine* e);
 
+/* ---- unit kernel of the boundary IIR step ------------------------------------------------------- */
+/* The reference's `filter_test_2` test kernel (src/waveguide/src/cl/filters.cpp:66-75, launched by
+ * tests/rectangular_kernel.cpp:170-190): n_filters independent order-6 filters, each fed
+ * input[s][f] for s = 0..n_samples-1; output[s][f] = filter output as float; memory[f][6] is
+ * read, advanced and written back.  Runs the same device code as the boundary kernel. */
+int wv_filter_test_2(const float* input, float* output, double* memory,
+                     const wv_coefficients_canonical* coeffs, uint32_t n_filters, uint32_t n_samples);
+/* Row length (in elements) of the stored pressure fields returned by wv_device_buffer:
+ * nx rounded up to the wave tile (128 doubles / 256 floats); element (x,y,z) is at
+ * (z*ny + y)*pitch + x and the pad columns are zero. */
+int wv_field_pitch(wv_engine* e, uint64_t* pitch_elements);
+
 /* ---- host helpers ------------------------------------------------------------------------------ */
 /* Synthetic box mesh of SURVEY.md 8(d): planes [z_begin, z_begin+z_count) of a global
  * nx*ny*nz_global box; boundary_index numbered per dimensionality in increasing node index

@@ -163,3 +163,20 @@ def test_impulse_response_known_answer():
     assert steps == 8
     assert out[3, 0] == pytest.approx((1.0 / 3.0) ** 3, rel=1e-15)
     assert np.all(out[:3, 0] == 0)
+
+
+@pytest.mark.parametrize("quiet", [False, True])
+def test_iir_unit_kernel_matches_golden(quiet):
+    """G4: the `filter_test_2` unit kernel on 256 seeded filters x 1000 samples (and the +-1e-35
+    'quiet' variant of tests/rectangular_kernel.cpp:79-101): outputs and final memories equal the
+    reference kernel's, and stay finite."""
+    from helpers import sha
+    from wayverb_amd import engine as E
+    c = cases.case_filters(quiet)
+    g = golden("filters_quiet" if quiet else "filters_noise")
+    mem = np.zeros((256, 6))
+    out = E.filter_test_2(c["input"], mem, c["coeffs"])
+    assert np.isfinite(out).all()
+    assert sha(out) == str(g["sha_outputs"])
+    assert np.array_equal(out[-1], g["last_output"])
+    assert np.array_equal(mem, g["final_memory"])

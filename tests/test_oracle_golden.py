@@ -107,3 +107,44 @@ def test_error_flags_match_reference_kernel(oracle):
             cur = np.zeros(mesh.num_nodes, dtype=np.float32)
             flags.append(impl.step(prev, cur, mesh, [mesh.boundary_data(d) for d in (1, 2, 3)]))
         assert flags[0] == flags[1] and flags[0] & bit
+
+
+def _compare_filters_inputs():
+    rng = np.random.default_rng(321)
+    n = 256
+    sections = [[M.peak_biquad(rng.uniform(0.1, 1.0), rng.uniform(0.0, 0.5), rng.uniform(0.0, 1.0)) for _ in range(3)]
+                for _ in range(n)]
+    biquads = np.zeros((n, 3, 6))
+    canonical = np.zeros(n, dtype=M.coefficients_dtype)
+    for i, secs in enumerate(sections):
+        for s, (b, a) in enumerate(secs):
+            biquads[i, s, :3] = b
+            biquads[i, s, 3:] = a
+        b, a = M.convolve_sections(secs)
+        canonical[i] = M.make_coefficients(b, a)
+    impulse = np.zeros((200, n), dtype=np.float32)
+    impulse[0] = 0.25
+    noise = rng.uniform(-0.25, 0.25, (2000, n)).astype(np.float32)
+    return biquads, canonical, impulse, noise
+
+
+@pytest.mark.parametrize("which", ["impulse", "noise"])
+def test_biquad_cascade_equals_convolved_canonical_filter(oracle, which):
+    """compare_filters (tests/rectangular_kernel.cpp:307-360): 3-biquad cascade == convolved
+    order-6 filter to 1e-3 on an impulse and on noise; and both unit kernels of the restatement
+    equal the reference's, bit for bit, when oracle/_ref is present."""
+    biquads, canonical, impulse, noise = _compare_filters_inputs()
+    x = impulse if which == "impulse" else noise
+    impls = [oracle] + ([Reference("f32")] if reference_available() else [])
+    results = []
+    for impl in impls:
+        bm = np.zeros((256, 3, 2))
+        cm = np.zeros((256, 6))
+        a = np.array([impl.filter_test(x[s], bm, biquads) for s in range(x.shape[0])])
+        b = np.array([impl.filter_test_2(x[s], cm, canonical) for s in range(x.shape[0])])
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        assert np.max(np.abs(a - b)) < 1e-3
+        results.append((a, b, bm, cm))
+    if len(results) == 2:
+        for u, v in zip(results[0], results[1]):
+            assert u.tobytes() == v.tobytes()

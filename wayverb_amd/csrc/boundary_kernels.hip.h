@@ -35,6 +35,29 @@ __device__ __forceinline__ void filter_step_6(double in, double m[6], const doub
     m[5] = b - a;
 }
 
+// `filter_test_2` (src/waveguide/src/cl/filters.cpp:66-75; tests/rectangular_kernel.cpp:180): one
+// canonical filter per work-item, float in / float out; here all samples of a filter in one launch.
+__global__ void __launch_bounds__(64) filter_test_2_kernel(const float* input, float* output, double* memory,
+                                                           const double* coeffs, uint32_t n_filters,
+                                                           uint32_t n_samples) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_filters) return;
+    double m[6], cb[7], ca[7];
+    for (int j = 0; j < 6; ++j) m[j] = memory[(size_t)f * 6 + j];
+    for (int j = 0; j < 7; ++j) {
+        cb[j] = coeffs[(size_t)f * 14 + j];
+        ca[j] = coeffs[(size_t)f * 14 + 7 + j];
+    }
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const double in = (double)input[(size_t)s * n_filters + f];
+        // the step's output is needed here, so it is restated rather than taken from filter_step_6
+        const double out = (in * cb[0] + m[0]) / ca[0];
+        filter_step_6(in, m, cb, ca);
+        output[(size_t)s * n_filters + f] = (float)out;
+    }
+    for (int j = 0; j < 6; ++j) memory[(size_t)f * 6 + j] = m[j];
+}
+
 template <typename Real, int D>
 __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint32_t k, uint32_t entry,
                                               uint32_t slot_base, uint32_t n_d, int& bad) {

@@ -78,6 +78,7 @@ struct wv_engine {
     virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
     virtual int comm_destroy() = 0;
+    virtual uint64_t field_pitch() const = 0;
     uint64_t steps_done = 0;
     bool timing = false;
 };
@@ -832,6 +833,7 @@ public:
         comm_ = std::move(c);
         return WV_OK;
     }
+    uint64_t field_pitch() const override { return (uint64_t)pitch_; }
     int comm_destroy() override {
         comm_.reset();
         return WV_OK;
@@ -1041,6 +1043,40 @@ int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks) {
 int wv_comm_destroy(wv_engine* e) {
     WV_NEED(e);
     return e->comm_destroy();
+}
+
+int wv_field_pitch(wv_engine* e, uint64_t* pitch_elements) {
+    WV_NEED(e);
+    *pitch_elements = e->field_pitch();
+    return WV_OK;
+}
+
+int wv_filter_test_2(const float* input, float* output, double* memory, const wv_coefficients_canonical* coeffs,
+                     uint32_t n_filters, uint32_t n_samples) {
+    if (!input || !output || !memory || !coeffs) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    const size_t n = n_filters, total = (size_t)n_filters * n_samples;
+    float *d_in = nullptr, *d_out = nullptr;
+    double *d_mem = nullptr, *d_c = nullptr;
+    WV_HIP(hipMalloc((void**)&d_in, total * sizeof(float)));
+    WV_HIP(hipMalloc((void**)&d_out, total * sizeof(float)));
+    WV_HIP(hipMalloc((void**)&d_mem, n * 6 * sizeof(double)));
+    WV_HIP(hipMalloc((void**)&d_c, n * 14 * sizeof(double)));
+    WV_HIP(hipMemcpy(d_in, input, total * sizeof(float), hipMemcpyHostToDevice));
+    WV_HIP(hipMemcpy(d_mem, memory, n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    WV_HIP(hipMemcpy(d_c, coeffs, n * 14 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(wv::filter_test_2_kernel, dim3((n_filters + 63) / 64), dim3(64), 0, 0, d_in, d_out, d_mem, d_c,
+                       n_filters, n_samples);
+    WV_HIP(hipGetLastError());
+    WV_HIP(hipMemcpy(output, d_out, total * sizeof(float), hipMemcpyDeviceToHost));
+    WV_HIP(hipMemcpy(memory, d_mem, n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_mem);
+    (void)hipFree(d_c);
+    return WV_OK;
 }
 
 }  // extern "C"

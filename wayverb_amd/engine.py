@@ -28,7 +28,7 @@ EXPORTS = [
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning",
+    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch",
 ]
 
 
@@ -101,6 +101,8 @@ def load_library():
     lib.wv_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     lib.wv_synchronize.argtypes = [C.c_void_p]
     lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.wv_filter_test_2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.wv_field_pitch.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.wv_comm_unique_id.argtypes = [C.c_void_p]
     lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.wv_comm_destroy.argtypes = [C.c_void_p]
@@ -140,6 +142,20 @@ def make_box_nodes(nx, ny, nz_global, z_begin=0, z_count=None, number_from=None,
     _check(lib.wv_make_box_nodes(nx, ny, nz_global, z_begin, z_count, number_from, number_to,
                                  nodes.ctypes.data_as(C.c_void_p), counts))
     return nodes, tuple(int(c) for c in counts)
+
+
+def filter_test_2(inputs, memory, coeffs):
+    """wv_filter_test_2: inputs float32[n_samples, n_filters]; memory float64[n_filters, 6] is
+    advanced in place; returns outputs float32[n_samples, n_filters]."""
+    lib = load_library()
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    coeffs = np.ascontiguousarray(coeffs, dtype=M.coefficients_dtype)
+    assert memory.dtype == np.float64 and memory.flags.c_contiguous
+    out = np.zeros_like(inputs)
+    _check(lib.wv_filter_test_2(inputs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                memory.ctypes.data_as(C.c_void_p), coeffs.ctypes.data_as(C.c_void_p),
+                                inputs.shape[1], inputs.shape[0]))
+    return out
 
 
 class Engine:
