@@ -53,7 +53,7 @@ __global__ void cls_kernel(uint8_t* cls, int nx, int ny, int nz, int pitch) {
             else if (x == 1 || y == 1 || z == 1 || x == nx - 2 || y == ny - 2 || z == nz - 2) c = 2;
             byte |= c << (2 * j);
         }
-        cls[i] = (uint8_t)byte;
+        cls[wv::cls_byte_index(xb * 4, y, z, ny, pitch)] = (uint8_t)byte;
     }
 }
 
@@ -264,7 +264,8 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&c.s));
     CK(hipMalloc((void**)&c.a, N * 8 + 256));
     CK(hipMalloc((void**)&c.b, N * 8 + 256 + (4 << 20)));
-    CK(hipMalloc((void**)&c.cls, (int64_t)c.pitch * n * n + 16));
+    CK(hipMalloc((void**)&c.cls, (int64_t)c.pitch * 4 * ((n + 3) / 4) * n + 16));
+    CK(hipMemset(c.cls, 0, (int64_t)c.pitch * 4 * ((n + 3) / 4) * n + 16));
     CK(hipMalloc((void**)&c.flag, 4));
     CK(hipMemset(c.flag, 0, 4));
     hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, c.s, c.a, N, 1u);
@@ -274,6 +275,21 @@ int main(int argc, char** argv) {
 
     using namespace wv;
     constexpr int P = X_PRODUCT;
+    if (argc > 3 && std::string(argv[3]) == "abl") {
+        constexpr int S2 = X_NT_STORE | X_NT_PREV;
+        for (int rep = 0; rep < 2; ++rep) {
+            run_sweep<4, 1, 4, S2>(c, "base", 32);
+            run_sweep<4, 1, 4, S2 | X_MUL_THIRD>(c, "mul_third", 32);
+            run_sweep<4, 1, 4, S2 | X_NO_EDGE>(c, "no_edge", 32);
+            run_sweep<4, 1, 4, S2 | X_NO_CLS>(c, "no_cls", 32);
+            run_sweep<4, 1, 4, S2 | X_MUL_THIRD | X_NO_EDGE | X_NO_CLS>(c, "bare", 32);
+            run_sweep<4, 1, 4, S2 | X_STORE_ALL>(c, "store_all", 32);
+            run_sweep<4, 1, 4, S2 | X_STORE_ALL | X_MUL_THIRD>(c, "store_all_mul", 32);
+            run_sweep<4, 2, 2, S2 | X_STORE_ALL>(c, "store_all", 32);
+            run_sweep<4, 1, 4, S2 | X_STORE_ALL>(c, "store_all", 64);
+        }
+        return 0;
+    }
     if (argc > 3 && std::string(argv[3]) == "prof2") {
         constexpr int S2 = X_NT_STORE | X_NT_PREV;
         run_sweep<4, 1, 4, S2>(c, "sweep", 16);
@@ -346,8 +362,6 @@ int main(int argc, char** argv) {
         run_sweep<2, 4, 1, S>(c, "sweep", sr);
         run_sweep<4, 4, 1, S>(c, "sweep", sr);
         run_sweep<4, 8, 1, S>(c, "sweep", sr);
-        run_sweep<8, 1, 1, S>(c, "sweep", sr);
-        run_sweep<8, 4, 1, S>(c, "sweep", sr);
     }
     run_sweep<4, 1, 4, 0>(c, "sweep_no_nt", 64);
     run_sweep<4, 1, 4, S | X_NT_CUR>(c, "sweep_nt_cur", 64);

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) setup_classify_kernel(const SetupArgs a) 
                 a.btype[off + k] = (uint8_t)dirs;
             }
         }
-        a.cls[grow * a.cls_pitch + xb] = (uint8_t)byte;
+        a.cls[cls_byte_index(xb * 4, (int)(grow % a.ny), z, a.ny, a.cls_pitch)] = (uint8_t)byte;
     }
 }
 
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs 
                     flag |= FLAG_OUTSIDE_MESH;
                     break;  // the reference returns from the surrounding sum here
                 }
-                const uint8_t byte = a.cls[((int64_t)p[2] * a.ny + p[1]) * a.cls_pitch + (p[0] >> 2)];
+                const uint8_t byte = a.cls[cls_byte_index(p[0], p[1], p[2], a.ny, a.cls_pitch)];
                 const uint32_t c = (byte >> ((p[0] & 3) * 2)) & 3u;
                 if (c == CLS_NONE || c == CLS_INSIDE) flag |= FLAG_SUSPICIOUS;
             }

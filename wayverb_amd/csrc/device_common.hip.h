@@ -21,6 +21,17 @@ enum : int { FLAG_INF = 1, FLAG_NAN = 2, FLAG_OUTSIDE_RANGE = 4, FLAG_OUTSIDE_ME
 
 constexpr uint32_t INVALID_NODE = 0xFFFFFFFFu;
 
+// Class-map addressing.  One 32-bit word holds 4 rows x 4 nodes: byte (y & 3) of word
+// [z][y >> 2][x >> 2] carries the 2-bit classes of nodes x&~3 .. x|3 of row y, so a wave fetches
+// the classes of all the rows of its tile with ONE coalesced dword load.  cls_pitch = words per
+// row group = pitch / 4.
+__host__ __device__ inline int64_t cls_word_index(int x, int y, int z, int ny, int cls_pitch) {
+    return ((int64_t)z * ((ny + 3) >> 2) + (y >> 2)) * cls_pitch + (x >> 2);
+}
+__host__ __device__ inline int64_t cls_byte_index(int x, int y, int z, int ny, int cls_pitch) {
+    return cls_word_index(x, y, z, ny, cls_pitch) * 4 + (y & 3);
+}
+
 template <typename Real>
 struct Vec16;
 template <>
@@ -96,7 +107,7 @@ template <typename Real>
 struct StreamArgs {
     Real* prev;          // previous field, overwritten in place with the next field
     const Real* cur;     // current field (read only)
-    const uint8_t* cls;  // class map, cls_pitch = pitch/4 bytes per x-row
+    const uint8_t* cls;  // class map (see cls_word_index), cls_pitch = pitch/4 words per row group
     int* flag;           // error_code word of this step
     int nx, ny, nz;
     int pitch;           // elements per stored row: nx rounded up to 64 lanes x 16 B
@@ -107,15 +118,6 @@ struct StreamArgs {
     int total_tiles, tiles_per_xcd;
     // plane-sweep kernel only: rows per XCD stripe, tiles per stripe-plane, passes over z
     int stripe_rows, tiles_y_stripe, passes;
-    // boundary nodes fused into the sweep launch: `nb` extra workgroups per (pass, plane, XCD)
-    // group update that group's boundary nodes right after its tiles, while their lines are hot
-    // in that XCD's L2.  Group g = (pass*gz_count + z - gz_begin)*8 + xcd owns
-    // border[gstart[g] .. gstart[g]+gcount[g]) (entry ids); nb = 0 disables.
-    int nb, gz_begin, gz_count;
-    const uint32_t* border;
-    const uint32_t* gstart;
-    const uint32_t* gcount;
-    BoundaryArgs<Real> b;
 };
 
 template <typename Real>

@@ -117,10 +117,6 @@ public:
         WV_HIP(hipGetDevice(&device_));
         WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
-        WV_HIP(hipStreamCreateWithFlags(&bnd_stream_, hipStreamNonBlocking));
-        WV_HIP(hipEventCreateWithFlags(&ev_inputs_ready_, hipEventDisableTiming));
-        WV_HIP(hipEventCreateWithFlags(&ev_boundary_done_, hipEventDisableTiming));
-        overlap_boundary_ = env_int("WV_BOUNDARY_OVERLAP", 0) != 0;  // measured: concurrency costs the sweep more than it hides
 
         // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
         field_bytes_ = stored_nodes_ * sizeof(Real);
@@ -132,8 +128,10 @@ public:
 
         // ---- class map + compact boundary lists ------------------------------------------------
         cls_pitch_ = pitch_ / 4;
-        const uint64_t cls_bytes = (uint64_t)cls_pitch_ * ny_ * nz_;
+        // one 32-bit word per (row group of 4, quad of 4 nodes): see cls_word_index
+        const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
         WV_HIP(hipMalloc((void**)&cls_, cls_bytes + 16));
+        WV_HIP(hipMemsetAsync(cls_, 0, cls_bytes + 16, stream_));
         n1_ = (uint32_t)m.num_boundary_1;
         n2_ = (uint32_t)m.num_boundary_2;
         n3_ = (uint32_t)m.num_boundary_3;
@@ -248,10 +246,6 @@ public:
         courant_sq_ = (Real)1 / (Real)3;
 
         plan_stream();
-        {
-            const int rc = build_boundary_schedule();
-            if (rc != WV_OK) return rc;
-        }
         const int n_ev = 2 * kRing;
         events_.resize(n_ev);
         for (auto& e : events_) WV_HIP(hipEventCreate(&e));
@@ -267,77 +261,27 @@ public:
         tune_nwy_ = nwy;
         tune_zchunks_ = zchunks;
         plan_stream();
-        return build_boundary_schedule();
+        return WV_OK;
     }
 
-    // Boundary nodes in sweep order.  With the plane-sweep kernel, the boundary nodes of one
-    // (pass, plane, XCD-stripe) group are updated by `nb` extra workgroups of the same launch,
-    // dispatched right after the group's tiles to the same XCD (their `cur`/`prev` lines are then in
-    // that L2).  Groups too large for that (whole boundary planes / rows: coalesced anyway) stay
-    // with the stand-alone kernel, which then walks `dense_order_`.
-    int build_boundary_schedule() {
-        for (void** p : {(void**)&border_, (void**)&gstart_, (void**)&gcount_, (void**)&dense_order_}) {
-            if (*p) WV_HIP(hipFree(*p));
-            *p = nullptr;
-        }
-        n_dense_ = 0;
-        fused_nb_ = 0;
-        // Worth it only where a group has many tile workgroups to hide the (latency-bound) boundary
-        // ones behind.  Measured step time, fp64: 1024^3 (32 tiles/group) 4.85 ms unfused, 4.72 with
-        // 1 boundary workgroup per group, 4.76 with 2, 5.11 with 4; 512^3 (16 tiles/group) and 256^3
-        // (4) are slower fused (profiles/r01/fused_boundary.txt).
-        const int tiles_per_group = plan_.tiles_x * plan_.tiles_y_stripe;
-        const int want_nb = env_int("WV_FUSED_BOUNDARY_BLOCKS", tiles_per_group >= 32 ? 1 : 0);
-        if (plan_.variant != 2 || !n_entries_ || want_nb <= 0) return WV_OK;
-        if (bnode_host_.empty()) {
-            bnode_host_.resize(n_entries_);
-            WV_HIP(hipMemcpy(bnode_host_.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
-        const int gz = z_end_ - z_begin_;
-        const size_t n_groups = (size_t)plan_.passes * gz * 8;
-        std::vector<uint32_t> count(n_groups, 0), key(n_entries_);
+    // Boundary entries sorted by plane (stable: list order inside a plane), so that the boundary
+    // nodes of a plane range are one contiguous run of `zorder_`.  Only the slab path needs it: the
+    // face planes' boundary nodes must be final before the halo exchange, the rest follow the
+    // interior sweep.
+    int build_plane_order() {
+        if (zorder_ || !n_entries_) return WV_OK;
+        std::vector<uint32_t> bnode(n_entries_);
+        WV_HIP(hipMemcpy(bnode.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t plane = (uint32_t)pitch_ * (uint32_t)ny_;
-        constexpr uint32_t kNone = 0xFFFFFFFFu;
-        for (uint32_t e = 0; e < n_entries_; ++e) {
-            const uint32_t idx = bnode_host_[e];
-            key[e] = kNone;
-            if (idx == wv::INVALID_NODE) continue;
-            const int z = (int)(idx / plane), y = (int)((idx / (uint32_t)pitch_) % (uint32_t)ny_);
-            if (z < z_begin_ || z >= z_end_) continue;
-            const int stripe = y / plan_.stripe_rows;
-            const size_t g = ((size_t)(stripe / 8) * gz + (size_t)(z - z_begin_)) * 8 + (size_t)(stripe % 8);
-            key[e] = (uint32_t)g;
-            ++count[g];
-        }
-        // groups beyond `limit` entries go to the stand-alone kernel
-        const uint32_t limit = (uint32_t)want_nb * plan_.block * 2u;
-        std::vector<uint32_t> start(n_groups, 0), fused_count(n_groups, 0);
-        uint32_t n_fused = 0;
-        for (size_t g = 0; g < n_groups; ++g) {
-            start[g] = n_fused;
-            if (count[g] <= limit) {
-                fused_count[g] = count[g];
-                n_fused += count[g];
-            }
-        }
-        std::vector<uint32_t> border(std::max<uint32_t>(n_fused, 1)), dense, cursor(start);
-        for (uint32_t e = 0; e < n_entries_; ++e) {  // stable: node order inside a group
-            if (key[e] == kNone) continue;
-            if (count[key[e]] <= limit) border[cursor[key[e]]++] = e;
-            else dense.push_back(e);
-        }
-        WV_HIP(hipMalloc((void**)&border_, border.size() * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(border_, border.data(), border.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        WV_HIP(hipMalloc((void**)&gstart_, n_groups * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(gstart_, start.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
-        WV_HIP(hipMalloc((void**)&gcount_, n_groups * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(gcount_, fused_count.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
-        n_dense_ = (uint32_t)dense.size();
-        if (n_dense_) {
-            WV_HIP(hipMalloc((void**)&dense_order_, dense.size() * sizeof(uint32_t)));
-            WV_HIP(hipMemcpy(dense_order_, dense.data(), dense.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
-        fused_nb_ = want_nb;
+        plane_start_.assign((size_t)nz_ + 1, 0);
+        for (uint32_t e = 0; e < n_entries_; ++e)
+            if (bnode[e] != wv::INVALID_NODE) ++plane_start_[bnode[e] / plane + 1];
+        for (int z = 0; z < nz_; ++z) plane_start_[z + 1] += plane_start_[z];
+        std::vector<uint32_t> order(std::max<uint32_t>(plane_start_[nz_], 1)), cursor(plane_start_.begin(), plane_start_.end() - 1);
+        for (uint32_t e = 0; e < n_entries_; ++e)
+            if (bnode[e] != wv::INVALID_NODE) order[cursor[bnode[e] / plane]++] = e;
+        WV_HIP(hipMalloc((void**)&zorder_, order.size() * sizeof(uint32_t)));
+        WV_HIP(hipMemcpy(zorder_, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         return WV_OK;
     }
 
@@ -442,14 +386,7 @@ public:
             a.stripe_rows = plan_.stripe_rows;
             a.tiles_y_stripe = plan_.tiles_y_stripe;
             a.passes = plan_.passes;
-            a.nb = fused_nb_;
-            a.gz_begin = z_begin_;
-            a.gz_count = z_end_ - z_begin_;
-            a.border = border_;
-            a.gstart = gstart_;
-            a.gcount = gcount_;
-            if (fused_nb_ > 0) a.b = boundary_args(prev, cur, flag);
-            grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe + a.nb);
+            grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
         } else if (plan_.variant == 0) {
             a.zc = std::min(plan_.zc, z1 - z0);
             a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
@@ -498,18 +435,21 @@ public:
         return b;
     }
 
-    // the boundary nodes the streaming launch does not cover (all of them unless fused)
-    int launch_boundary(Real* prev, const Real* cur, int* flag, hipStream_t on) {
-        if (!n_entries_) return WV_OK;
+    // Boundary nodes of planes [z0, z1).  MUST be enqueued after the streaming launch that covers
+    // those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
+    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1) {
+        if (!n_entries_ || z0 >= z1) return WV_OK;
         wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
         uint32_t n = n_entries_;
-        if (fused_nb_ > 0) {
-            if (!n_dense_) return WV_OK;
-            b.order = dense_order_;
-            b.n_order = n_dense_;
-            n = n_dense_;
+        if (z0 > z_begin_ || z1 < z_end_) {
+            const int rc = build_plane_order();
+            if (rc != WV_OK) return rc;
+            b.order = zorder_ + plane_start_[z0];
+            b.n_order = plane_start_[z1] - plane_start_[z0];
+            n = b.n_order;
+            if (!n) return WV_OK;
         }
-        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n + 255) / 256), dim3(256), 0, on, b);
+        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n + 255) / 256), dim3(256), 0, stream_, b);
         return WV_OK;
     }
 
@@ -539,34 +479,24 @@ public:
             pp.flag_init = static_flag_;
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
-        // The boundary kernel and the streaming kernel write disjoint nodes of `prev` and only read
-        // `cur`, so they run concurrently: boundary nodes on their own stream, fenced by two events
-        // per step (inputs ready -> boundary; boundary done -> next step / halo exchange).
-        hipStream_t bstream = overlap_boundary_ && n_entries_ ? bnd_stream_ : stream_;
-        if (bstream != stream_) {
-            WV_HIP(hipEventRecord(ev_inputs_ready_, stream_));
-            WV_HIP(hipStreamWaitEvent(bstream, ev_inputs_ready_, 0));
-        }
+        // Order on the one compute stream: a plane's sweep, then that plane's boundary nodes.
         if (comm_) {
             // slab faces first, so that their exchange overlaps the interior update
             const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
             const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
-            if ((rc = launch_boundary(prev, cur, flag, bstream))) return rc;
-            if (bstream != stream_) WV_HIP(hipEventRecord(ev_boundary_done_, bstream));
             if ((rc = launch_stream(prev, cur, flag, z_begin_, zi0, false))) return rc;
             if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag, z_begin_, zi0))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag, zi1, z_end_))) return rc;
             WV_HIP(hipGetLastError());
-            if (!comm_->exchange_faces(stream_, bstream != stream_ ? ev_boundary_done_ : nullptr, prev, sizeof(Real),
-                                       pitch_, ny_, nz_, &cerr))
+            if (!comm_->exchange_faces(stream_, nullptr, prev, sizeof(Real), pitch_, ny_, nz_, &cerr))
                 return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
         } else {
-            if ((rc = launch_boundary(prev, cur, flag, bstream))) return rc;
-            if (bstream != stream_) WV_HIP(hipEventRecord(ev_boundary_done_, bstream));
             if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
+            if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) return rc;
         }
-        // whatever follows on the main stream (next step, flag copy, field reads) sees both kernels
-        if (bstream != stream_) WV_HIP(hipStreamWaitEvent(stream_, ev_boundary_done_, 0));
         WV_HIP(hipGetLastError());
         return WV_OK;
     }
@@ -819,7 +749,6 @@ public:
 
     int synchronize() override {
         WV_HIP(hipStreamSynchronize(stream_));
-        WV_HIP(hipStreamSynchronize(bnd_stream_));
         WV_HIP(hipStreamSynchronize(comm_stream_));
         return WV_OK;
     }
@@ -843,21 +772,17 @@ private:
     void release() {
         comm_.reset();
         if (stream_) (void)hipStreamSynchronize(stream_);
-        if (bnd_stream_) (void)hipStreamSynchronize(bnd_stream_);
         for (auto& e : events_) (void)hipEventDestroy(e);
         events_.clear();
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
         void* ptrs[] = {cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
-                        border_, gstart_, gcount_, dense_order_};
+                        zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (flags_host_) (void)hipHostFree(flags_host_);
         if (stream_) (void)hipStreamDestroy(stream_);
         if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
-        if (bnd_stream_) (void)hipStreamDestroy(bnd_stream_);
-        if (ev_inputs_ready_) (void)hipEventDestroy(ev_inputs_ready_);
-        if (ev_boundary_done_) (void)hipEventDestroy(ev_boundary_done_);
     }
 
     wv_options opt_{};
@@ -873,11 +798,9 @@ private:
     uint8_t* btype_ = nullptr;
     double* fmem_ = nullptr;
     uint32_t* cidx_ = nullptr;
-    // boundary schedule of the fused sweep launch (build_boundary_schedule)
-    uint32_t *border_ = nullptr, *gstart_ = nullptr, *gcount_ = nullptr, *dense_order_ = nullptr;
-    uint32_t n_dense_ = 0;
-    int fused_nb_ = 0;
-    std::vector<uint32_t> bnode_host_;
+    // boundary entries by plane (build_plane_order; slab path only)
+    uint32_t* zorder_ = nullptr;
+    std::vector<uint32_t> plane_start_;
     int* status_ = nullptr;
     int* static_flag_dev_ = nullptr;
     int static_flag_ = 0;
@@ -886,9 +809,7 @@ private:
     int* flags_host_ = nullptr;
     void* scratch_ = nullptr;
     Real courant_ = 0, courant_sq_ = 0;
-    hipStream_t stream_ = nullptr, comm_stream_ = nullptr, bnd_stream_ = nullptr;
-    hipEvent_t ev_inputs_ready_ = nullptr, ev_boundary_done_ = nullptr;
-    bool overlap_boundary_ = false;
+    hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
     StreamPlan plan_;
     int tune_variant_ = -1, tune_ry_ = 0, tune_nwx_ = 0, tune_nwy_ = 0, tune_zchunks_ = 0;
     std::vector<hipEvent_t> events_;

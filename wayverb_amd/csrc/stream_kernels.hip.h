@@ -2,8 +2,7 @@
 //
 // Replaces the `normal_waveguide_update` arm of `condensed_waveguide`
 // (src/waveguide/src/program.cpp:393-412, :494-530) and its id_none arm (:485).  Boundary nodes
-// (class 2) are left to boundary_kernels.hip.h; the two kernels write disjoint nodes of
-// `prev` and read only `cur`, so they may run in either order or concurrently.
+// (class 2) are left to boundary_kernels.hip.h, which runs after this kernel (see X_STORE_ALL).
 //
 // Arithmetic per updated node, in the pressure type Real, no FMA contraction:
 //     s = 0; s += nx; s += px; s += ny; s += py; s += nz; s += pz   (off-grid ports contribute +0,
@@ -16,7 +15,6 @@
 //
 // Bound: HBM.  Algorithmic traffic per node = read prev + read cur + write next = 3*sizeof(Real).
 #pragma once
-#include "boundary_kernels.hip.h"
 #include "device_common.hip.h"
 
 namespace wv {
@@ -24,7 +22,8 @@ namespace wv {
 // Experiment switches (tools/stream_bench.hip only).  The first group changes results and exists
 // to price a piece of the kernel; the nt ones are result-neutral cache hints.
 enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
-             X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512 };
+             X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512,
+             X_STORE_ALL = 1024 };  // boundary nodes get their old value written back: no masked stores
 // what the engine runs: `prev` and `next` are touched exactly once per step, so they carry the
 // non-temporal hint and do not displace the re-used `cur` lines from L2
 constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
@@ -65,8 +64,12 @@ __device__ __forceinline__ typename Vec16<Real>::type update_row(
         const uint32_t c = (cls_bits >> (2 * j)) & 3u;
         const Real o = (c & 1u) ? s : Real(0);
         bad |= bad_bits(o);
-        out[j] = o;
-        skip |= (c == CLS_BOUNDARY);
+        if (X & X_STORE_ALL) {
+            out[j] = (c == CLS_BOUNDARY) ? pv[j] : o;  // boundary node: its old value goes back
+        } else {
+            out[j] = o;
+            skip |= (c == CLS_BOUNDARY);
+        }
     }
     return out;
 }
@@ -76,7 +79,7 @@ template <typename Real, int X>
 __device__ __forceinline__ void store_row(Real* q, typename Vec16<Real>::type out, uint32_t cls_bits, bool skip) {
     using V = typename Vec16<Real>::type;
     constexpr int VX = Vec16<Real>::N;
-    if (!__any(skip)) {
+    if ((X & X_STORE_ALL) || !__any(skip)) {
         store_vec<V, (X & X_NT_STORE) != 0>(reinterpret_cast<V*>(q), out);
     } else {
 #pragma unroll
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
         const int z = a.z_begin + (int)(q / a.ny);
         const int64_t row = (int64_t)z * a.ny + y;
         const int64_t idx = row * a.pitch + x;
-        const uint32_t c = (a.cls[row * a.cls_pitch + (x >> 2)] >> ((x & 3) * 2)) & 3u;
+        const uint32_t c = (a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)] >> ((x & 3) * 2)) & 3u;
         if (c == CLS_BOUNDARY) continue;
         Real out = 0;
         if (c & 1u) {
@@ -162,10 +165,14 @@ struct TileIO {
         }
         return e;
     }
-    // 2 class bits for each of this lane's VX nodes
-    __device__ __forceinline__ uint32_t cls_row(int y, int z) const {
-        const uint8_t byte = a.cls[((int64_t)z * a.ny + y) * a.cls_pitch + (xl >> 2)];
-        return (VX == 4) ? (uint32_t)byte : (((uint32_t)byte >> ((lane & 1) * 4)) & 0xFu);
+    // class bits of this lane's VX nodes for the 4 rows of row group y >> 2: ONE dword load
+    __device__ __forceinline__ uint32_t cls_word(int y, int z) const {
+        return reinterpret_cast<const uint32_t*>(a.cls)[cls_word_index(xl, y, z, a.ny, a.cls_pitch)];
+    }
+    // ... and the 2 bits per node of row y out of that word
+    __device__ __forceinline__ uint32_t cls_of_row(uint32_t word, int y) const {
+        const uint32_t byte = (word >> ((y & 3) * 8)) & 0xFFu;
+        return (VX == 4) ? byte : ((byte >> ((lane & 1) * 4)) & 0xFu);
     }
 };
 
@@ -233,11 +240,13 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 #pragma unroll
     for (int r = 0; r < RY + 2; ++r) above[r] = halo_or_cur(r, zb + 1);
     above_e = load_edges(zb + 1);
+    static_assert(RY <= 4 && 4 % RY == 0, "a tile's rows must sit inside one class-map row group");
+    uint32_t clw = (X & X_NO_CLS) ? 0x55555555u : io.cls_word(y0, zb);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         const bool live = y0 + r < a.ny;
         pv[r] = live ? io.template prev_row<NTP>(y0 + r, zb) : (V)(Real(0));
-        cl[r] = (X & X_NO_CLS) ? 0x55u : (live ? io.cls_row(y0 + r, zb) : 0xAAu);
+        cl[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
     }
 
     int bad = 0;
@@ -248,11 +257,12 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 #pragma unroll
         for (int r = 0; r < RY + 2; ++r) nxt[r] = halo_or_cur(r, z + 2);
         const Real nxt_e = load_edges(z + 2);
+        clw = (X & X_NO_CLS) ? 0x55555555u : (z + 1 < ze ? io.cls_word(y0, z + 1) : 0u);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const bool live = y0 + r < a.ny && z + 1 < ze;
             pv_n[r] = live ? io.template prev_row<NTP>(y0 + r, z + 1) : (V)(Real(0));
-            cl_n[r] = (X & X_NO_CLS) ? 0x55u : (live ? io.cls_row(y0 + r, z + 1) : 0xAAu);
+            cl_n[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
         }
         // ---- update plane z
 #pragma unroll
@@ -301,8 +311,16 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 //   - all 8 XCDs advance through z together, so the chip-wide access front is 8 short runs
 //     per stream inside one plane.
 // `cur` is then fetched from HBM once per step (plus 2 halo rows per stripe).
+//
+// Stores are always full 16-byte vectors: a boundary node gets its OLD `prev` value written back
+// (X_STORE_ALL) instead of being masked out, which removes the per-row "does this wave hold a
+// boundary node" vote and the masked-store path (measured -4 %).  The price is an ordering rule:
+// this kernel must have finished a plane before the boundary kernel updates that plane's boundary
+// nodes (engine.hip enforces it: sweep, then boundary, on one stream).
 // ---------------------------------------------------------------------------------------------
-template <typename Real, int RY, int NWX, int NWY, int X = X_NT_STORE | X_NT_PREV>
+constexpr int X_SWEEP = X_NT_STORE | X_NT_PREV | X_STORE_ALL;
+
+template <typename Real, int RY, int NWX, int NWY, int X = X_SWEEP>
 __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
     using V = typename Vec16<Real>::type;
     constexpr int WX = TileIO<Real>::WX;
@@ -315,24 +333,12 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
     const int per_plane = a.tiles_x * a.tiles_y_stripe;
-    const int per_group = per_plane + a.nb;
-    const int tl = j % per_group;
-    j /= per_group;
+    const int tl = j % per_plane;
+    j /= per_plane;
     const int nzr = a.z_end - a.z_begin;
     const int z = a.z_begin + j % nzr;
     const int pass = j / nzr;
     const int stripe = pass * 8 + xcd;
-
-    if (tl >= per_plane) {
-        // ---- a boundary workgroup: this (pass, plane, XCD) group's boundary nodes
-        const int g = (pass * a.gz_count + (z - a.gz_begin)) * 8 + xcd;
-        const uint32_t start = a.gstart[g], count = a.gcount[g];
-        int bbad = 0;
-        for (uint32_t i = (uint32_t)(tl - per_plane) * blockDim.x + threadIdx.x; i < count; i += (uint32_t)a.nb * blockDim.x)
-            boundary_entry<Real>(a.b, a.border[start + i], bbad);
-        if (bbad) atomicOr(a.flag, bbad);
-        return;
-    }
     const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
 
     const int y_lo = stripe * a.stripe_rows;
@@ -348,15 +354,17 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     uint32_t cl[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) above[r] = io.template cur_row<(X & X_NT_CUR) != 0>(y0 + r, z + 1);  // first touch: HBM
+    static_assert(RY <= 4 && 4 % RY == 0, "a tile's rows must sit inside one class-map row group");
+    const uint32_t clw = (X & X_NO_CLS) ? 0x55555555u : io.cls_word(y0, z);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         const bool live = y0 + r < y_hi;
         pv[r] = live ? io.template prev_row<NTP>(y0 + r, z) : (V)(Real(0));
-        cl[r] = live ? io.cls_row(y0 + r, z) : 0xAAu;
+        cl[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
     }
 #pragma unroll
     for (int r = 0; r < RY + 2; ++r) mid[r] = io.template cur_row<(X & X_NT_MID) != 0>(y0 - 1 + r, z);  // L2: was z+1 a plane ago
-    const Real mid_e = io.template edges<RY>(y0, z);
+    const Real mid_e = (X & X_NO_EDGE) ? Real(0) : io.template edges<RY>(y0, z);
 #pragma unroll
     for (int r = 0; r < RY; ++r) below[r] = io.template cur_row<(X & X_NT_BELOW) != 0>(y0 + r, z - 1);  // L2: last use
 
