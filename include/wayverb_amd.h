@@ -209,6 +209,16 @@ int wv_make_box_nodes(int32_t nx, int32_t ny, int32_t nz_global, int32_t z_begin
                       int32_t number_from, int32_t number_to, wv_condensed_node* nodes,
                       uint64_t counts[3]);
 
+/* ---- mesh set-up (first slice) -------------------------------------------- */
+/* From per-node inside flags (what `set_node_inside` yields, mesh_setup_program.cpp:110-140) to
+ * the `condensed_node` array: the reference's `set_node_boundary_type` kernel
+ * (src/waveguide/src/mesh_setup_program.cpp:66-108,142-172) on the GPU, then `set_boundary_index`
+ * as compute_boundary_index_data applies it (boundary_coefficient_finder.cpp:11-19,44-54):
+ * counts[0] = 1-D boundary OR re-entrant nodes, counts[1] = 2-D, counts[2] = 3-D.
+ * inside: uint8[nx*ny*nz], non-zero = inside the model. */
+int wv_classify_nodes(int32_t nx, int32_t ny, int32_t nz, const uint8_t* inside, wv_condensed_node* nodes,
+                      uint64_t counts[3]);
+
 #ifdef __cplusplus
 }
 #endif

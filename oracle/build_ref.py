@@ -120,6 +120,59 @@ def assemble(promote):
     return "\n".join(parts)
 
 
+def representation_any(path, type_name):
+    """Like representation(), for specialisations spelled without the waveguide:: prefix."""
+    with open(path) as f:
+        text = f.read()
+    m = re.search(r"cl_representation<\s*" + re.escape(type_name) + r"\s*>\s*final\s*\{(.*?)\};", text, re.S)
+    if not m:
+        raise RuntimeError("no cl_representation for %s in %s" % (type_name, path))
+    return RAW.findall(m.group(1))[0]
+
+
+def assemble_setup():
+    """The mesh set-up program, in the order of src/waveguide/src/mesh_setup_program.cpp:175-193."""
+    core = os.path.join(REF, "src", "core")
+    cinc = os.path.join(core, "include", "core", "cl")
+    inc = os.path.join(WG, "include", "waveguide")
+    parts = [
+        representation_any(os.path.join(cinc, "scene_structs.h"), "bands_type"),
+        representation_any(os.path.join(cinc, "scene_structs.h"), "surface<simulation_bands>"),
+        representation_any(os.path.join(cinc, "triangle.h"), "triangle"),
+        representation_any(os.path.join(cinc, "scene_structs.h"), "triangle_verts"),
+        representation_any(os.path.join(cinc, "voxel_structs.h"), "aabb"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "ray"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "triangle_inter"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "intersection"),
+        representation(os.path.join(inc, "cl", "utils.h"), "boundary_type"),
+        representation(os.path.join(inc, "cl", "structs.h"), "condensed_node"),
+        representation(os.path.join(inc, "mesh_descriptor.h"), "mesh_descriptor"),
+        raw_strings(os.path.join(core, "src", "cl", "geometry.cpp"))[0],
+        raw_strings(os.path.join(core, "src", "cl", "voxel.cpp"))[0],
+        raw_strings(os.path.join(WG, "src", "cl", "utils.cpp"))[0],
+        raw_strings(os.path.join(WG, "src", "mesh_setup_program.cpp"))[0],
+    ]
+    return "\n".join(parts)
+
+
+def build_setup(tmp, verbose):
+    """oracle/_ref/libwvref_setup.so: set_node_inside + set_node_boundary_type, unmodified."""
+    cl = os.path.join(tmp, "setup.cl")
+    with open(cl, "w") as f:
+        f.write(assemble_setup())
+    obj = os.path.join(tmp, "setup.o")
+    subprocess.check_call([
+        CLANG, "-x", "cl", "-cl-std=CL1.2", "-target", "x86_64-unknown-linux-gnu",
+        "-Xclang", "-finclude-default-header", "-O2", "-ffp-contract=off",
+        "-fPIC", "-Werror", "-c", cl, "-o", obj])
+    so = os.path.join(OUT, "libwvref_setup.so")
+    subprocess.check_call([
+        CLANGXX, "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-std=c++14",
+        os.path.join(HERE, "ref_shim_setup.cpp"), obj, "-o", so])
+    if verbose:
+        print("[build_ref] built", so)
+
+
 def build(verbose=True):
     if not os.path.isdir(WG):
         if verbose:
@@ -128,6 +181,7 @@ def build(verbose=True):
     os.makedirs(OUT, exist_ok=True)
     shim = os.path.join(HERE, "ref_shim.cpp")
     with tempfile.TemporaryDirectory(prefix="wvref_") as tmp:
+        build_setup(tmp, verbose)
         for tag, promote in (("f32", False), ("f64", True)):
             cl = os.path.join(tmp, "program_%s.cl" % tag)
             with open(cl, "w") as f:

@@ -21,7 +21,7 @@ def _ptr(a):
 
 def build_oracle():
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("waveguide_oracle.c", "waveguide_oracle_body.h")]
+    srcs = [os.path.join(HERE, f) for f in ("waveguide_oracle.c", "waveguide_oracle_body.h", "mesh_setup_oracle.c")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -49,6 +49,20 @@ class Oracle:
         self.lib.wvo_filter_test.argtypes = [C.c_void_p] * 4 + [C.c_int]
         self.lib.wvo_directional_receiver.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                                       C.c_double, C.c_void_p]
+
+    def classify(self, inside_mask):
+        """Node classification from an inside mask [nz, ny, nx] (bool): boundary types
+        (`set_node_boundary_type`) + boundary indices.  Returns (nodes, (n1, n2, n3))."""
+        from wayverb_amd import mesh as M
+        nz, ny, nx = inside_mask.shape
+        nodes = np.zeros(nx * ny * nz, dtype=M.condensed_node_dtype)
+        nodes["boundary_type"] = np.where(inside_mask.reshape(-1), 1, 0)
+        self.lib.wvo_set_node_boundary_type.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.lib.wvo_set_node_boundary_type(_ptr(nodes), nx, ny, nz)
+        counts = (C.c_uint64 * 3)()
+        self.lib.wvo_set_boundary_indices.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        self.lib.wvo_set_boundary_indices(_ptr(nodes), nodes.shape[0], counts)
+        return nodes, tuple(int(c) for c in counts)
 
     @staticmethod
     def real(dtype):
@@ -103,6 +117,27 @@ class Oracle:
         self.lib.wvo_directional_receiver(_ptr(p7), p7.shape[0], spacing, sample_rate,
                                           ambient_density, _ptr(out))
         return out
+
+
+class ReferenceSetup:
+    """The reference's mesh set-up kernels, host-compiled (oracle/_ref/libwvref_setup.so)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(HERE, "_ref", "libwvref_setup.so"))
+        self.lib.wvref_set_node_boundary_type.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        self.lib.wvref_set_node_boundary_type.restype = None
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(HERE, "_ref", "libwvref_setup.so"))
+
+    def set_node_boundary_type(self, inside_mask):
+        from wayverb_amd import mesh as M
+        nz, ny, nx = inside_mask.shape
+        nodes = np.zeros(nx * ny * nz, dtype=M.condensed_node_dtype)
+        nodes["boundary_type"] = np.where(inside_mask.reshape(-1), 1, 0)
+        self.lib.wvref_set_node_boundary_type(_ptr(nodes), nx, ny, nz, 0.1)
+        return nodes
 
 
 def reference_available():

@@ -32,7 +32,16 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-#define WV_HIP(expr)                                                                              \
+}  // namespace
+
+namespace wv {
+// for the other translation units of the library (mesh_setup.hip)
+int fail_with(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace wv
+
+namespace {
+
+#define WV_HIP(expr)                                                                            \
     do {                                                                                          \
         hipError_t err__ = (expr);                                                                \
         if (err__ != hipSuccess)                                                                  \

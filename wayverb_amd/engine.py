@@ -28,7 +28,7 @@ EXPORTS = [
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch",
+    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes",
 ]
 
 
@@ -103,6 +103,7 @@ def load_library():
     lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.wv_filter_test_2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     lib.wv_field_pitch.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.wv_classify_nodes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.wv_comm_unique_id.argtypes = [C.c_void_p]
     lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.wv_comm_destroy.argtypes = [C.c_void_p]
@@ -141,6 +142,17 @@ def make_box_nodes(nx, ny, nz_global, z_begin=0, z_count=None, number_from=None,
     counts = (C.c_uint64 * 3)()
     _check(lib.wv_make_box_nodes(nx, ny, nz_global, z_begin, z_count, number_from, number_to,
                                  nodes.ctypes.data_as(C.c_void_p), counts))
+    return nodes, tuple(int(c) for c in counts)
+
+
+def classify_nodes(inside_mask):
+    """wv_classify_nodes: inside mask [nz, ny, nx] -> (condensed nodes, (n1, n2, n3))."""
+    lib = load_library()
+    mask = np.ascontiguousarray(inside_mask, dtype=np.uint8)
+    nz, ny, nx = mask.shape
+    nodes = np.zeros(nx * ny * nz, dtype=M.condensed_node_dtype)
+    counts = (C.c_uint64 * 3)()
+    _check(lib.wv_classify_nodes(nx, ny, nz, mask.ctypes.data_as(C.c_void_p), nodes.ctypes.data_as(C.c_void_p), counts))
     return nodes, tuple(int(c) for c in counts)
 
 

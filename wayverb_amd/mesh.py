@@ -207,6 +207,56 @@ def box_mesh(nx, ny, nz, coefficients=None, surface_of_face=None, spacing=0.05):
     return Mesh((nx, ny, nz), nodes, coefficients, bidx[0], bidx[1], bidx[2], spacing=spacing)
 
 
+def mesh_from_nodes(dims, nodes, counts, coefficients, surface_of_port=None, spacing=0.05):
+    """Mesh around already-classified nodes (wv_classify_nodes / the reference's
+    set_node_boundary_type + set_boundary_index).  The filter of inner direction p (port order
+    nx,px,ny,py,nz,pz) of every boundary node takes surface `surface_of_port[p]` -- a stand-in
+    for the closest-triangle lookup of boundary_coefficient_finder.
+    counts[0] includes re-entrant nodes, which carry an (unused) 1-D slot like in the reference."""
+    if surface_of_port is None:
+        surface_of_port = [0] * 6
+    sof = np.asarray(surface_of_port, dtype=np.uint32)
+    t = nodes["boundary_type"]
+    k = nodes["boundary_index"]
+    pc = np.zeros(t.shape, dtype=np.int32)
+    for bit in range(8):
+        pc += (t >> bit) & 1
+    is_b = (t & (ID_INSIDE | ID_REENTRANT)) == 0
+    bidx = []
+    for d in (1, 2, 3):
+        arr = np.zeros((counts[d - 1], d), dtype=np.uint32)
+        sel = np.nonzero((pc == d) & is_b)[0]
+        slot = np.zeros(sel.shape[0], dtype=np.int64)
+        for p in range(6):
+            has = (t[sel] & (1 << (p + 1))) != 0
+            rows = np.nonzero(has)[0]
+            arr[k[sel][rows], slot[rows]] = sof[p]
+            slot[rows] += 1
+        bidx.append(arr)
+    return Mesh(dims, nodes, coefficients, bidx[0], bidx[1], bidx[2], spacing=spacing)
+
+
+def room_mask(shape, kind, seed=0):
+    """Inside masks [nz, ny, nx] of a few non-box rooms for tests: 'L' (L-shaped prism),
+    'sphere', 'blob' (sphere + box + seeded speckle: every boundary type incl. re-entrant)."""
+    nz, ny, nx = shape
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    margin = (x > 1) & (y > 1) & (z > 1) & (x < nx - 2) & (y < ny - 2) & (z < nz - 2)
+    if kind == "L":
+        m = margin & ~((x >= nx // 2) & (y >= ny // 2))
+    elif kind == "sphere":
+        m = (x - (nx - 1) / 2) ** 2 + (y - (ny - 1) / 2) ** 2 + (z - (nz - 1) / 2) ** 2 < (min(shape) / 2 - 2.5) ** 2
+    elif kind == "blob":
+        rng = np.random.default_rng(seed)
+        m = ((x - nx / 2) ** 2 + (y - ny / 2) ** 2 + (z - nz / 2) ** 2 < (min(shape) / 2.6) ** 2) | \
+            ((x > 2) & (x < nx - 3) & (y > 2) & (y < ny // 2) & (z > 2) & (z < nz - 3))
+        m = m & margin
+        m = m ^ ((rng.random(shape) < 0.02) & margin)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(m)
+
+
 # ---- coefficient helpers (inputs for tests / benches; host-side, run once) ------------------
 
 def make_coefficients(b, a):
