@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-end evidence: tests, bench (N=1), rocprofv3 kernel stats + PMC traffic, engine sweeps.
+R=${1:-r01}
+mkdir -p gpurun_out/$R; export TMPDIR=/tmp
+python -m pytest tests -m gpu -q > gpurun_out/$R/pytest_gpu.txt 2>&1; tail -3 gpurun_out/$R/pytest_gpu.txt
+python __graft_entry__.py --smoke > gpurun_out/$R/smoke.txt 2>&1; tail -1 gpurun_out/$R/smoke.txt
+python bench.py > gpurun_out/$R/bench_n1.json 2> gpurun_out/$R/bench_n1.err; tail -1 gpurun_out/$R/bench_n1.json | cut -c1-300
+python bench.py --precision f32 --no-cpu-baseline --no-small > gpurun_out/$R/bench_n1_f32.json 2>/dev/null
+python bench.py --nx 256 --ny 256 --nz 256 --no-cpu-baseline --no-small --steps 10000 --warmup 500 > gpurun_out/$R/bench_256cubed_10k_steps.json 2>/dev/null; tail -1 gpurun_out/$R/bench_256cubed_10k_steps.json | cut -c1-200
+CMD="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-small"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -o bench -- $CMD > gpurun_out/$R/trace.log 2>&1
+cp gpurun_out/$R/trace/bench_kernel_stats.csv gpurun_out/$R/rocprof_kernel_stats.csv; head -4 gpurun_out/$R/rocprof_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmc_fetch -o bench -- $CMD > gpurun_out/$R/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$R/pmc_write -o bench -- $CMD > gpurun_out/$R/pmc_write.log 2>&1
+python3 - "$R" <<'PY'
+import csv, collections, glob, json, sys
+R=sys.argv[1]; out={}
+for tag in ('pmc_fetch','pmc_write'):
+    for f in glob.glob('gpurun_out/%s/%s/**/*counter_collection.csv'%(R,tag), recursive=True):
+        agg=collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r['Kernel_Name'].split('(')[0][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+        for k,v in agg.items():
+            for c,x in v.items(): out.setdefault(k,{})[c]={'mean':sum(x)/len(x),'n':len(x)}
+json.dump(out, open('gpurun_out/%s/pmc_summary.json'%R,'w'), indent=1)
+for k,v in out.items():
+    if 'sweep' in k or 'boundary_kernel' in k: print(k, v)
+PY
+rm -rf gpurun_out/$R/trace gpurun_out/$R/pmc_fetch gpurun_out/$R/pmc_write
+python tools/sweep_stream.py --steps 10 --out gpurun_out/$R/sweep_engine_1024_f64.json > /dev/null 2>&1
+ls gpurun_out/$R
