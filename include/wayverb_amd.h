@@ -219,6 +219,28 @@ int wv_make_box_nodes(int32_t nx, int32_t ny, int32_t nz_global, int32_t z_begin
 int wv_classify_nodes(int32_t nx, int32_t ny, int32_t nz, const uint8_t* inside, wv_condensed_node* nodes,
                       uint64_t counts[3]);
 
+/* Second slice: the inside flags themselves, for triangle-soup scenes.
+ * vertices: float[n][4] (cl_float3); triangles: uint32[m][4] = {surface, v0, v1, v2}
+ * (src/core/include/core/cl/triangle.h:9-14).
+ *
+ * wv_voxelise (host): the flattened voxel -> triangle-list array of `get_flattened`
+ * (src/core/src/spatial_division/voxel_collection.cpp:9-37) over a side^3 grid on [aabb_min,
+ * aabb_max]; a triangle is listed in every voxel whose box, padded by 0.001, it overlaps
+ * (src/core/include/core/spatial_division/voxelised_scene_data.h:28-44).  Two-call protocol:
+ * *needed always receives the word count; nothing is written unless capacity >= *needed.
+ *
+ * wv_nodes_inside (GPU): the reference's `set_node_inside` kernel
+ * (src/waveguide/src/mesh_setup_program.cpp:110-140; voxel ray-parity test
+ * src/core/src/cl/voxel.cpp:98-225) for every node of the mesh (nx, ny, nz, min_corner, spacing):
+ * inside[i] = 1 / 0. */
+int wv_voxelise(const float* vertices, uint32_t n_vertices, const uint32_t* triangles, uint32_t n_triangles,
+                const float aabb_min[3], const float aabb_max[3], uint32_t side, uint32_t* out, uint64_t capacity,
+                uint64_t* needed);
+int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3], float spacing,
+                    const uint32_t* voxel_index, uint64_t n_voxel_words, const float aabb_min[3],
+                    const float aabb_max[3], uint32_t side, const uint32_t* triangles, uint32_t n_triangles,
+                    const float* vertices, uint32_t n_vertices, uint8_t* inside);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,3 +87,116 @@ def test_hot_path_parity_on_non_box_rooms(oracle, built_library, shape, kind, ta
     assert got["previous"].tobytes() == want["previous"].tobytes()
     for a, b in zip(got["bd"], want["bd"]):
         assert a.tobytes() == b.tobytes()
+
+
+# ---- slice 2: inside flags from triangle scenes ------------------------------------------------------
+from wayverb_amd import scene as S  # noqa: E402
+
+
+def _scenes():
+    L = [(0, 0), (4, 0), (4, 2), (2, 2), (2, 3), (0, 3)]
+    return {
+        "box": S.box_scene((0.0, 0.0, 0.0), (2.0, 1.5, 2.5)),
+        "L": S.prism_scene(L, 0.0, 2.5),
+        "sphere": S.icosphere_scene((0.1, -0.2, 0.3), 1.5, 2),
+    }
+
+
+def _grid_for(vertices, spacing):
+    """What compute_voxels_and_mesh does (src/waveguide/src/mesh.cpp:143-159): adjusted boundary
+    around the geometry with a node at the anchor (here the centroid), octree depth 5 -> side 32,
+    mesh dimensions = extent / spacing (truncated, mesh.cpp:65-71)."""
+    lo = vertices[:, :3].min(axis=0)
+    hi = vertices[:, :3].max(axis=0)
+    anchor = vertices[:, :3].mean(axis=0)
+    c0, c1 = S.compute_adjusted_boundary(lo, hi, anchor, spacing)
+    dims = tuple(int(v) for v in ((c1 - c0) / np.float32(spacing)).astype(np.int32))
+    return (c0, c1), dims
+
+
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_voxeliser_lists_every_triangle_where_it_passes(built_library, name):
+    from wayverb_amd import engine as E
+    v, t = _scenes()[name]
+    aabb, _ = _grid_for(v, 0.2)
+    side = 8
+    vox = E.voxelise(v, t, aabb, side)
+    rng = np.random.default_rng(1)
+    dim = (aabb[1] - aabb[0]) / side
+    for ti in range(t.shape[0]):
+        a, b, c = (v[t[ti, k], :3].astype(np.float64) for k in (1, 2, 3))
+        w = rng.dirichlet([1, 1, 1], 64)
+        pts = w[:, :1] * a + w[:, 1:2] * b + w[:, 2:] * c
+        cells = np.floor((pts - aabb[0]) / dim).astype(int)
+        for cx, cy, cz in np.unique(cells, axis=0):
+            off = vox[cx * side * side + cy * side + cz]
+            assert ti in vox[off + 1: off + 1 + vox[off]]
+    # structure: offsets are increasing and the array is exactly used up
+    offs = vox[:side ** 3]
+    assert offs[0] == side ** 3 and np.all(np.diff(offs.astype(np.int64)) >= 1)
+    assert offs[-1] + 1 + vox[offs[-1]] == vox.shape[0]
+
+
+@pytest.mark.skipif(not ReferenceSetup.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_inside_restatement_matches_reference_kernel(oracle, built_library, name):
+    from wayverb_amd import engine as E
+    v, t = _scenes()[name]
+    spacing = 0.17
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    got = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    want = ReferenceSetup().nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    assert np.array_equal(got, want)
+    assert 0 < got.sum() < got.size
+    if name == "box":   # analytic: strictly inside the box
+        nx, ny, nz = dims
+        z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        px = aabb[0][0] + x * np.float32(spacing)
+        py = aabb[0][1] + y * np.float32(spacing)
+        pz = aabb[0][2] + z * np.float32(spacing)
+        clear = lambda p, a, b: (np.abs(p - a) > 1e-4) & (np.abs(p - b) > 1e-4)  # noqa: E731
+        sure = clear(px, 0, 2.0) & clear(py, 0, 1.5) & clear(pz, 0, 2.5)
+        analytic = (px > 0) & (px < 2.0) & (py > 0) & (py < 1.5) & (pz > 0) & (pz < 2.5)
+        assert np.array_equal(got.astype(bool)[sure], analytic[sure])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_gpu_inside_flags_match_restatement(oracle, built_library, name):
+    from wayverb_amd import engine as E
+    v, t = _scenes()[name]
+    spacing = 0.11
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    got = E.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    want = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_scene_to_impulse_response_end_to_end(oracle, built_library):
+    """Triangle scene -> voxels -> inside flags -> node types -> engine run, all on the GPU
+    side of the ABI, against the same chain through the oracle."""
+    from wayverb_amd import engine as E
+    v, t = _scenes()["L"]
+    spacing = 0.125
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    mask = E.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    nodes, counts = E.classify_nodes(mask)
+    o_nodes, o_counts = oracle.classify(oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v).astype(bool))
+    assert counts == o_counts and nodes.tobytes() == o_nodes.tobytes()
+    coeffs = np.array([M.flat_coefficients(0.1)], dtype=M.coefficients_dtype)
+    mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, spacing=spacing)
+    inside = np.nonzero(nodes["boundary_type"] == M.ID_INSIDE)[0]
+    src, rcv = int(inside[len(inside) // 3]), int(inside[2 * len(inside) // 3])
+    steps = 200
+    sig = np.zeros(steps)
+    sig[0] = M.rectilinear_calibration_factor(spacing, 400.0)
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=src, signal=sig, recv=[rcv], init=None)
+    want = run_oracle(oracle, case, np.float32, threads=4)
+    got = run_engine(case, "f32")
+    assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()

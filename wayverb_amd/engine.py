@@ -28,7 +28,7 @@ EXPORTS = [
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes",
+    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
 ]
 
 
@@ -154,6 +154,46 @@ def classify_nodes(inside_mask):
     counts = (C.c_uint64 * 3)()
     _check(lib.wv_classify_nodes(nx, ny, nz, mask.ctypes.data_as(C.c_void_p), nodes.ctypes.data_as(C.c_void_p), counts))
     return nodes, tuple(int(c) for c in counts)
+
+
+def voxelise(vertices, triangles, aabb, side=32):
+    """wv_voxelise: flattened voxel -> triangle lists (uint32 array) for a triangle soup.
+    vertices float32[n, 4] (cl_float3), triangles uint32[m, 4] = {surface, v0, v1, v2}."""
+    lib = load_library()
+    lib.wv_voxelise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    t = np.ascontiguousarray(triangles, dtype=np.uint32)
+    a0 = np.ascontiguousarray(aabb[0], dtype=np.float32)
+    a1 = np.ascontiguousarray(aabb[1], dtype=np.float32)
+    need = C.c_uint64()
+    args = [v.ctypes.data_as(C.c_void_p), v.shape[0], t.ctypes.data_as(C.c_void_p), t.shape[0],
+            a0.ctypes.data_as(C.c_void_p), a1.ctypes.data_as(C.c_void_p), side]
+    _check(lib.wv_voxelise(*args, None, 0, C.byref(need)))
+    out = np.zeros(need.value, dtype=np.uint32)
+    _check(lib.wv_voxelise(*args, out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(need)))
+    return out
+
+
+def nodes_inside(dims, min_corner, spacing, voxel_index, aabb, side, triangles, vertices):
+    """wv_nodes_inside: uint8 inside mask [nz, ny, nx] of the mesh nodes."""
+    lib = load_library()
+    lib.wv_nodes_inside.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64,
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                    C.c_void_p]
+    nx, ny, nz = dims
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    t = np.ascontiguousarray(triangles, dtype=np.uint32)
+    vox = np.ascontiguousarray(voxel_index, dtype=np.uint32)
+    mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+    a0 = np.ascontiguousarray(aabb[0], dtype=np.float32)
+    a1 = np.ascontiguousarray(aabb[1], dtype=np.float32)
+    out = np.zeros(nx * ny * nz, dtype=np.uint8)
+    _check(lib.wv_nodes_inside(nx, ny, nz, mc.ctypes.data_as(C.c_void_p), float(spacing), vox.ctypes.data_as(C.c_void_p),
+                               vox.shape[0], a0.ctypes.data_as(C.c_void_p), a1.ctypes.data_as(C.c_void_p), side,
+                               t.ctypes.data_as(C.c_void_p), t.shape[0], v.ctypes.data_as(C.c_void_p), v.shape[0],
+                               out.ctypes.data_as(C.c_void_p)))
+    return out.reshape(nz, ny, nx)
 
 
 def filter_test_2(inputs, memory, coeffs):
