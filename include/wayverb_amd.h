@@ -241,6 +241,24 @@ int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3
                     const float aabb_max[3], uint32_t side, const uint32_t* triangles, uint32_t n_triangles,
                     const float* vertices, uint32_t n_vertices, uint8_t* inside);
 
+/* Third slice: which scene surface each boundary filter takes -- compute_boundary_index_data
+ * (src/waveguide/src/boundary_coefficient_finder.cpp:38-131) and its kernels
+ * boundary_coefficient_finder_1d/_2d/_3d (src/waveguide/src/boundary_coefficient_program.cpp:
+ * 310-338, 356-413, 429-484; nearest triangle by exact point-triangle distance, :16-143,218-235).
+ * nodes: in, boundary_type as wv_classify_nodes leaves it (boundary_index is ignored);
+ *        out, boundary_index as `run` wants it (1-D numbering without the re-entrant nodes).
+ * b1 [counts[0]][1], b2 [counts[1]][2], b3 [counts[2]][3]: surface index per filter, i.e. the
+ * wv_mesh::boundary_indices_* arrays.  counts[] is always written; WV_E_INVALID_ARGUMENT when a
+ * capacity (in rows) is too small -- wv_classify_nodes' counts are upper bounds -- or when the
+ * mesh lacks 1-D, 2-D or 3-D boundary nodes ("No boundaries.", boundary_coefficient_finder.cpp:30-33).
+ * Entry 0 of the 1-D array is written by its owner only (the reference lets every inside node race
+ * for it). */
+int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3], float spacing,
+                           wv_condensed_node* nodes, const uint32_t* triangles, uint32_t n_triangles,
+                           const float* vertices, uint32_t n_vertices, uint32_t* b1, uint64_t capacity_1,
+                           uint32_t* b2, uint64_t capacity_2, uint32_t* b3, uint64_t capacity_3,
+                           uint64_t counts[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,6 +173,61 @@ def build_setup(tmp, verbose):
         print("[build_ref] built", so)
 
 
+def assemble_bcf():
+    """The boundary coefficient program, in the order of
+    src/waveguide/src/boundary_coefficient_program.cpp:486-504."""
+    core = os.path.join(REF, "src", "core")
+    cinc = os.path.join(core, "include", "core", "cl")
+    inc = os.path.join(WG, "include", "waveguide")
+    bia = os.path.join(inc, "cl", "boundary_index_array.h")
+    parts = [
+        representation(os.path.join(inc, "mesh_descriptor.h"), "mesh_descriptor"),
+        representation(os.path.join(inc, "cl", "utils.h"), "boundary_type"),
+        representation(os.path.join(inc, "cl", "structs.h"), "condensed_node"),
+        representation(bia, "boundary_index_array_1"),
+        representation(bia, "boundary_index_array_2"),
+        representation(bia, "boundary_index_array_3"),
+        representation_any(os.path.join(cinc, "voxel_structs.h"), "aabb"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "ray"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "triangle_inter"),
+        representation_any(os.path.join(cinc, "geometry_structs.h"), "intersection"),
+        representation_any(os.path.join(cinc, "scene_structs.h"), "triangle_verts"),
+        representation_any(os.path.join(cinc, "triangle.h"), "triangle"),
+        raw_strings(os.path.join(core, "src", "cl", "geometry.cpp"))[0],
+        raw_strings(os.path.join(core, "src", "cl", "voxel.cpp"))[0],
+        raw_strings(os.path.join(WG, "src", "cl", "utils.cpp"))[0],
+        raw_strings(os.path.join(WG, "src", "boundary_coefficient_program.cpp"))[0],
+    ]
+    text = "\n".join(parts)
+    # clang (unlike the OpenCL compiler the reference was developed against) refuses the
+    # implicit int3 -> float3 conversion in two expressions of `closest_triangle_in_voxel`.
+    # No kernel reaches that function (the 1-D kernel calls slow_closest_triangle), so spelling
+    # the conversion out changes no result; it only lets the unmodified kernels compile.
+    text, n = re.subn(r"\((this_voxel_index \+ \(int3\)\([01]\))\) \* voxel_dimensions",
+                      r"convert_float3(\1) * voxel_dimensions", text)
+    if n != 2:
+        raise RuntimeError("boundary coefficient program changed: %d conversions patched" % n)
+    return text
+
+
+def build_bcf(tmp, verbose):
+    """oracle/_ref/libwvref_bcf.so: boundary_coefficient_finder_{1,2,3}d, unmodified."""
+    cl = os.path.join(tmp, "bcf.cl")
+    with open(cl, "w") as f:
+        f.write(assemble_bcf())
+    obj = os.path.join(tmp, "bcf.o")
+    subprocess.check_call([
+        CLANG, "-x", "cl", "-cl-std=CL1.2", "-target", "x86_64-unknown-linux-gnu",
+        "-Xclang", "-finclude-default-header", "-O2", "-ffp-contract=off",
+        "-fPIC", "-Werror", "-c", cl, "-o", obj])
+    so = os.path.join(OUT, "libwvref_bcf.so")
+    subprocess.check_call([
+        CLANGXX, "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-Wl,-z,defs",
+        "-std=c++14", os.path.join(HERE, "ref_shim_bcf.cpp"), obj, "-o", so])
+    if verbose:
+        print("[build_ref] built", so)
+
+
 def build(verbose=True):
     if not os.path.isdir(WG):
         if verbose:
@@ -182,6 +237,7 @@ def build(verbose=True):
     shim = os.path.join(HERE, "ref_shim.cpp")
     with tempfile.TemporaryDirectory(prefix="wvref_") as tmp:
         build_setup(tmp, verbose)
+        build_bcf(tmp, verbose)
         for tag, promote in (("f32", False), ("f64", True)):
             cl = os.path.join(tmp, "program_%s.cl" % tag)
             with open(cl, "w") as f:

@@ -22,7 +22,7 @@ def _ptr(a):
 def build_oracle():
     so = os.path.join(HERE, "liboracle.so")
     srcs = [os.path.join(HERE, f) for f in ("waveguide_oracle.c", "waveguide_oracle_body.h", "mesh_setup_oracle.c",
-                                          "node_inside_oracle.c")]
+                                          "node_inside_oracle.c", "boundary_surfaces_oracle.c")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -78,6 +78,43 @@ class Oracle:
         self.lib.wvo_nodes_inside(nx, ny, nz, _ptr(mc), float(spacing), _ptr(voxel_index), _ptr(a0), _ptr(a1), side,
                                   _ptr(triangles), _ptr(vertices), _ptr(out))
         return out.reshape(nz, ny, nx)
+
+    def point_triangle_dist2(self, v0, v1, v2, p):
+        f = self.lib.wvo_point_triangle_dist2
+        f.restype = C.c_float
+        f.argtypes = [C.c_void_p] * 4
+        a = [np.ascontiguousarray(v, dtype=np.float32) for v in (v0, v1, v2, p)]
+        return np.float32(f(*[_ptr(v) for v in a]))
+
+    def boundary_coefficient_finder(self, nodes, dims, min_corner, spacing, triangles, vertices, counts,
+                                    entry0_last_writer=False):
+        """The three finder kernels restated, on first-numbering nodes: (out1 [n1], out2 [n2,2], out3 [n3,3])."""
+        nx, ny, nz = dims
+        mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+        o = [np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)]
+        f = self.lib.wvo_boundary_coefficient_finder
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        f(_ptr(nodes), nx, ny, nz, float(spacing), _ptr(mc), _ptr(triangles), triangles.shape[0], _ptr(vertices),
+          _ptr(o[0]), counts[0], _ptr(o[1]), counts[1], _ptr(o[2]), counts[2], int(entry0_last_writer))
+        return o
+
+    def boundary_index_data(self, nodes, dims, min_corner, spacing, triangles, vertices, entry0_last_writer=False):
+        """compute_boundary_index_data restated.  nodes: types set (indices rewritten in place).
+        Returns [b1 [n1,1], b2 [n2,2], b3 [n3,3]] surface indices."""
+        nx, ny, nz = dims
+        mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+        n = nodes.shape[0]
+        o = [np.zeros((n, 1), dtype=np.uint32), np.zeros((n, 2), dtype=np.uint32), np.zeros((n, 3), dtype=np.uint32)]
+        counts = (C.c_uint64 * 3)()
+        f = self.lib.wvo_boundary_index_data
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        f(_ptr(nodes), nx, ny, nz, float(spacing), _ptr(mc), _ptr(triangles), triangles.shape[0], _ptr(vertices),
+          _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), counts, int(entry0_last_writer))
+        return [o[d][:int(counts[d])].copy() for d in range(3)]
 
     @staticmethod
     def real(dtype):
@@ -169,6 +206,21 @@ class ReferenceSetup:
         nodes["boundary_type"] = np.where(inside_mask.reshape(-1), 1, 0)
         self.lib.wvref_set_node_boundary_type(_ptr(nodes), nx, ny, nz, 0.1)
         return nodes
+
+    def boundary_coefficient_finder(self, nodes, dims, min_corner, spacing, triangles, vertices, counts):
+        """The reference's boundary_coefficient_finder_{1,2,3}d kernels (serial, in index order) on
+        first-numbering nodes: (out1 [n1,1], out2 [n2,2], out3 [n3,3])."""
+        lib = C.CDLL(os.path.join(HERE, "_ref", "libwvref_bcf.so"))
+        nx, ny, nz = dims
+        mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+        o = [np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)]
+        f = lib.wvref_boundary_coefficient_finder
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        f(_ptr(nodes), nx, ny, nz, float(spacing), _ptr(mc), _ptr(triangles), triangles.shape[0], _ptr(vertices),
+          _ptr(o[0]), counts[0], _ptr(o[1]), counts[1], _ptr(o[2]), counts[2])
+        return o
 
 
 def reference_available():

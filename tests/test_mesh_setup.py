@@ -5,6 +5,7 @@ meshes (L-shaped room, sphere, speckled blob with re-entrant nodes) against the 
 import numpy as np
 import pytest
 
+from conftest import golden
 from helpers import run_engine, run_oracle
 from oracle.oracle import ReferenceSetup
 from wayverb_amd import mesh as M
@@ -200,3 +201,171 @@ def test_scene_to_impulse_response_end_to_end(oracle, built_library):
     assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
     assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
     assert got["current"].tobytes() == want["current"].tobytes()
+
+
+# ---- slice 3: which surface each boundary filter takes ------------------------------------------------
+def _multi_surface(t, n=7):
+    t = t.copy()
+    t[:, 0] = np.arange(t.shape[0]) % n
+    return t
+
+
+def _first_numbering(oracle, name, spacing):
+    from wayverb_amd import engine as E
+    v, t = _scenes()[name]
+    t = _multi_surface(t)
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    mask = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v).astype(bool)
+    nodes, counts = oracle.classify(mask)
+    return v, t, aabb, dims, nodes, counts
+
+
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_setup_restatements_match_golden(oracle, name):
+    """The whole set-up chain of the restatement against vectors the reference's kernels produced
+    (tests/golden/make_golden_setup.py): inside flags, node types, surfaces per filter."""
+    g = golden("setup_" + name)
+    dims = tuple(int(d) for d in g["dims"])
+    aabb = (g["aabb"][0], g["aabb"][1])
+    v, t, vox, side, spacing = g["vertices"], g["triangles"], g["voxel_index"], int(g["side"]), float(g["spacing"])
+    mask = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, side, t, v)
+    n = dims[0] * dims[1] * dims[2]
+    assert np.array_equal(mask.reshape(-1), np.unpackbits(g["inside_bits"])[:n])
+    nodes, counts = oracle.classify(mask.astype(bool))
+    assert np.array_equal(nodes["boundary_type"], g["boundary_type"])
+    assert counts == tuple(int(c) for c in g["counts"])
+    out = oracle.boundary_coefficient_finder(nodes, dims, aabb[0], spacing, t, v, counts, entry0_last_writer=True)
+    for got, key in zip(out, ("out1", "out2", "out3")):
+        assert np.array_equal(got, g[key])
+
+
+@pytest.mark.skipif(not ReferenceSetup.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_surface_finder_restatement_matches_reference_kernels(oracle, built_library, name):
+    v, t, aabb, dims, nodes, counts = _first_numbering(oracle, name, 0.17)
+    want = ReferenceSetup().boundary_coefficient_finder(nodes, dims, aabb[0], 0.17, t, v, counts)
+    got = oracle.boundary_coefficient_finder(nodes, dims, aabb[0], 0.17, t, v, counts, entry0_last_writer=True)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # the product's deterministic rule differs only through entry 0 of the 1-D array
+    det = oracle.boundary_coefficient_finder(nodes, dims, aabb[0], 0.17, t, v, counts, entry0_last_writer=False)
+    assert np.array_equal(det[0][1:], want[0][1:])
+    for d in (1, 2):
+        changed = det[d] != want[d]
+        assert np.all((det[d][changed] == det[0][0, 0]) & (want[d][changed] == want[0][0, 0]))
+
+
+def test_point_triangle_distance_against_float64_minimisation(oracle):
+    """Independent check of the region logic: squared distance equals the minimum over a dense
+    float64 sampling of the triangle, up to sampling + float32 error."""
+    rng = np.random.default_rng(5)
+    w = np.linspace(0, 1, 201)
+    a, b = np.meshgrid(w, w, indexing="ij")
+    keep = a + b <= 1.0 + 1e-12
+    a, b = a[keep], b[keep]
+    for k in range(200):
+        v0, v1, v2 = (rng.normal(size=3).astype(np.float32) for _ in range(3))
+        p = (rng.normal(size=3) * (0.3 if k % 2 else 2.0)).astype(np.float32)
+        got = float(oracle.point_triangle_dist2(v0, v1, v2, p))
+        pts = v0.astype(np.float64) + a[:, None] * (v1 - v0).astype(np.float64) + b[:, None] * (v2 - v0).astype(np.float64)
+        want = ((pts - p.astype(np.float64)) ** 2).sum(axis=1).min()
+        edge = max(np.linalg.norm(v1 - v0), np.linalg.norm(v2 - v0), np.linalg.norm(v2 - v1))
+        assert got <= want + 1e-5 * (1 + want)
+        assert got >= want - 2 * np.sqrt(want) * edge / 200 - (edge / 200) ** 2 - 1e-5
+
+
+def test_box_faces_take_the_surface_of_their_wall(oracle, built_library):
+    """Analytic case: a box whose six walls carry six surfaces; every 1-D boundary node belongs to
+    the wall it sits behind."""
+    from wayverb_amd import engine as E
+    v, t = S.box_scene((0.0, 0.0, 0.0), (2.0, 1.5, 2.5))
+    t = t.copy()
+    for k in range(t.shape[0]):   # surface = wall id from the triangle's constant coordinate
+        p = v[t[k, 1:], :3]
+        axis = int(np.argmin(p.max(axis=0) - p.min(axis=0)))
+        t[k, 0] = 2 * axis + (1 if p[0, axis] > 0 else 0)
+    spacing = 0.13
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    mask = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v).astype(bool)
+    nodes, _ = oracle.classify(mask)
+    b = oracle.boundary_index_data(nodes, dims, aabb[0], spacing, t, v)
+    bt, bi = nodes["boundary_type"], nodes["boundary_index"]
+    # node type bit p+1 = "the inside neighbour is in direction p" (nx,px,ny,py,nz,pz):
+    # a node whose inside lies at +x sits behind the x = 0 wall, etc.
+    wall_of_port = {0: 1, 1: 0, 2: 3, 3: 2, 4: 5, 5: 4}
+    for port, wall in wall_of_port.items():
+        sel = bt == (1 << (port + 1))
+        assert sel.any() and np.all(b[0][bi[sel], 0] == wall)
+    assert b[0].shape[0] == np.count_nonzero(np.isin(bt, [2, 4, 8, 16, 32, 64]))
+    # edges and corners inherit from a face neighbour
+    assert set(np.unique(b[1])) <= set(range(6)) and set(np.unique(b[2])) <= set(range(6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_gpu_boundary_index_data_matches_restatement(oracle, built_library, name):
+    from wayverb_amd import engine as E
+    v, t, aabb, dims, nodes, _ = _first_numbering(oracle, name, 0.11)
+    o_nodes = nodes.copy()
+    want = oracle.boundary_index_data(o_nodes, dims, aabb[0], 0.11, t, v)
+    g_nodes = nodes.copy()
+    g_nodes["boundary_index"] = 0xdeadbeef   # must be ignored on input
+    got = E.boundary_index_data(dims, aabb[0], 0.11, g_nodes, t, v)
+    assert g_nodes.tobytes() == o_nodes.tobytes()
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_boundary_index_data_many_triangles(oracle, built_library):
+    """More triangles than one LDS stage (512) and a list that is not a multiple of it."""
+    from wayverb_amd import engine as E
+    v, t = S.icosphere_scene((0.0, 0.0, 0.0), 1.2, 3)   # 1280 triangles
+    t = _multi_surface(t, 11)
+    assert t.shape[0] > 1024
+    spacing = 0.1
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    mask = E.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    nodes, _ = E.classify_nodes(mask)
+    o_nodes = nodes.copy()
+    want = oracle.boundary_index_data(o_nodes, dims, aabb[0], spacing, t, v)
+    got = E.boundary_index_data(dims, aabb[0], spacing, nodes, t, v)
+    assert nodes.tobytes() == o_nodes.tobytes()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_multi_surface_scene_to_impulse_response(oracle, built_library):
+    """Scene with several materials -> full mesh (types, indices, surfaces per filter) through the
+    ABI -> engine run, against the oracle stepping the same mesh."""
+    from wayverb_amd import engine as E
+    v, t = _scenes()["L"]
+    t = _multi_surface(t, 3)
+    spacing = 0.125
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    mask = E.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    nodes, _ = E.classify_nodes(mask)
+    b = E.boundary_index_data(dims, aabb[0], spacing, nodes, t, v)
+    coeffs = np.zeros(3, dtype=M.coefficients_dtype)
+    coeffs[0] = M.flat_coefficients(0.05)
+    coeffs[1] = M.flat_coefficients(0.4)
+    coeffs[2] = M.passive_peak_filter_coefficients(np.random.default_rng(3), 1)[0]
+    mesh = M.Mesh(dims, nodes, coeffs, b[0], b[1], b[2], spacing=spacing)
+    inside = np.nonzero(nodes["boundary_type"] == M.ID_INSIDE)[0]
+    src, rcv = int(inside[len(inside) // 3]), int(inside[2 * len(inside) // 3])
+    steps = 300
+    sig = np.zeros(steps)
+    sig[0] = M.rectilinear_calibration_factor(spacing, 400.0)
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=src, signal=sig, recv=[rcv], init=None)
+    for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
+        want = run_oracle(oracle, case, dtype, threads=4)
+        got = run_engine(case, tag)
+        assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
+        assert got["flag"] == want["flag"]
+        assert np.array_equal(got["trace"], want["trace"])
+        assert np.array_equal(got["current"], want["current"])

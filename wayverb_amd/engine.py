@@ -29,6 +29,7 @@ EXPORTS = [
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
     "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
+    "wv_boundary_index_data",
 ]
 
 
@@ -194,6 +195,33 @@ def nodes_inside(dims, min_corner, spacing, voxel_index, aabb, side, triangles, 
                                t.ctypes.data_as(C.c_void_p), t.shape[0], v.ctypes.data_as(C.c_void_p), v.shape[0],
                                out.ctypes.data_as(C.c_void_p)))
     return out.reshape(nz, ny, nx)
+
+
+def boundary_index_data(dims, min_corner, spacing, nodes, triangles, vertices):
+    """wv_boundary_index_data: surface index per boundary filter.  `nodes` (types set) get their
+    final boundary_index in place.  Returns [b1 [n1,1], b2 [n2,2], b3 [n3,3]] uint32."""
+    lib = load_library()
+    lib.wv_boundary_index_data.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    nx, ny, nz = dims
+    assert nodes.dtype == M.condensed_node_dtype and nodes.flags.c_contiguous and nodes.shape[0] == nx * ny * nz
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    t = np.ascontiguousarray(triangles, dtype=np.uint32)
+    mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+    bt = nodes["boundary_type"]
+    pc = np.zeros(bt.shape, dtype=np.int8)
+    for bit in range(1, 7):
+        pc += ((bt >> bit) & 1).astype(np.int8)
+    cap = [max(1, int(np.count_nonzero(pc == d))) for d in (1, 2, 3)]
+    out = [np.zeros((cap[d], d + 1), dtype=np.uint32) for d in range(3)]
+    counts = (C.c_uint64 * 3)()
+    _check(lib.wv_boundary_index_data(nx, ny, nz, mc.ctypes.data_as(C.c_void_p), float(spacing),
+                                      nodes.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), t.shape[0],
+                                      v.ctypes.data_as(C.c_void_p), v.shape[0],
+                                      out[0].ctypes.data_as(C.c_void_p), cap[0], out[1].ctypes.data_as(C.c_void_p), cap[1],
+                                      out[2].ctypes.data_as(C.c_void_p), cap[2], counts))
+    return [out[d][:int(counts[d])].copy() for d in range(3)]
 
 
 def filter_test_2(inputs, memory, coeffs):
