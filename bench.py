@@ -55,8 +55,10 @@ def cpu_baseline(args, elem):
     cores = os.cpu_count() or 1
     nx, ny, nz = args.nx, args.ny, 32
     nodes, counts = make_box_nodes(nx, ny, nz)
-    coeffs = np.array([M.flat_coefficients(0.1)], dtype=M.coefficients_dtype)
-    mesh = M.Mesh((nx, ny, nz), nodes, coeffs, *[np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)])
+    coeffs = M.bench_materials()
+    mesh = M.Mesh((nx, ny, nz), nodes, coeffs,
+                  *[(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1)
+                    for d in range(3)])
     dtype = np.float32 if args.precision == "f32" else np.float64
     prev = np.zeros(mesh.num_nodes, dtype=dtype)
     cur = np.zeros(mesh.num_nodes, dtype=dtype)
@@ -133,7 +135,7 @@ def main():
     nz_global = args.nz * world
     layout = SlabLayout((nx, ny, nz_global), rank, world)
     t_setup = time.perf_counter()
-    mesh = box_slab_mesh(nx, ny, nz_global, layout)
+    mesh = box_slab_mesh(nx, ny, nz_global, layout, coefficients=M.bench_materials())
     eng = E.Engine(mesh, precision=args.precision, device=local_rank,
                    ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi)
     mesh.nodes = None  # host copy no longer needed
@@ -208,7 +210,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "%dx%dx%d box mesh, %s pressures, flat absorption 0.1 walls, hard-source impulse + 1 receiver"
+        "config": {"workload": "%dx%dx%d box mesh, %s pressures, walls of 4 mixed materials (2 flat, 2 frequency-dependent order-6 IIR), hard-source impulse + 1 receiver"
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
                    "per_gpu": "%dx%dx%d z-slab" % (nx, ny, args.nz), "decomposition": "z-slabs x%d" % world,
                    "halo": "RCCL send/recv, 1 plane per neighbour per step" if world > 1 else "none",
@@ -224,7 +226,7 @@ def main():
     if world == 1 and rank == 0 and not args.no_small and (nx, ny, args.nz) == (1024, 1024, 1024):
         # side measurement: BASELINE configs[1] (256^3; the whole working set sits in the 256 MiB
         # Infinity Cache, so it is not an HBM roofline point)
-        m2 = M.box_mesh(256, 256, 256)
+        m2 = M.box_mesh(256, 256, 256, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
         e2 = E.Engine(m2, precision=args.precision, device=local_rank)
         sig = np.zeros(2200)
         sig[0] = 1.0

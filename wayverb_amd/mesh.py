@@ -340,6 +340,16 @@ def rectilinear_calibration_factor(grid_spacing, acoustic_impedance):
     return math.sqrt(acoustic_impedance / (4 * math.pi)) / (0.3405 * grid_spacing)
 
 
+def bench_materials():
+    """The wall materials of bench.py / smoke: two flat absorbers and two frequency-dependent
+    order-6 impedance filters (seeded), so the boundary kernel runs real IIR recursions."""
+    out = np.zeros(4, dtype=coefficients_dtype)
+    out[0] = flat_coefficients(0.1)
+    out[1] = flat_coefficients(0.35)
+    out[2:] = passive_peak_filter_coefficients(np.random.default_rng(2016), 2)
+    return out
+
+
 def passive_peak_filter_coefficients(rng, n, sections=3, scale=0.9):
     """n stable, energy-absorbing order-6 impedance filters for tests: peak-biquad cascades with
     negative gain (U(-3,-0.1) dB), reflectance scaled by `scale` < 1.  With sections < 3 the

@@ -84,7 +84,9 @@ def slab_mesh(global_mesh, layout):
 def box_slab_mesh(nx, ny, nz_global, layout, coefficients=None, make_nodes=None):
     """One rank's slab of the synthetic box without ever materialising the global mesh
     (the 1024x1024x8192 mesh of BASELINE configs[3] has 2^33 nodes: no 32-bit global index).
-    All walls use coefficient 0.  `make_nodes` = wayverb_amd.engine.make_box_nodes."""
+    With one coefficient set all walls use it; with several, filter j of boundary node k takes
+    set (k*D + j) mod n -- a deterministic mix of materials over the walls.
+    `make_nodes` = wayverb_amd.engine.make_box_nodes."""
     L = layout
     if make_nodes is None:
         from .engine import make_box_nodes as make_nodes
@@ -92,7 +94,9 @@ def box_slab_mesh(nx, ny, nz_global, layout, coefficients=None, make_nodes=None)
                                number_from=L.z0, number_to=L.z1)
     if coefficients is None:
         coefficients = np.array([M.flat_coefficients(0.1)], dtype=M.coefficients_dtype)
-    bidx = [np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)]
+    n_sets = int(np.asarray(coefficients).shape[0])
+    bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(n_sets)).reshape(counts[d], d + 1)
+            for d in range(3)]
     return M.Mesh(L.local_dims, nodes, coefficients, bidx[0], bidx[1], bidx[2])
 
 
