@@ -259,6 +259,28 @@ int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const float min_c
                            uint32_t* b2, uint64_t capacity_2, uint32_t* b3, uint64_t capacity_3,
                            uint64_t counts[3]);
 
+/* ---- boundary filter design, host side --------------------------------- */
+/* arbitrary_magnitude_filter<6> (src/waveguide/include/waveguide/arbitrary_magnitude_filter.h:63-95):
+ * (frequency 0..1 = DC..Nyquist, amplitude) points in any order -> order-6 IIR b/a whose magnitude
+ * approximates them.  Points outside [0, 1] are dropped, (0,0) and (1,0) are added, the envelope is
+ * resampled to 256 points by linear interpolation and fitted by the modified Yule-Walker method
+ * (the reference calls itpp::yulewalk; see wayverb_amd/csrc/filter_design.cpp for what is restated). */
+int wv_arbitrary_magnitude_filter(const double* frequency, const double* amplitude, uint32_t n_points,
+                                  double b[7], double a[7]);
+/* is_stable (src/waveguide/include/waveguide/stable.h:43-50) on ascending-power denominator
+ * coefficients a[0..n-1] */
+int wv_is_stable(const double* a, uint32_t n, int32_t* stable);
+/* hrtf_data::hrtf_band_centres (src/hrtf/lib/include/hrtf/multiband.h:13-20): centres of the 8
+ * simulation bands over 20 Hz..20 kHz, divided by sample_rate */
+int wv_band_centres(double sample_rate, double centres[8]);
+/* compute_reflectance_filter_coefficients (fitted_boundary.h:79-104): 8 band absorptions ->
+ * pressure reflectance sqrt(1 - absorption) at 2*centre/sample_rate -> the filter above; fails with
+ * "Unable to generate stable boundary filter." when the denominator is not stable */
+int wv_reflectance_filter(const double absorption[8], double sample_rate, wv_coefficients_canonical* out);
+/* to_impedance_coefficients (fitted_boundary.h:21-48): b' = a + b, a' = a - b, scaled by 1/a'[0]
+ * when that is non-zero: what wv_mesh::coefficients holds for a surface (mesh.cpp:126-138) */
+int wv_impedance_coefficients(const wv_coefficients_canonical* reflectance, wv_coefficients_canonical* impedance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,119 @@
+"""Boundary filter design, host side, no GPU needed.
+
+Parity for this row is UNPINNED (see oracle/filter_design_oracle.py): the reference's designer is
+itpp::yulewalk, which is not in the reference tree.  What is checked: (a) the properties the
+reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp: every designed
+denominator is stable, on the same envelopes), (b) the C++ implementation against the independent
+numpy restatement to 1e-9, (c) that the designed response follows the requested magnitudes."""
+import numpy as np
+import pytest
+
+from oracle import filter_design_oracle as O
+from wayverb_amd import filters as F
+from wayverb_amd import mesh as M
+
+TOL = 1e-9   # C++ (own FFT / QR / Durand-Kerner) vs numpy (pocketfft / LAPACK): rounding only
+
+
+def _reference_test_envelopes():
+    """tests/arbitrary_magnitude_filter.cpp:16-32"""
+    env = []
+    yield list(env)
+    for p in [(0, 0), (0.5, 1), (0.49, 0), (0.51, 0)]:
+        env.append(p)
+        yield list(env)
+
+
+def test_stable_on_the_reference_test_envelopes(built_library):
+    for env in _reference_test_envelopes():
+        b, a = F.arbitrary_magnitude_filter(env)
+        assert np.all(np.isfinite(b)) and np.all(np.isfinite(a))
+        assert F.is_stable(a)
+
+
+def test_stable_on_1000_random_envelopes(built_library):
+    """tests/arbitrary_magnitude_filter.cpp:34-44: 1000 envelopes of 100 uniform random points."""
+    rng = np.random.default_rng(2016)
+    for _ in range(1000):
+        env = rng.random((100, 2), dtype=np.float32).astype(np.float64)
+        b, a = F.arbitrary_magnitude_filter(env)
+        assert F.is_stable(a), env
+        assert np.all(np.abs(np.roots(a)) < 1 + 1e-9)
+
+
+def test_cpp_matches_numpy_restatement(built_library):
+    rng = np.random.default_rng(7)
+    cases = list(_reference_test_envelopes())[2:]
+    cases.append([(0.2, 0), (0.4, 1), (0.6, 0.5), (0.8, 1), (1.0, 0)])   # tests/fitted_boundary.cpp:33-35
+    cases += [rng.random((int(rng.integers(3, 100)), 2)).tolist() for _ in range(25)]
+    cases.append([(-0.5, 3.0), (0.3, 0.7), (0.3, 0.2), (1.5, 2.0), (0.9, 0.4)])   # out of range + duplicates
+    for env in cases:
+        b, a = F.arbitrary_magnitude_filter(env)
+        ob, oa = O.arbitrary_magnitude_filter(env)
+        assert np.abs(b - ob).max() <= TOL * max(1.0, np.abs(ob).max())
+        assert np.abs(a - oa).max() <= TOL * max(1.0, np.abs(oa).max())
+        assert F.is_stable(a) == O.is_stable(oa)
+
+
+def test_is_stable_agrees_with_the_roots(built_library):
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        n = int(rng.integers(1, 8))
+        r = rng.uniform(0, 1.3, n) * np.exp(1j * rng.uniform(0, np.pi, n))
+        a = np.real(np.poly(np.concatenate([r, np.conj(r)])))
+        want = bool(np.all(np.abs(r) < 1))
+        if np.min(np.abs(np.abs(r) - 1)) < 1e-3:
+            continue
+        assert F.is_stable(a) == want == O.is_stable(a)
+    assert F.is_stable([3.0])
+
+
+def test_response_follows_the_envelope(built_library):
+    from scipy.signal import freqz
+    env = [(0.05, 0.9), (0.2, 0.85), (0.4, 0.6), (0.6, 0.5), (0.8, 0.7), (0.95, 0.75)]
+    b, a = F.arbitrary_magnitude_filter(env)
+    f = np.linspace(0.1, 0.9, 33)
+    _, h = freqz(b, a, worN=np.pi * f)
+    want = np.interp(f, [p[0] for p in env], [p[1] for p in env])
+    assert np.abs(np.abs(h) - want).max() < 0.1
+
+
+@pytest.mark.parametrize("sample_rate", [1333.3, 8000.0, 44100.0])
+def test_reflectance_chain(built_library, sample_rate):
+    """compute_reflectance_filter_coefficients + to_impedance_coefficients on the `FrontColor`
+    material of the reference's concert-hall demo."""
+    absorption = [0.30, 0.30, 0.45, 0.65, 0.56, 0.59, 0.71, 0.71]
+    assert np.allclose(F.band_centres(sample_rate), O.band_centres(sample_rate), rtol=1e-15)
+    assert np.allclose(F.band_centres(1.0)[[0, 7]], [20 * 1000 ** (1 / 16), 20 * 1000 ** (15 / 16)])
+    r = F.reflectance_filter(absorption, sample_rate)
+    ob, oa = O.reflectance_filter(absorption, sample_rate)
+    assert np.abs(r["b"] - ob).max() <= TOL and np.abs(r["a"] - oa).max() <= TOL
+    assert F.is_stable(r["a"])
+    z = F.impedance_coefficients(r)
+    want = M.to_impedance_coefficients(r["b"], r["a"])
+    assert np.array_equal(z["b"], want["b"]) and np.array_equal(z["a"], want["a"])
+    assert z["a"][0] == 1.0
+    # passive wall: |reflectance| <= 1 everywhere
+    from scipy.signal import freqz
+    _, h = freqz(r["b"], r["a"], worN=512)
+    assert np.abs(h).max() <= 1.0 + 1e-9
+
+
+def test_surface_coefficients_run_clean_in_the_oracle(built_library, oracle):
+    """A mesh whose walls carry designed (frequency-dependent) filters steps without error flags
+    and loses energy."""
+    from helpers import run_oracle
+    spacing, c = 0.1, 340.0
+    coeffs = np.zeros(2, dtype=M.coefficients_dtype)
+    coeffs[0] = F.surface_coefficients([0.05] * 8, c, spacing)
+    coeffs[1] = F.surface_coefficients([0.30, 0.30, 0.45, 0.65, 0.56, 0.59, 0.71, 0.71], c, spacing)
+    mesh = M.box_mesh(14, 12, 10, coefficients=coeffs, surface_of_face=[0, 1, 0, 1, 0, 1], spacing=spacing)
+    steps = 400
+    sig = np.zeros(steps)
+    sig[0] = 1.0
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=mesh.compute_index(7, 6, 5), signal=sig,
+                recv=[mesh.compute_index(4, 4, 4)], init=None)
+    out = run_oracle(oracle, case, np.float64, threads=2)
+    assert out["flag"] == 0
+    tr = np.abs(out["trace"][:, 0])
+    assert tr[:100].max() > 0 and tr[-50:].max() < 0.5 * tr[:100].max()
