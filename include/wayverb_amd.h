@@ -281,6 +281,46 @@ int wv_reflectance_filter(const double absorption[8], double sample_rate, wv_coe
  * when that is non-zero: what wv_mesh::coefficients holds for a surface (mesh.cpp:126-138) */
 int wv_impedance_coefficients(const wv_coefficients_canonical* reflectance, wv_coefficients_canonical* impedance);
 
+/* ---- receiver traces -> audio, host side --------------------------------- */
+/* postprocessor::directional_receiver::output (src/waveguide/include/waveguide/postprocessor/
+ * directional_receiver.h:22-25): what `canonical` collects per step */
+typedef struct wv_directional_output {
+    float intensity[3];
+    float pressure;
+} wv_directional_output;
+/* bandpass_band (src/waveguide/include/waveguide/bandpass_band.h:11-20) */
+typedef struct wv_waveguide_band {
+    const wv_directional_output* directional;
+    uint64_t n;
+    double sample_rate;
+    double valid_hz_min, valid_hz_max;
+} wv_waveguide_band;
+enum { WV_ATTENUATOR_NULL = 0,       /* core::attenuator::null: the pressure itself */
+       WV_ATTENUATOR_MICROPHONE = 1  /* core::attenuator::microphone (pointing, shape) */ };
+enum { WV_FILTER_LOPASS = 0, WV_FILTER_HIPASS = 1, WV_FILTER_BANDPASS = 2 };
+
+/* attenuate / make_attenuate_mapper (src/waveguide/include/waveguide/attenuator.h:13-49;
+ * microphone: src/core/src/attenuator/microphone.cpp:18-25), float arithmetic as there.
+ * Fails with "Acoustic impedance outside expected range." unless 300 <= Z < 500. */
+int wv_attenuate(int32_t method, const float pointing[3], float shape, float acoustic_impedance,
+                 const wv_directional_output* in, uint64_t n, float* out);
+/* adjust_sampling_rate (src/waveguide/src/config.cpp:29-56): (size_t)(out/in * n) samples of
+ * band-limited interpolation scaled by in/out.  *n_out always receives the length; nothing is
+ * written unless capacity suffices.  (The reference calls libsamplerate; see postprocess.cpp.) */
+int wv_adjust_sampling_rate(const float* in, uint64_t n, double in_sample_rate, double out_sample_rate, float* out,
+                            uint64_t capacity, uint64_t* n_out);
+/* frequency_domain::filter{best_fft_length(n) << 2}.run with compute_lopass / hipass /
+ * bandpass_magnitude as the per-bin gain (src/frequency_domain/src/filter.cpp:22-47,
+ * envelope.cpp:60-112); edges relative to the sample rate, in place */
+int wv_frequency_domain_filter(float* signal, uint64_t n, int32_t kind, double edge_lo, double edge_hi,
+                               double width_factor, uint32_t steepness);
+/* waveguide::postprocess(bandpass_bands, method, Z, output_sample_rate)
+ * (src/waveguide/include/waveguide/postprocess.h:74-126): attenuate, resample, band-pass each
+ * band at its valid range, sum, 10 Hz DC block.  Size-query protocol as above. */
+int wv_postprocess_waveguide(const wv_waveguide_band* bands, uint32_t n_bands, int32_t method, const float pointing[3],
+                             float shape, float acoustic_impedance, double output_sample_rate, float* out,
+                             uint64_t capacity, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

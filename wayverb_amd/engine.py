@@ -30,7 +30,8 @@ EXPORTS = [
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
     "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
-    "wv_reflectance_filter", "wv_impedance_coefficients",
+    "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
+    "wv_frequency_domain_filter", "wv_postprocess_waveguide",
 ]
 
 
