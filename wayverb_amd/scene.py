@@ -140,3 +140,24 @@ def compute_adjusted_boundary(min_lo, min_hi, anchor, cube_side):
     dim = np.ceil((hi - c0) / side).astype(np.int32) + 2
     c1 = c0 + dim.astype(np.float32) * side
     return c0.astype(np.float32), c1.astype(np.float32)
+
+
+def hall_scene(width=18.0, depth=30.0, height=11.0, stage_depth=7.0, stage_height=1.1):
+    """A small concert-hall-like room for end-to-end runs: a shoebox (surface 0: plaster) with a
+    raised stage block at the front (surface 1: wood).  The room is the prism extruded along x from
+    the side-view polygon (y = length, z = height), so the stage is a step in the floor.
+    Returns (vertices, triangles) with triangles[:, 0] the surface index."""
+    side = [(0.0, 0.0), (stage_depth, 0.0), (stage_depth, -stage_height), (depth, -stage_height), (depth, height),
+            (0.0, height)]
+    # prism_scene extrudes an xy polygon along z; build it there and rotate axes (x,y,z) <- (z,x,y)
+    v, t = prism_scene(side, 0.0, width)
+    out = v.copy()
+    out[:, 0], out[:, 1], out[:, 2] = v[:, 2], v[:, 0], v[:, 1]
+    t = t.copy()
+    for k in range(t.shape[0]):
+        p = out[t[k, 1:], :3]
+        # stage = the triangles lying on the raised floor (z = 0, y <= stage_depth) or its riser
+        on_top = np.all(np.abs(p[:, 2]) < 1e-6) and np.all(p[:, 1] <= stage_depth + 1e-6)
+        on_riser = np.all(np.abs(p[:, 1] - stage_depth) < 1e-6) and np.all(p[:, 2] <= 1e-6)
+        t[k, 0] = 1 if (on_top or on_riser) else 0
+    return out, t
