@@ -1,0 +1,252 @@
+// wayverb_amd/setup.h -- C++14 host mirror of what surrounds `waveguide::run` in the reference
+// (SURVEY.md 8(f)): scene -> mesh, wall filter design, receiver traces -> audio.  Header only, over
+// the C ABI of wayverb_amd.h; link against libwayverb_amd.so.
+//
+// Same names and argument meaning as the reference (paths relative to its repository root):
+//   compute_adjusted_boundary            src/waveguide/src/boundary_adjust.cpp:8-22
+//   compute_voxels_and_mesh, compute_mesh  src/waveguide/src/mesh.cpp:54-159
+//   estimate_volume                      src/waveguide/src/mesh.cpp:40-49
+//   arbitrary_magnitude_filter<6>        src/waveguide/include/waveguide/arbitrary_magnitude_filter.h:63-95
+//   is_stable                            src/waveguide/include/waveguide/stable.h:43-50
+//   compute_reflectance_filter_coefficients  src/waveguide/include/waveguide/fitted_boundary.h:79-104
+//   attenuate / postprocess              src/waveguide/include/waveguide/{attenuator,postprocess}.h
+//   adjust_sampling_rate                 src/waveguide/src/config.cpp:29-56
+//   config::grid_spacing / time_step     src/waveguide/src/config.cpp:15-25
+//
+// What differs, deliberately:
+//   - the scene is plain arrays (`scene_data`: cl_float3-strided vertices, {surface, v0, v1, v2}
+//     triangles, 8-band absorption per surface) instead of core::generic_scene_data /
+//     voxelised_scene_data templates; `voxels_and_mesh::voxels` is the flattened voxel array the
+//     device kernels walk (what scene_buffers uploads), not the octree object.
+//   - microphone / null attenuators only (the HRTF tables are not part of this engine).
+#pragma once
+
+#include "waveguide.h"
+
+namespace wayverb {
+namespace core {
+
+struct triangle final {  // src/core/include/core/cl/triangle.h:9-14
+    uint32_t surface, v0, v1, v2;
+};
+struct scene_vertex final {  // cl_float3
+    float x, y, z, w;
+};
+struct surface_absorption final {  // core::surface<simulation_bands>::absorption
+    double s[8];
+};
+struct scene_data final {
+    std::vector<scene_vertex> vertices;
+    std::vector<triangle> triangles;
+    std::vector<surface_absorption> surfaces;
+};
+struct box final {  // core::geo::box
+    waveguide::vec3 c0, c1;
+};
+
+namespace attenuator {
+struct null final {};
+struct microphone final {  // src/core/include/core/attenuator/microphone.h
+    waveguide::vec3 pointing{0, 0, 1};
+    float shape{0};
+};
+}  // namespace attenuator
+}  // namespace core
+
+namespace waveguide {
+namespace config {
+inline double time_step(double speed_of_sound, double grid_spacing) {
+    return grid_spacing / (speed_of_sound * std::sqrt(3.0));
+}
+inline double grid_spacing(double speed_of_sound, double time_step) {
+    return speed_of_sound * time_step * std::sqrt(3.0);
+}
+}  // namespace config
+
+/// boundary_adjust.cpp:8-22, in float like glm::vec3
+inline core::box compute_adjusted_boundary(const core::box& min_boundary, const vec3& anchor, float cube_side) {
+    const float lo[3] = {min_boundary.c0.x, min_boundary.c0.y, min_boundary.c0.z};
+    const float hi[3] = {min_boundary.c1.x, min_boundary.c1.y, min_boundary.c1.z};
+    const float an[3] = {anchor.x, anchor.y, anchor.z};
+    float c0[3], c1[3];
+    for (int k = 0; k < 3; ++k) {
+        const int ceiled = (int)std::ceil((an[k] - lo[k]) / cube_side);
+        c0[k] = an[k] - (float)(ceiled + 2) * cube_side;
+        const int dim = (int)std::ceil((hi[k] - c0[k]) / cube_side) + 2;
+        c1[k] = c0[k] + (float)dim * cube_side;
+    }
+    return core::box{vec3{c0[0], c0[1], c0[2]}, vec3{c1[0], c1[1], c1[2]}};
+}
+
+// ---- wall filter design ----------------------------------------------------------------------------
+struct frequency_domain_envelope final {  // frequency_domain_envelope.h (points kept in insertion order)
+    struct point final {
+        double frequency, amplitude;
+    };
+    std::vector<point> points;
+    void insert(point p) { points.push_back(p); }
+};
+
+template <size_t N>
+coefficients_canonical arbitrary_magnitude_filter(const frequency_domain_envelope& env) {
+    static_assert(N == 6, "the engine's boundary filters are order 6 (cl/filter_structs.h:65-66)");
+    std::vector<double> f, m;
+    for (const auto& p : env.points) {
+        f.push_back(p.frequency);
+        m.push_back(p.amplitude);
+    }
+    coefficients_canonical c{};
+    detail::check(wv_arbitrary_magnitude_filter(f.data(), m.data(), (uint32_t)f.size(), c.b, c.a));
+    return c;
+}
+
+template <typename T>
+bool is_stable(const T& a) {
+    const std::vector<double> v(std::begin(a), std::end(a));
+    int32_t stable = 0;
+    detail::check(wv_is_stable(v.data(), (uint32_t)v.size(), &stable));
+    return stable != 0;
+}
+
+/// fitted_boundary.h:79-104; throws "Unable to generate stable boundary filter."
+inline coefficients_canonical compute_reflectance_filter_coefficients(const double (&absorption)[8],
+                                                                       double sample_rate) {
+    coefficients_canonical c{};
+    if (wv_reflectance_filter(absorption, sample_rate, &c) != WV_OK) throw std::runtime_error{wv_last_error()};
+    return c;
+}
+
+// ---- scene -> mesh ---------------------------------------------------------------------------------
+struct voxels_and_mesh final {  // mesh.h:52-58
+    std::vector<uint32_t> voxels;  // flattened side^3 voxel -> triangle lists
+    core::box voxels_aabb;
+    uint32_t voxels_side;
+    waveguide::mesh mesh;
+};
+
+inline double estimate_volume(const mesh& m) {  // mesh.cpp:40-49
+    size_t inside = 0;
+    for (const auto& n : m.get_structure().get_condensed_nodes()) inside += is_inside(n) ? 1 : 0;
+    const double s = m.get_descriptor().spacing;
+    return s * s * s * (double)inside;
+}
+
+/// compute_voxels_and_mesh (mesh.cpp:143-159): octree depth 5 over the adjusted boundary, inside
+/// flags, node types, boundary indices, one impedance filter per surface.  All node work runs on
+/// the GPU selected by `cc`.
+template <typename Context>
+voxels_and_mesh compute_voxels_and_mesh(const Context& cc, const core::scene_data& scene, const vec3& anchor,
+                                        double sample_rate, double speed_of_sound) {
+    (void)cc;
+    if (scene.vertices.empty() || scene.triangles.empty()) throw std::runtime_error{"empty scene"};
+    const float mesh_spacing = (float)config::grid_spacing(speed_of_sound, 1 / sample_rate);
+    core::box bounds{vec3{scene.vertices[0].x, scene.vertices[0].y, scene.vertices[0].z},
+                     vec3{scene.vertices[0].x, scene.vertices[0].y, scene.vertices[0].z}};
+    for (const auto& v : scene.vertices) {
+        bounds.c0 = vec3{std::min(bounds.c0.x, v.x), std::min(bounds.c0.y, v.y), std::min(bounds.c0.z, v.z)};
+        bounds.c1 = vec3{std::max(bounds.c1.x, v.x), std::max(bounds.c1.y, v.y), std::max(bounds.c1.z, v.z)};
+    }
+    const core::box aabb = compute_adjusted_boundary(bounds, anchor, mesh_spacing);
+    const float c0[3] = {aabb.c0.x, aabb.c0.y, aabb.c0.z}, c1[3] = {aabb.c1.x, aabb.c1.y, aabb.c1.z};
+    const uint32_t side = 1u << 5;
+    const float* verts = &scene.vertices[0].x;
+    const uint32_t* tris = &scene.triangles[0].surface;
+    const uint32_t n_verts = (uint32_t)scene.vertices.size(), n_tris = (uint32_t)scene.triangles.size();
+
+    uint64_t words = 0;
+    detail::check(wv_voxelise(verts, n_verts, tris, n_tris, c0, c1, side, nullptr, 0, &words));
+    std::vector<uint32_t> voxels(words);
+    detail::check(wv_voxelise(verts, n_verts, tris, n_tris, c0, c1, side, voxels.data(), words, &words));
+
+    const ivec3 dim{(int)((c1[0] - c0[0]) / mesh_spacing), (int)((c1[1] - c0[1]) / mesh_spacing),
+                    (int)((c1[2] - c0[2]) / mesh_spacing)};  // mesh.cpp:65-71
+    const size_t n = (size_t)dim.x * dim.y * dim.z;
+    std::vector<uint8_t> inside(n);
+    detail::check(wv_nodes_inside(dim.x, dim.y, dim.z, c0, mesh_spacing, voxels.data(), words, c0, c1, side, tris,
+                                  n_tris, verts, n_verts, inside.data()));
+    std::vector<condensed_node> nodes(n);
+    uint64_t first[3] = {0, 0, 0};
+    detail::check(wv_classify_nodes(dim.x, dim.y, dim.z, inside.data(), nodes.data(), first));
+    boundary_index_data bid;
+    bid.b1.resize(std::max<uint64_t>(first[0], 1));
+    bid.b2.resize(std::max<uint64_t>(first[1], 1));
+    bid.b3.resize(std::max<uint64_t>(first[2], 1));
+    uint64_t counts[3] = {0, 0, 0};
+    if (wv_boundary_index_data(dim.x, dim.y, dim.z, c0, mesh_spacing, nodes.data(), tris, n_tris, verts, n_verts,
+                               &bid.b1[0].array[0], bid.b1.size(), &bid.b2[0].array[0], bid.b2.size(),
+                               &bid.b3[0].array[0], bid.b3.size(), counts) != WV_OK)
+        throw std::runtime_error{wv_last_error()};  // "No boundaries."
+    bid.b1.resize(counts[0]);
+    bid.b2.resize(counts[1]);
+    bid.b3.resize(counts[2]);
+
+    std::vector<coefficients_canonical> coefficients;  // mesh.cpp:126-138
+    const double fs = 1 / config::time_step(speed_of_sound, mesh_spacing);
+    for (const auto& s : scene.surfaces)
+        coefficients.push_back(to_impedance_coefficients(compute_reflectance_filter_coefficients(s.s, fs)));
+
+    return voxels_and_mesh{std::move(voxels), aabb, side,
+                           mesh{mesh_descriptor{aabb.c0, dim, mesh_spacing},
+                                vectors{std::move(nodes), std::move(coefficients), std::move(bid)}}};
+}
+
+// ---- receiver traces -> audio ------------------------------------------------------------------------
+namespace detail {
+inline std::vector<wv_directional_output> to_abi(const band& b) {
+    std::vector<wv_directional_output> out(b.directional.size());
+    for (size_t i = 0; i < out.size(); ++i) {
+        out[i].intensity[0] = b.directional[i].intensity.x;
+        out[i].intensity[1] = b.directional[i].intensity.y;
+        out[i].intensity[2] = b.directional[i].intensity.z;
+        out[i].pressure = b.directional[i].pressure;
+    }
+    return out;
+}
+inline std::vector<float> postprocess_impl(const std::vector<bandpass_band>& results, int method,
+                                           const float* pointing, float shape, double acoustic_impedance,
+                                           double output_sample_rate) {
+    std::vector<std::vector<wv_directional_output>> keep;
+    std::vector<wv_waveguide_band> bands;
+    for (const auto& r : results) {
+        keep.push_back(to_abi(r.band));
+        bands.push_back(wv_waveguide_band{keep.back().data(), keep.back().size(), r.band.sample_rate, r.valid_hz_min,
+                                          r.valid_hz_max});
+    }
+    uint64_t n = 0;
+    auto call = [&](float* out, uint64_t cap) {
+        if (wv_postprocess_waveguide(bands.data(), (uint32_t)bands.size(), method, pointing, shape,
+                                     (float)acoustic_impedance, output_sample_rate, out, cap, &n) != WV_OK)
+            throw std::runtime_error{wv_last_error()};  // e.g. "Acoustic impedance outside expected range."
+    };
+    call(nullptr, 0);
+    std::vector<float> out(n);
+    call(out.data(), n);
+    return out;
+}
+}  // namespace detail
+
+/// postprocess.h:74-126
+inline std::vector<float> postprocess(const std::vector<bandpass_band>& results, const core::attenuator::null&,
+                                      double acoustic_impedance, double output_sample_rate) {
+    return detail::postprocess_impl(results, WV_ATTENUATOR_NULL, nullptr, 0.0f, acoustic_impedance, output_sample_rate);
+}
+inline std::vector<float> postprocess(const std::vector<bandpass_band>& results,
+                                      const core::attenuator::microphone& mic, double acoustic_impedance,
+                                      double output_sample_rate) {
+    const float p[3] = {mic.pointing.x, mic.pointing.y, mic.pointing.z};
+    return detail::postprocess_impl(results, WV_ATTENUATOR_MICROPHONE, p, mic.shape, acoustic_impedance,
+                                    output_sample_rate);
+}
+
+/// config.cpp:29-56
+inline std::vector<float> adjust_sampling_rate(const float* data, size_t size, double in_sr, double out_sr) {
+    uint64_t n = 0;
+    if (wv_adjust_sampling_rate(data, size, in_sr, out_sr, nullptr, 0, &n) != WV_OK)
+        throw std::runtime_error{wv_last_error()};
+    std::vector<float> out(n);
+    detail::check(wv_adjust_sampling_rate(data, size, in_sr, out_sr, out.data(), n, &n));
+    return out;
+}
+
+}  // namespace waveguide
+}  // namespace wayverb

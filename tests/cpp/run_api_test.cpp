@@ -4,12 +4,16 @@
 //   verify determinism       tests/verify_compensation_signal.cpp:24-31,50-92
 //   nan_in_waveguide         tests/nan_in_waveguide.cpp:15-72    (gaussian + directional receiver)
 //   canonical                include/waveguide/canonical.h:29-88 (fast path == generic path)
+//   arbitrary_magnitude_filter stable   tests/arbitrary_magnitude_filter.cpp:11-45
+//   scene -> mesh -> run -> audio       src/waveguide/src/mesh.cpp:143-159 + postprocess.h:74-126,
+//                                       shaped like bin/waveguide-style callers (setup.h mirror)
 // Exit code 0 = all assertions held.  Needs a GPU (the library has no CPU fallback).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 
+#include "wayverb_amd/setup.h"
 #include "wayverb_amd/waveguide.h"
 
 using namespace wayverb::waveguide;
@@ -153,12 +157,95 @@ static void canonical_matches_generic() {
     std::puts("canonical ok");
 }
 
+static void filters_are_stable() {  // host only
+    frequency_domain_envelope env;
+    REQUIRE(is_stable(arbitrary_magnitude_filter<6>(env).a));
+    for (const auto& p : {frequency_domain_envelope::point{0, 0}, frequency_domain_envelope::point{0.5, 1},
+                          frequency_domain_envelope::point{0.49, 0}, frequency_domain_envelope::point{0.51, 0}}) {
+        env.insert(p);
+        REQUIRE(is_stable(arbitrary_magnitude_filter<6>(env).a));
+    }
+    unsigned seed = 12345;
+    auto uniform = [&] { return (seed = seed * 1664525u + 1013904223u) / 4294967296.0; };
+    for (int i = 0; i != 200; ++i) {
+        frequency_domain_envelope e;
+        for (int j = 0; j != 100; ++j) e.insert({uniform(), uniform()});
+        REQUIRE(is_stable(arbitrary_magnitude_filter<6>(e).a));
+    }
+    const double wood[8] = {0.30, 0.30, 0.45, 0.65, 0.56, 0.59, 0.71, 0.71};
+    const auto c = to_impedance_coefficients(compute_reflectance_filter_coefficients(wood, 1333.3));
+    REQUIRE(c.a[0] == 1.0);
+    std::puts("filter design ok");
+}
+
+static void scene_to_audio() {
+    // a 6 x 5 x 4 m box room: floor of surface 1, the rest surface 0
+    scene_data scene;
+    for (int i = 0; i < 8; ++i)
+        scene.vertices.push_back(scene_vertex{(i & 1) ? 6.0f : 0.0f, (i & 2) ? 5.0f : 0.0f, (i & 4) ? 4.0f : 0.0f, 0.0f});
+    const uint32_t quads[6][4] = {{0, 1, 3, 2}, {4, 6, 7, 5}, {0, 4, 5, 1}, {2, 3, 7, 6}, {0, 2, 6, 4}, {1, 5, 7, 3}};
+    for (uint32_t q = 0; q < 6; ++q) {
+        const uint32_t s = q == 0 ? 1u : 0u;
+        scene.triangles.push_back(triangle{s, quads[q][0], quads[q][1], quads[q][2]});
+        scene.triangles.push_back(triangle{s, quads[q][0], quads[q][2], quads[q][3]});
+    }
+    scene.surfaces.push_back(surface_absorption{{0.05, 0.05, 0.05, 0.05, 0.05, 0.05, 0.05, 0.05}});
+    scene.surfaces.push_back(surface_absorption{{0.30, 0.30, 0.45, 0.65, 0.56, 0.59, 0.71, 0.71}});
+
+    const compute_context cc{};
+    const environment env{};
+    const vec3 source{1.5f, 1.5f, 1.5f}, receiver{4.0f, 3.0f, 2.0f};
+    const single_band_parameters params{150.0, 0.6};
+    const auto vm = compute_voxels_and_mesh(cc, scene, receiver, compute_sampling_frequency(params.cutoff, params.usable_portion),
+                                            env.speed_of_sound);
+    const auto& d = vm.mesh.get_descriptor();
+    const vec3 at = compute_position(d, compute_locator(d, receiver));
+    REQUIRE(std::fabs(at.x - receiver.x) < 1e-4 && std::fabs(at.y - receiver.y) < 1e-4 && std::fabs(at.z - receiver.z) < 1e-4);
+    REQUIRE(std::fabs(estimate_volume(vm.mesh) - 120.0) < 0.25 * 120.0);
+    REQUIRE(vm.mesh.get_structure().get_coefficients().size() == 2);
+    bool floor_seen = false, wall_seen = false;
+    for (const auto& b : vm.mesh.get_structure().get_boundary_index_data().b1) {
+        floor_seen |= b.array[0] == 1;
+        wall_seen |= b.array[0] == 0;
+    }
+    REQUIRE(floor_seen && wall_seen);
+
+    const auto bands = canonical(cc, vm.mesh, source, receiver, env, params, 0.25, true, [](size_t, size_t) {});
+    REQUIRE(bool(bands) && bands->size() == 1);
+    const double fs = bands->front().band.sample_rate;
+    const size_t steps = bands->front().band.directional.size();
+    REQUIRE(steps == (size_t)std::ceil(fs * 0.25));
+    attenuator::microphone mic;
+    mic.pointing = vec3{0, 1, 0};
+    mic.shape = 0.5f;
+    const auto audio = postprocess(*bands, mic, env.acoustic_impedance, 44100.0);
+    REQUIRE(audio.size() == (size_t)(44100.0 / fs * (double)steps));
+    float peak = 0;
+    for (float v : audio) {
+        REQUIRE(std::isfinite(v));
+        peak = std::max(peak, std::fabs(v));
+    }
+    REQUIRE(peak > 0);
+    const auto omni = postprocess(*bands, attenuator::null{}, env.acoustic_impedance, 44100.0);
+    REQUIRE(omni.size() == audio.size());
+    bool threw = false;
+    try {
+        postprocess(*bands, mic, 250.0, 44100.0);
+    } catch (const std::runtime_error& e) {
+        threw = std::strstr(e.what(), "Acoustic impedance outside expected range.") != nullptr;
+    }
+    REQUIRE(threw);
+    std::puts("scene to audio ok");
+}
+
 int main() {
     try {
+        filters_are_stable();
         run_waveguide();
         determinism();
         nan_in_waveguide();
         canonical_matches_generic();
+        scene_to_audio();
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 2;

@@ -13,7 +13,8 @@ EXE = os.path.join(ROOT, "tests", "cpp", "run_api_test")
 def _build(built_library):
     if os.path.exists(EXE) and os.path.getmtime(EXE) > max(
             os.path.getmtime(SRC), os.path.getmtime(built_library),
-            os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "waveguide.h"))):
+            os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "waveguide.h")),
+            os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "setup.h"))):
         return
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
                            "-o", EXE, "-L", os.path.join(ROOT, "wayverb_amd"), "-lwayverb_amd",
@@ -27,6 +28,7 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_a_gpu(built_library):
         pytest.skip("a GPU is present")
     p = subprocess.run([EXE], capture_output=True, text=True)
     assert p.returncode == 2 and "no HIP device" in p.stdout
+    assert "filter design ok" in p.stdout      # the host-only part ran before the first GPU call
 
 
 @pytest.mark.gpu
