@@ -326,9 +326,13 @@ public:
             // 4 MiB L2 (measured best at 0.75-1.5 MiB), at least 8 stripes so every XCD has one
             const int tile_rows = p.ry * p.nwy;
             int64_t rows = knob > 0 ? knob : (int64_t)(1600 * 1024) / (3ll * pitch_ * (int64_t)sizeof(Real));
-            int pow2 = tile_rows;
-            while (pow2 * 2 <= rows) pow2 *= 2;
-            rows = pow2;
+            if (knob > 0) {
+                rows = std::max<int64_t>(tile_rows, rows / tile_rows * tile_rows);  // explicit: any whole number of tiles
+            } else {
+                int pow2 = tile_rows;
+                while (pow2 * 2 <= rows) pow2 *= 2;
+                rows = pow2;
+            }
             const int per_xcd = (((ny_ + 7) / 8) + tile_rows - 1) / tile_rows * tile_rows;
             if (knob <= 0) rows = std::min<int64_t>(rows, per_xcd);
             rows = std::max<int64_t>(rows, 1);
