@@ -248,8 +248,8 @@ int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3
  * nodes: in, boundary_type as wv_classify_nodes leaves it (boundary_index is ignored);
  *        out, boundary_index as `run` wants it (1-D numbering without the re-entrant nodes).
  * b1 [counts[0]][1], b2 [counts[1]][2], b3 [counts[2]][3]: surface index per filter, i.e. the
- * wv_mesh::boundary_indices_* arrays.  counts[] is always written; WV_E_INVALID_ARGUMENT when a
- * capacity (in rows) is too small -- wv_classify_nodes' counts are upper bounds -- or when the
+ * wv_mesh::boundary_indices_* arrays.  counts[] is always written; with b1 = b2 = b3 = NULL the call
+ * is a size query.  WV_E_INVALID_ARGUMENT when a capacity (in rows) is too small or when the
  * mesh lacks 1-D, 2-D or 3-D boundary nodes ("No boundaries.", boundary_coefficient_finder.cpp:30-33).
  * Entry 0 of the 1-D array is written by its owner only (the reference lets every inside node race
  * for it). */

@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wayverb_amd.h"
@@ -242,33 +243,61 @@ extern "C" int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const 
     // first numbering (boundary_coefficient_finder.cpp:44-54): the 1-D array also has a slot for
     // every re-entrant node; lists of the nodes each kernel has work for
     const size_t n = (size_t)nx * ny * nz;
+    // (two passes over the planes on all host cores: count per plane, prefix, fill)
+    auto dim_of = [](int32_t bt) -> int {
+        if (bt == WV_ID_REENTRANT) return 0;
+        if (bt == WV_ID_NONE || (bt & (WV_ID_INSIDE | WV_ID_REENTRANT))) return -1;
+        const int bits = __builtin_popcount((uint32_t)bt);
+        return bits >= 1 && bits <= 3 ? bits - 1 : -1;
+    };
+    const size_t plane = (size_t)nx * ny;
+    const int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)nz);
+    std::vector<uint32_t> start((size_t)(nz + 1) * 4, 0);  // per plane: 1-D+re-entrant, 2-D, 3-D, true 1-D
+    auto for_planes = [&](auto&& body) {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t] {
+                for (int z = t; z < nz; z += n_threads) body(z);
+            });
+        for (auto& th : pool) th.join();
+    };
+    for_planes([&](int z) {
+        uint32_t k[4] = {0, 0, 0, 0};
+        for (size_t i = (size_t)z * plane; i < (size_t)(z + 1) * plane; ++i) {
+            const int d = dim_of(nodes[i].boundary_type);
+            if (d >= 0) ++k[d];
+            if (d == 0 && nodes[i].boundary_type != WV_ID_REENTRANT) ++k[3];
+        }
+        for (int d = 0; d < 4; ++d) start[(size_t)(z + 1) * 4 + d] = k[d];
+    });
+    for (int z = 0; z < nz; ++z)
+        for (int d = 0; d < 4; ++d) start[(size_t)(z + 1) * 4 + d] += start[(size_t)z * 4 + d];
+    const uint32_t* total = &start[(size_t)nz * 4];
+    const uint32_t c[3] = {total[0], total[1], total[2]};
+    const uint64_t true_1d = total[3];
     std::vector<uint64_t> list[3];
-    std::vector<uint32_t> slot1;
-    uint32_t c[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; ++i) {
-        const int32_t bt = nodes[i].boundary_type;
-        int d = -1;
-        if (bt == WV_ID_REENTRANT) {
-            d = 0;
-        } else if (bt != WV_ID_NONE && !(bt & (WV_ID_INSIDE | WV_ID_REENTRANT))) {
-            const int bits = __builtin_popcount((uint32_t)bt);
-            if (bits >= 1 && bits <= 3) d = bits - 1;
+    for (int d = 0; d < 3; ++d) list[d].resize(c[d]);
+    std::vector<uint32_t> slot1(c[0]);
+    for_planes([&](int z) {
+        uint32_t k[3] = {start[(size_t)z * 4], start[(size_t)z * 4 + 1], start[(size_t)z * 4 + 2]};
+        for (size_t i = (size_t)z * plane; i < (size_t)(z + 1) * plane; ++i) {
+            const int d = dim_of(nodes[i].boundary_type);
+            if (d < 0) {
+                nodes[i].boundary_index = 0;
+                continue;
+            }
+            nodes[i].boundary_index = k[d];
+            list[d][k[d]] = i;
+            if (d == 0) slot1[k[d]] = k[d];
+            ++k[d];
         }
-        if (d < 0) {
-            nodes[i].boundary_index = 0;
-            continue;
-        }
-        nodes[i].boundary_index = c[d]++;
-        list[d].push_back(i);
-        if (d == 0) slot1.push_back(nodes[i].boundary_index);
-    }
-    uint64_t true_1d = 0;
-    for (uint64_t i : list[0]) true_1d += nodes[i].boundary_type != WV_ID_REENTRANT;
+    });
     counts[0] = true_1d;
     counts[1] = c[1];
     counts[2] = c[2];
     if (!c[0] || !c[1] || !c[2])  // init_buffer, boundary_coefficient_finder.cpp:30-33
         return wv::fail_with(WV_E_INVALID_ARGUMENT, "No boundaries.");
+    if (!b1 && !b2 && !b3) return WV_OK;  // size query: counts only (the nodes' indices hold the first numbering)
     if (capacity_1 < true_1d || capacity_2 < c[1] || capacity_3 < c[2] || !b1 || !b2 || !b3)
         return wv::fail_with(WV_E_INVALID_ARGUMENT, "boundary index arrays too small (see counts)");
 

@@ -211,17 +211,14 @@ def boundary_index_data(dims, min_corner, spacing, nodes, triangles, vertices):
     v = np.ascontiguousarray(vertices, dtype=np.float32)
     t = np.ascontiguousarray(triangles, dtype=np.uint32)
     mc = np.ascontiguousarray(min_corner, dtype=np.float32)
-    bt = nodes["boundary_type"]
-    pc = np.zeros(bt.shape, dtype=np.int8)
-    for bit in range(1, 7):
-        pc += ((bt >> bit) & 1).astype(np.int8)
-    cap = [max(1, int(np.count_nonzero(pc == d))) for d in (1, 2, 3)]
-    out = [np.zeros((cap[d], d + 1), dtype=np.uint32) for d in range(3)]
     counts = (C.c_uint64 * 3)()
-    _check(lib.wv_boundary_index_data(nx, ny, nz, mc.ctypes.data_as(C.c_void_p), float(spacing),
-                                      nodes.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), t.shape[0],
-                                      v.ctypes.data_as(C.c_void_p), v.shape[0],
-                                      out[0].ctypes.data_as(C.c_void_p), cap[0], out[1].ctypes.data_as(C.c_void_p), cap[1],
+    args = (nx, ny, nz, mc.ctypes.data_as(C.c_void_p), float(spacing), nodes.ctypes.data_as(C.c_void_p),
+            t.ctypes.data_as(C.c_void_p), t.shape[0], v.ctypes.data_as(C.c_void_p), v.shape[0])
+    _check(lib.wv_boundary_index_data(*args, None, 0, None, 0, None, 0, counts))     # size query
+    cap = [max(1, int(counts[d])) for d in range(3)]
+    out = [np.zeros((cap[d], d + 1), dtype=np.uint32) for d in range(3)]
+    _check(lib.wv_boundary_index_data(*args, out[0].ctypes.data_as(C.c_void_p), cap[0],
+                                      out[1].ctypes.data_as(C.c_void_p), cap[1],
                                       out[2].ctypes.data_as(C.c_void_p), cap[2], counts))
     return [out[d][:int(counts[d])].copy() for d in range(3)]
 
