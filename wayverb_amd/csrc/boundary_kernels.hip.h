@@ -5,9 +5,9 @@
 // `filter_step_canonical` (src/waveguide/src/cl/filters.cpp:17-36,39).
 //
 // Data layout (HBM): boundary nodes are compacted into one entry list, all 1-D nodes first,
-// then 2-D, then 3-D, each in the reference's boundary_index order (increasing node index,
-// boundary_coefficient_finder.cpp:11-19) so consecutive lanes touch consecutive memory on the
-// y- and z-faces.  Filter state is structure-of-arrays: fmem[j][slot], slot = base_D + i*n_D + k
+// then 2-D, then 3-D; inside a class the engine orders them by 64x8x8 brick (engine.hip, init) so
+// that consecutive lanes touch consecutive memory on the y- and z-walls and share cache lines
+// on the x-walls.  Filter state is structure-of-arrays: fmem[j][slot], slot = base_D + i*n_D + k
 // for filter i of node k, so the 6 state words of 64 neighbouring nodes are 6 coalesced 512-byte
 // rows instead of 64 strided 56-byte structs (cl/structs.h:38-41).
 //
@@ -339,12 +339,15 @@ struct BoundaryDataArgs {
     uint32_t n_slots, slot_base, n_d;
     int dim;
     uint64_t* aos;  // boundary_data_array<dim>[n_d] as 7 x 8-byte words per filter
+    uint32_t entry_off;          // first entry of this dimensionality class
+    const uint32_t* ref_to_pos;  // [n_entries] caller's boundary_index (+ entry_off) -> processing position
 };
 
 __global__ void __launch_bounds__(256) boundary_data_scatter_kernel(const BoundaryDataArgs a, int to_device) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_d * (uint32_t)a.dim) return;
-    const uint32_t k = t / (uint32_t)a.dim, i = t % (uint32_t)a.dim;
+    const uint32_t k_ref = t / (uint32_t)a.dim, i = t % (uint32_t)a.dim;
+    const uint32_t k = a.ref_to_pos[a.entry_off + k_ref] - a.entry_off;
     const uint32_t slot = a.slot_base + i * a.n_d + k;
     uint64_t* rec = a.aos + (size_t)t * 7;
     if (to_device) {

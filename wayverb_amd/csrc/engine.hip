@@ -220,12 +220,60 @@ public:
         if (status_host[0] & 2) return fail(WV_E_INVALID_MESH, "boundary_index exceeds the boundary array length");
         static_flag_ = status_host[1];
 
+        // ---- processing order of the boundary entries: inside each dimensionality class, sort by
+        // 64 x 8 x 8 (x, y, z) brick, then z, y, x inside the brick.  Runs along x stay runs (the
+        // y- and z-walls keep their coalescing); nodes isolated in x (the x-walls) end up as 8 x 8
+        // (y, z) patches per wave, so that a wave's `current` neighbours share cache lines instead
+        // of touching four private lines per node.  Filter slots follow the processing order;
+        // `ref_to_pos_` translates the caller's boundary_index wherever it crosses the ABI.
+        std::vector<uint32_t> ref_to_pos(ne);
+        for (uint32_t e = 0; e < n_entries_; ++e) ref_to_pos[e] = e;
+        WV_HIP(hipMalloc((void**)&ref_to_pos_, ne * sizeof(uint32_t)));
+        if (n_entries_ && env_int("WV_BOUNDARY_ORDER", 1) != 0) {
+            std::vector<uint32_t> bnode(n_entries_);
+            std::vector<uint8_t> btype(n_entries_);
+            WV_HIP(hipMemcpy(bnode.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            WV_HIP(hipMemcpy(btype.data(), btype_, (size_t)n_entries_, hipMemcpyDeviceToHost));
+            const uint32_t nd[3] = {n1_, n2_, n3_};
+            const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
+            std::vector<uint64_t> key(n_entries_);
+            std::vector<uint32_t> by_pos(n_entries_);
+            uint32_t off = 0;
+            for (int d = 0; d < 3; ++d) {
+                for (uint32_t k = 0; k < nd[d]; ++k) {
+                    const uint32_t idx = bnode[off + k];
+                    uint64_t kk = ~0ull >> 8;  // entries this engine does not own go last
+                    if (idx != wv::INVALID_NODE) {
+                        const uint64_t x = idx % (uint32_t)pitch_, q = idx / (uint32_t)pitch_;
+                        const uint64_t y = q % (uint32_t)ny_, z = q / (uint32_t)ny_;
+                        const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
+                        kk = (brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63);
+                    }
+                    key[off + k] = kk;
+                    by_pos[off + k] = off + k;
+                }
+                std::sort(by_pos.begin() + off, by_pos.begin() + off + nd[d],
+                          [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+                off += nd[d];
+            }
+            std::vector<uint32_t> bnode2(n_entries_);
+            std::vector<uint8_t> btype2(n_entries_);
+            for (uint32_t pos = 0; pos < n_entries_; ++pos) {
+                bnode2[pos] = bnode[by_pos[pos]];
+                btype2[pos] = btype[by_pos[pos]];
+                ref_to_pos[by_pos[pos]] = pos;
+            }
+            WV_HIP(hipMemcpy(bnode_, bnode2.data(), (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+            WV_HIP(hipMemcpy(btype_, btype2.data(), (size_t)n_entries_, hipMemcpyHostToDevice));
+        }
+        WV_HIP(hipMemcpy(ref_to_pos_, ref_to_pos.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice));
+
         // ---- filter state: coefficient indices per filter slot (get_boundary_data<N>, setup.h:68-85)
         {
             std::vector<uint32_t> cidx(ns, 0u);
             const uint32_t* src[3] = {m.boundary_indices_1, m.boundary_indices_2, m.boundary_indices_3};
             const uint32_t nd[3] = {n1_, n2_, n3_};
-            uint32_t base = 0;
+            uint32_t base = 0, entry_off = 0;
             for (int d = 1; d <= 3; ++d) {
                 if (nd[d - 1] && !src[d - 1]) return fail(WV_E_INVALID_ARGUMENT, "boundary index array missing");
                 for (uint32_t k = 0; k < nd[d - 1]; ++k)
@@ -233,9 +281,10 @@ public:
                         const uint32_t c = src[d - 1][(size_t)k * d + i];
                         if (c >= m.num_coefficients)
                             return fail(WV_E_INVALID_MESH, "coefficient index exceeds the coefficient array length");
-                        cidx[base + (uint32_t)i * nd[d - 1] + k] = c;
+                        cidx[base + (uint32_t)i * nd[d - 1] + (ref_to_pos[entry_off + k] - entry_off)] = c;
                     }
                 base += (uint32_t)d * nd[d - 1];
+                entry_off += nd[d - 1];
             }
             WV_HIP(hipMemcpy(cidx_, cidx.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
@@ -727,6 +776,8 @@ public:
         a.n_d = nd;
         a.dim = dim;
         a.aos = aos;
+        a.entry_off = dim == 1 ? 0u : (dim == 2 ? n1_ : n1_ + n2_);
+        a.ref_to_pos = ref_to_pos_;
         const uint32_t n = nd * (uint32_t)dim;
         hipLaunchKernelGGL(wv::boundary_data_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream_, a,
                            to_device ? 1 : 0);
@@ -789,7 +840,7 @@ private:
         events_.clear();
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
-        void* ptrs[] = {cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
+        void* ptrs[] = {ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
                         zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -808,6 +859,7 @@ private:
     int cls_pitch_ = 0;
     uint32_t n1_ = 0, n2_ = 0, n3_ = 0, n_entries_ = 0, n_slots_ = 0, n_coeffs_ = 0;
     uint32_t* bnode_ = nullptr;
+    uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
     uint8_t* btype_ = nullptr;
     double* fmem_ = nullptr;
     uint32_t* cidx_ = nullptr;
