@@ -421,3 +421,29 @@ def test_locator_index_round_trips():
         assert mesh.compute_index(*loc) == i
         pos = vm.min_corner + np.array(loc, dtype=np.float32) * np.float32(mesh.spacing)
         assert vm.compute_locator(pos) == tuple(loc)
+
+
+def test_malformed_scenes_are_refused_before_any_device_work(built_library):
+    """The set-up kernels follow triangle and voxel indices unchecked, so the ABI validates them."""
+    from wayverb_amd import engine as E
+    v, t = _scenes()["box"]
+    aabb, dims = _grid_for(v, 0.3)
+    vox = E.voxelise(v, t, aabb, 8)
+    bad_t = t.copy()
+    bad_t[3, 2] = v.shape[0] + 5
+    with pytest.raises(E.WaveguideError, match="missing vertex"):
+        E.voxelise(v, bad_t, aabb, 8)
+    with pytest.raises(E.WaveguideError, match="missing vertex"):
+        E.nodes_inside(dims, aabb[0], 0.3, vox, aabb, 8, bad_t, v)
+    bad_vox = vox.copy()
+    bad_vox[5] = vox.shape[0] + 100
+    with pytest.raises(E.WaveguideError, match="outside the array"):
+        E.nodes_inside(dims, aabb[0], 0.3, bad_vox, aabb, 8, t, v)
+    bad_vox = vox.copy()
+    full = int(np.argmax(vox[vox[:512]]))          # a cell with at least one triangle
+    bad_vox[vox[full] + 1] = t.shape[0] + 1
+    with pytest.raises(E.WaveguideError, match="missing triangle"):
+        E.nodes_inside(dims, aabb[0], 0.3, bad_vox, aabb, 8, t, v)
+    nodes = np.zeros(dims[0] * dims[1] * dims[2], dtype=M.condensed_node_dtype)
+    with pytest.raises(E.WaveguideError, match="missing vertex"):
+        E.boundary_index_data(dims, aabb[0], 0.3, nodes, bad_t, v)

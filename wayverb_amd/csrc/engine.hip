@@ -50,6 +50,14 @@ namespace {
 
 constexpr int kRing = 1024;  // steps per device batch (flag words / receiver rows kept on device)
 
+// a device allocation that lives for one scope (the WV_HIP early returns must not leak it)
+struct ScopedDevice {
+    void* p = nullptr;
+    ~ScopedDevice() {
+        if (p) (void)hipFree(p);
+    }
+};
+
 struct StreamPlan {
     int variant = 2;  // 2 = plane sweep (default), 0 = z-march, 1 = naive
     int ry = 4, nwx = 1, nwy = 4;
@@ -164,8 +172,9 @@ public:
         {
             const int64_t rows_total = (int64_t)ny_ * nz_;
             const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(32 << 20) / nx_);
-            wv::NodeRec* stage = nullptr;
-            WV_HIP(hipMalloc((void**)&stage, (size_t)rows_per_chunk * nx_ * sizeof(wv::NodeRec)));
+            ScopedDevice stage_mem;
+            WV_HIP(hipMalloc(&stage_mem.p, (size_t)rows_per_chunk * nx_ * sizeof(wv::NodeRec)));
+            wv::NodeRec* stage = static_cast<wv::NodeRec*>(stage_mem.p);
             for (int64_t row = 0; row < rows_total; row += rows_per_chunk) {
                 const int64_t rows = std::min(rows_per_chunk, rows_total - row);
                 const int64_t first = row * nx_, cnt = rows * nx_;
@@ -194,7 +203,6 @@ public:
                 WV_HIP(hipGetLastError());
                 WV_HIP(hipStreamSynchronize(stream_));  // `stage` is reused by the next chunk
             }
-            WV_HIP(hipFree(stage));
         }
         if (n_entries_) {
             wv::ValidateArgs v{};
@@ -725,8 +733,9 @@ public:
     int copy_field(Real* stored, void* host, bool to_device) {
         const int64_t rows_total = (int64_t)ny_ * nz_;
         const int64_t rows_per_chunk = std::max<int64_t>(1, (64ll << 20) / nx_);
-        Other* tmp = nullptr;
-        WV_HIP(hipMalloc((void**)&tmp, (size_t)std::min(rows_per_chunk, rows_total) * nx_ * sizeof(Other)));
+        ScopedDevice tmp_mem;
+        WV_HIP(hipMalloc(&tmp_mem.p, (size_t)std::min(rows_per_chunk, rows_total) * nx_ * sizeof(Other)));
+        Other* tmp = static_cast<Other*>(tmp_mem.p);
         for (int64_t row = 0; row < rows_total; row += rows_per_chunk) {
             const int64_t rows = std::min(rows_per_chunk, rows_total - row);
             const int64_t n = rows * nx_;
@@ -744,7 +753,6 @@ public:
             }
             WV_HIP(hipStreamSynchronize(stream_));
         }
-        WV_HIP(hipFree(tmp));
         return WV_OK;
     }
 
@@ -765,8 +773,9 @@ public:
         if (!nd) return WV_OK;
         const uint32_t base = dim == 1 ? 0u : (dim == 2 ? n1_ : n1_ + 2u * n2_);
         const size_t bytes = (size_t)nd * dim * sizeof(wv_boundary_data);
-        uint64_t* aos = nullptr;
-        WV_HIP(hipMalloc((void**)&aos, bytes));
+        ScopedDevice aos_mem;
+        WV_HIP(hipMalloc(&aos_mem.p, bytes));
+        uint64_t* aos = static_cast<uint64_t*>(aos_mem.p);
         if (to_device) WV_HIP(hipMemcpyAsync(aos, host, bytes, hipMemcpyHostToDevice, stream_));
         wv::BoundaryDataArgs a{};
         a.fmem = fmem_;
@@ -783,7 +792,6 @@ public:
                            to_device ? 1 : 0);
         if (!to_device) WV_HIP(hipMemcpyAsync(host, aos, bytes, hipMemcpyDeviceToHost, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
-        WV_HIP(hipFree(aos));
         return WV_OK;
     }
 
@@ -1044,12 +1052,14 @@ int wv_filter_test_2(const float* input, float* output, double* memory, const wv
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
     const size_t n = n_filters, total = (size_t)n_filters * n_samples;
-    float *d_in = nullptr, *d_out = nullptr;
-    double *d_mem = nullptr, *d_c = nullptr;
-    WV_HIP(hipMalloc((void**)&d_in, total * sizeof(float)));
-    WV_HIP(hipMalloc((void**)&d_out, total * sizeof(float)));
-    WV_HIP(hipMalloc((void**)&d_mem, n * 6 * sizeof(double)));
-    WV_HIP(hipMalloc((void**)&d_c, n * 14 * sizeof(double)));
+    ScopedDevice m_in, m_out, m_mem, m_c;
+    WV_HIP(hipMalloc(&m_in.p, std::max<size_t>(total, 1) * sizeof(float)));
+    WV_HIP(hipMalloc(&m_out.p, std::max<size_t>(total, 1) * sizeof(float)));
+    WV_HIP(hipMalloc(&m_mem.p, std::max<size_t>(n, 1) * 6 * sizeof(double)));
+    WV_HIP(hipMalloc(&m_c.p, std::max<size_t>(n, 1) * 14 * sizeof(double)));
+    float *d_in = static_cast<float*>(m_in.p), *d_out = static_cast<float*>(m_out.p);
+    double *d_mem = static_cast<double*>(m_mem.p), *d_c = static_cast<double*>(m_c.p);
+    if (total == 0) return WV_OK;
     WV_HIP(hipMemcpy(d_in, input, total * sizeof(float), hipMemcpyHostToDevice));
     WV_HIP(hipMemcpy(d_mem, memory, n * 6 * sizeof(double), hipMemcpyHostToDevice));
     WV_HIP(hipMemcpy(d_c, coeffs, n * 14 * sizeof(double), hipMemcpyHostToDevice));
@@ -1058,10 +1068,6 @@ int wv_filter_test_2(const float* input, float* output, double* memory, const wv
     WV_HIP(hipGetLastError());
     WV_HIP(hipMemcpy(output, d_out, total * sizeof(float), hipMemcpyDeviceToHost));
     WV_HIP(hipMemcpy(memory, d_mem, n * 6 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    (void)hipFree(d_mem);
-    (void)hipFree(d_c);
     return WV_OK;
 }
 

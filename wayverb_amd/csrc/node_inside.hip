@@ -292,6 +292,19 @@ extern "C" int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float m
     if (nx < 1 || ny < 1 || nz < 1 || !min_corner || !voxel_index || !aabb_min || !aabb_max || !triangles || !vertices ||
         !inside || side < 1 || n_voxel_words < (uint64_t)side * side * side)
         return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument");
+    // the kernel follows these indices without checks: refuse a malformed scene here
+    for (uint32_t t = 0; t < n_triangles; ++t)
+        for (int k = 1; k < 4; ++k)
+            if (triangles[4 * (size_t)t + k] >= n_vertices)
+                return wv::fail_with(WV_E_INVALID_ARGUMENT, "triangle refers to a missing vertex");
+    for (uint64_t cell = 0, cells = (uint64_t)side * side * side; cell < cells; ++cell) {
+        const uint64_t off = voxel_index[cell];
+        if (off >= n_voxel_words || off + 1 + voxel_index[off] > n_voxel_words)
+            return wv::fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list outside the array");
+        for (uint32_t k = 0; k < voxel_index[off]; ++k)
+            if (voxel_index[off + 1 + k] >= n_triangles)
+                return wv::fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list refers to a missing triangle");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return wv::fail_with(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
