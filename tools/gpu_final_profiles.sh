@@ -1,15 +1,12 @@
 #!/bin/bash
-# Round-end evidence: tests, bench (N=1), rocprofv3 kernel stats + PMC traffic, engine sweeps.
+# Round-end evidence: tests, rocprofv3 kernel stats + PMC traffic, bench (N=1), engine sweeps.
 R=${1:-r01}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
-python -m pytest tests -m gpu -q > gpurun_out/$R/pytest_gpu.txt 2>&1; tail -3 gpurun_out/$R/pytest_gpu.txt
+python -m pytest tests -m gpu -q > gpurun_out/$R/pytest_gpu.txt 2>&1; grep -h "passed\|failed" gpurun_out/$R/pytest_gpu.txt | tail -1
 python __graft_entry__.py --smoke > gpurun_out/$R/smoke.txt 2>&1; tail -1 gpurun_out/$R/smoke.txt
-python bench.py > gpurun_out/$R/bench_n1.json 2> gpurun_out/$R/bench_n1.err; tail -1 gpurun_out/$R/bench_n1.json | cut -c1-300
-python bench.py --precision f32 --no-cpu-baseline --no-small > gpurun_out/$R/bench_n1_f32.json 2>/dev/null
-python bench.py --nx 256 --ny 256 --nz 256 --no-cpu-baseline --no-small --steps 10000 --warmup 500 > gpurun_out/$R/bench_256cubed_10k_steps.json 2>/dev/null; tail -1 gpurun_out/$R/bench_256cubed_10k_steps.json | cut -c1-200
 CMD="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-small"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -o bench -- $CMD > gpurun_out/$R/trace.log 2>&1
-cp gpurun_out/$R/trace/bench_kernel_stats.csv gpurun_out/$R/rocprof_kernel_stats.csv; head -4 gpurun_out/$R/rocprof_kernel_stats.csv
+cp gpurun_out/$R/trace/bench_kernel_stats.csv gpurun_out/$R/rocprof_kernel_stats.csv; head -4 gpurun_out/$R/rocprof_kernel_stats.csv | cut -c1-160
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmc_fetch -o bench -- $CMD > gpurun_out/$R/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$R/pmc_write -o bench -- $CMD > gpurun_out/$R/pmc_write.log 2>&1
 python3 - "$R" <<'PY'
@@ -25,7 +22,20 @@ for tag in ('pmc_fetch','pmc_write'):
 json.dump(out, open('gpurun_out/%s/pmc_summary.json'%R,'w'), indent=1)
 for k,v in out.items():
     if 'sweep' in k or 'boundary_kernel' in k: print(k, v)
+    if 'stream_sweep_kernel<double' in k and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        rec = {"workload": "1024x1024x1024 f64", "kernel": k.replace('void ', ''),
+               "source": "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, launches of `bench.py --steps 30 --warmup 5`)" % R,
+               "FETCH_SIZE_KiB_raw": v['FETCH_SIZE']['mean'], "WRITE_SIZE_KiB_raw": v['WRITE_SIZE']['mean'],
+               "corrections": "gfx950: FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads -> x2 (calibrated on the in-place triad in tools/stream_bench.hip: 2*FETCH_SIZE*1024 = bytes read, exactly); WRITE_SIZE*1024 = bytes written, exactly; Infinity-Cache hits are counted (fabric-side counter)",
+               "hbm_bytes_per_launch": int(2 * v['FETCH_SIZE']['mean'] * 1024 + v['WRITE_SIZE']['mean'] * 1024)}
+        json.dump(rec, open('gpurun_out/%s/traffic.json' % R, 'w'), indent=1)
+        json.dump(rec, open('profiles/traffic.json', 'w'), indent=1)   # what this box's bench run reports
 PY
 rm -rf gpurun_out/$R/trace gpurun_out/$R/pmc_fetch gpurun_out/$R/pmc_write
+python bench.py > gpurun_out/$R/bench_n1.json 2> gpurun_out/$R/bench_n1.err; tail -1 gpurun_out/$R/bench_n1.json | cut -c1-400
+python bench.py --precision f32 --no-cpu-baseline --no-small > gpurun_out/$R/bench_n1_f32.json 2>/dev/null
+python bench.py --nx 256 --ny 256 --nz 256 --no-cpu-baseline --no-small --steps 10000 --warmup 500 > gpurun_out/$R/bench_256cubed_10k_steps.json 2>/dev/null; tail -1 gpurun_out/$R/bench_256cubed_10k_steps.json | cut -c1-200
+python bench.py --nx 1000 --ny 1000 --nz 1000 --no-cpu-baseline --no-small > gpurun_out/$R/bench_1000cubed.json 2>/dev/null
 python tools/sweep_stream.py --steps 10 --out gpurun_out/$R/sweep_engine_1024_f64.json > /dev/null 2>&1
+python tools/setup_bench.py --n 768 > gpurun_out/$R/setup_bench_768.json 2>/dev/null
 ls gpurun_out/$R
