@@ -12,6 +12,7 @@
 //   attenuate / postprocess              src/waveguide/include/waveguide/{attenuator,postprocess}.h
 //   adjust_sampling_rate                 src/waveguide/src/config.cpp:29-56
 //   config::grid_spacing / time_step     src/waveguide/src/config.cpp:15-25
+//   canonical (multiple bands)           src/waveguide/include/waveguide/canonical.h:127-176
 //
 // What differs, deliberately:
 //   - the scene is plain arrays (`scene_data`: cl_float3-strided vertices, {surface, v0, v1, v2}
@@ -122,6 +123,7 @@ struct voxels_and_mesh final {  // mesh.h:52-58
     core::box voxels_aabb;
     uint32_t voxels_side;
     waveguide::mesh mesh;
+    std::vector<core::surface_absorption> surfaces;  // voxels.get_scene_data().get_surfaces()
 };
 
 inline double estimate_volume(const mesh& m) {  // mesh.cpp:40-49
@@ -187,7 +189,49 @@ voxels_and_mesh compute_voxels_and_mesh(const Context& cc, const core::scene_dat
 
     return voxels_and_mesh{std::move(voxels), aabb, side,
                            mesh{mesh_descriptor{aabb.c0, dim, mesh_spacing},
-                                vectors{std::move(nodes), std::move(coefficients), std::move(bid)}}};
+                                vectors{std::move(nodes), std::move(coefficients), std::move(bid)}},
+                           scene.surfaces};
+}
+
+// ---- multi-band runs ---------------------------------------------------------------------------------
+struct multiple_band_constant_spacing_parameters final {  // simulation_parameters.h:32-43
+    size_t bands;
+    double cutoff;
+    double usable_portion;
+};
+
+/// hrtf_band_params_hz().edges (src/hrtf/lib/include/hrtf/multiband.h:22-25)
+inline std::array<double, 9> band_edges_hz() {
+    std::array<double, 9> e{};
+    for (size_t i = 0; i < e.size(); ++i) e[i] = 20.0 * std::pow(20000.0 / 20.0, (double)i / 8.0);
+    return e;
+}
+
+/// canonical.h:127-135
+inline void set_flat_coefficients_for_band(voxels_and_mesh& vm, size_t band) {
+    std::vector<coefficients_canonical> c;
+    for (const auto& s : vm.surfaces) c.push_back(to_flat_coefficients(s.s[band]));
+    vm.mesh.set_coefficients(std::move(c));
+}
+
+/// canonical.h:138-176: one run per band with flat per-band wall filters
+template <typename Context, typename PressureCallback>
+std::experimental::optional<std::vector<bandpass_band>> canonical(
+        const Context& cc, voxels_and_mesh voxelised, const vec3& source, const vec3& receiver,
+        const core::environment& environment, const multiple_band_constant_spacing_parameters& sim_params,
+        double simulation_time, const std::atomic_bool& keep_going, PressureCallback&& pressure_callback) {
+    const auto edges = band_edges_hz();
+    std::vector<bandpass_band> ret;
+    for (size_t band = 0; band != sim_params.bands; ++band) {
+        set_flat_coefficients_for_band(voxelised, band);
+        if (auto rendered = detail::canonical_impl(cc, voxelised.mesh, simulation_time, source, receiver, environment,
+                                                   keep_going, pressure_callback)) {
+            ret.push_back(bandpass_band{std::move(*rendered), edges[band], edges[band + 1]});
+        } else {
+            return std::experimental::nullopt;
+        }
+    }
+    return ret;
 }
 
 // ---- receiver traces -> audio ------------------------------------------------------------------------

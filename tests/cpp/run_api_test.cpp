@@ -235,6 +235,14 @@ static void scene_to_audio() {
         threw = std::strstr(e.what(), "Acoustic impedance outside expected range.") != nullptr;
     }
     REQUIRE(threw);
+    // canonical.h:138-176: two bands, flat per-band walls, each valid on its own band
+    const auto two = canonical(cc, vm, source, receiver, env, multiple_band_constant_spacing_parameters{2, 150.0, 0.6},
+                               0.05, true, [](size_t, size_t) {});
+    REQUIRE(bool(two) && two->size() == 2);
+    REQUIRE(std::fabs((*two)[0].valid_hz_min - 20.0) < 1e-9 && std::fabs((*two)[1].valid_hz_min - (*two)[0].valid_hz_max) < 1e-9);
+    REQUIRE((*two)[0].band.directional.size() == (*two)[1].band.directional.size());
+    const auto mixed = postprocess(*two, attenuator::null{}, env.acoustic_impedance, 44100.0);
+    REQUIRE(!mixed.empty());
     std::puts("scene to audio ok");
 }
 

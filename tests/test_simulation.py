@@ -82,3 +82,30 @@ def test_canonical_rejects_positions_outside_the_room(built_library):
         W.canonical(vm, (9.0, 3.0, -0.8), (8.0, 20.0, 1.2), env, 150.0, 0.6, 0.01)    # inside the stage block
     with pytest.raises(ValueError, match="absorption sets"):
         W.compute_voxels_and_mesh(v, t, [PLASTER], (8.0, 20.0, 1.2), 1000.0, 340.0)
+
+
+@pytest.mark.gpu
+def test_multiband_canonical(oracle, built_library):
+    """canonical.h:138-176: one run per band, every wall flat at that band's absorption; each band
+    equals a single-band run of a mesh built with those flat filters, and is tagged with its band."""
+    v, t = S.hall_scene()
+    env = W.Environment()
+    source, receiver = (9.0, 3.0, 1.5), (8.0, 20.0, 1.2)
+    vm = W.compute_voxels_and_mesh(v, t, [PLASTER, WOOD], receiver, W.compute_sampling_frequency(120.0, 0.6),
+                                   env.speed_of_sound)
+    designed = vm.mesh.coefficients.copy()
+    bands = W.canonical_multiband(vm, source, receiver, env, 3, 120.0, 0.6, 0.08)
+    assert len(bands) == 3 and np.array_equal(vm.mesh.coefficients, designed)      # restored afterwards
+    edges = W.band_edges_hz()
+    assert edges[0] == 20.0 and edges[8] == pytest.approx(20000.0)
+    for k, (directional, sr, valid) in enumerate(bands):
+        assert valid == (edges[k], edges[k + 1])
+        flat = np.zeros(2, dtype=M.coefficients_dtype)
+        flat[0], flat[1] = M.flat_coefficients(PLASTER[k]), M.flat_coefficients(WOOD[k])
+        vm.mesh.coefficients = flat
+        single = W.canonical(vm, source, receiver, env, 120.0, 0.6, 0.08)
+        vm.mesh.coefficients = designed
+        assert single[0][0].tobytes() == directional.tobytes()
+    audio = P.postprocess(bands, P.ATTENUATOR_NULL, acoustic_impedance=env.acoustic_impedance,
+                          output_sample_rate=8000.0)
+    assert audio.shape[0] == int(8000.0 / bands[0][1] * bands[0][0].shape[0]) and np.abs(audio).max() > 0

@@ -49,7 +49,8 @@ def compute_sample_rate(spacing, speed_of_sound):
 class VoxelsAndMesh:
     """voxels_and_mesh (mesh.h): the voxelised scene the set-up kernels walked + the mesh."""
 
-    def __init__(self, voxel_index, aabb, side, vertices, triangles, mesh, min_corner):
+    def __init__(self, voxel_index, aabb, side, vertices, triangles, mesh, min_corner, surface_absorptions=None):
+        self.surface_absorptions = surface_absorptions
         self.voxel_index = voxel_index
         self.aabb = aabb
         self.side = side
@@ -99,7 +100,7 @@ def compute_voxels_and_mesh(vertices, triangles, surface_absorptions, anchor, sa
     for i, a in enumerate(absorptions):
         coeffs[i] = F.surface_coefficients(a, speed_of_sound, float(spacing))   # mesh.cpp:126-138
     mesh = M.Mesh(dims, nodes, coeffs, b[0], b[1], b[2], spacing=float(spacing))
-    return VoxelsAndMesh(vox, (c0, c1), side, vertices, triangles, mesh, c0)
+    return VoxelsAndMesh(vox, (c0, c1), side, vertices, triangles, mesh, c0, absorptions)
 
 
 def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulation_time, precision="f32",
@@ -135,6 +136,38 @@ def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulat
         return None
     directional = P.directional_receiver(traces, mesh.spacing, sample_rate, environment.ambient_density)
     return [(directional, sample_rate, (0.0, float(cutoff)))]
+
+
+def band_edges_hz(bands=8, lo=20.0, hi=20000.0):
+    """hrtf_band_params_hz().edges: band_edge_frequency(i, 8, {20, 20000})
+    (src/frequency_domain/src/envelope.cpp:50-53, src/hrtf/lib/include/hrtf/multiband.h:22-25)"""
+    return [lo * (hi / lo) ** (i / float(bands)) for i in range(bands + 1)]
+
+
+def canonical_multiband(vm, source, receiver, environment, bands, cutoff, usable_portion, simulation_time,
+                        precision="f32", device=-1, keep_going=lambda: True):
+    """canonical for multiple_band_constant_spacing_parameters (canonical.h:138-176): one run per
+    band with every surface's filter replaced by the flat filter of that band's absorption
+    (set_flat_coefficients_for_band, :127-135); band i is valid on [edge_i, edge_i+1)."""
+    if vm.surface_absorptions is None:
+        raise ValueError("this VoxelsAndMesh carries no surface absorptions")
+    edges = band_edges_hz()
+    keep = vm.mesh.coefficients
+    out = []
+    try:
+        for band in range(int(bands)):
+            flat = np.zeros(len(vm.surface_absorptions), dtype=M.coefficients_dtype)
+            for i, a in enumerate(vm.surface_absorptions):
+                flat[i] = M.flat_coefficients(float(a[band]))
+            vm.mesh.coefficients = flat
+            r = canonical(vm, source, receiver, environment, cutoff, usable_portion, simulation_time, precision, device,
+                          keep_going)
+            if r is None:
+                return None
+            out.append((r[0][0], r[0][1], (edges[band], edges[band + 1])))
+    finally:
+        vm.mesh.coefficients = keep
+    return out
 
 
 def impulse_response(vertices, triangles, surface_absorptions, source, receiver, cutoff=200.0, usable_portion=0.6,
