@@ -106,7 +106,11 @@ typedef struct wv_options {
      * (1 = after every step, like waveguide.h:100-101; 0 = once per wv_run call) */
     int32_t flag_interval;
     int32_t stream_variant; /* 2 = plane sweep (default), 0 = register z-march, 1 = naive */
-    int32_t reserved_[9];
+    /* 0 (default): when a room leaves part of the mesh outside, the sweep visits only the tiles
+     * that hold inside nodes (outside nodes are 0 and stay 0; wv_write_field / wv_write_value
+     * re-enable the full sweep until they are 0 again).  1: always visit every tile. */
+    int32_t all_tiles;
+    int32_t reserved_[8];
 } wv_options;
 
 typedef struct wv_engine wv_engine;
@@ -137,7 +141,9 @@ int wv_read_boundary_data(wv_engine* e, int dimensionality, wv_boundary_data* ds
 int wv_write_boundary_data(wv_engine* e, int dimensionality, const wv_boundary_data* src);
 /* mesh::set_coefficients (src/waveguide/src/setup.cpp:38-50): n must equal num_coefficients */
 int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32_t n);
-/* Device addresses of the fields (element type per precision), for zero-copy wrappers. */
+/* Device addresses of the fields (element type per precision), for zero-copy wrappers.  Once a
+ * pointer has been handed out the engine stops assuming that outside nodes hold zeros (see
+ * wv_options::all_tiles). */
 int wv_device_buffer(wv_engine* e, int buffer, void** device_ptr);
 
 /* ---- stepping: the generic path ------------------------------------------------------------- */

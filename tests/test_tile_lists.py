@@ -1,0 +1,108 @@
+"""The sweep's work lists (rooms that leave part of the mesh outside): same results as visiting every
+tile, and the reference's treatment of outside nodes -- whatever a caller writes there is zeroed by
+the next steps (program.cpp:405-411, `default: return 0`) -- survives the shortcut."""
+import numpy as np
+import pytest
+
+from helpers import run_engine, run_oracle
+from wayverb_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_rooms(dims=(300, 40, 24)):
+    """Two separate box rooms in one mesh: most tiles hold no inside node."""
+    nx, ny, nz = dims
+    mask = np.zeros((nz, ny, nx), dtype=bool)
+    mask[3:20, 4:36, 10:120] = True
+    mask[6:15, 8:30, 200:280] = True
+    return mask
+
+
+def _mesh(mask, built_library):
+    from wayverb_amd import engine as E
+    nodes, counts = E.classify_nodes(mask)
+    coeffs = np.zeros(3, dtype=M.coefficients_dtype)
+    coeffs[0] = M.flat_coefficients(0.2)
+    coeffs[1:] = M.passive_peak_filter_coefficients(np.random.default_rng(4), 2)
+    nz, ny, nx = mask.shape
+    return M.mesh_from_nodes((nx, ny, nz), nodes, counts, coeffs, surface_of_port=[0, 1, 2, 0, 1, 2])
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_partial_room_lists_equal_full_sweep_and_oracle(oracle, built_library, tag, dtype):
+    mask = _two_rooms()
+    mesh = _mesh(mask, built_library)
+    assert mask.mean() < 0.5
+    steps = 70
+    sig = np.zeros(steps)
+    sig[0] = 1.0
+    src = mesh.compute_index(60, 20, 10)
+    recv = [mesh.compute_index(100, 30, 15), mesh.compute_index(240, 20, 10), mesh.compute_index(150, 20, 10)]
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=src, signal=sig, recv=recv, init=None)
+    want = run_oracle(oracle, case, dtype, threads=4)
+    lists = run_engine(case, tag)
+    full = run_engine(case, tag, all_tiles=True)
+    assert want["flag"] == 0 and np.abs(want["trace"][:, 0]).max() > 0
+    for got in (lists, full):
+        assert np.array_equal(got["trace"], want["trace"])
+        assert got["current"].tobytes() == want["current"].tobytes()
+        assert got["previous"].tobytes() == want["previous"].tobytes()
+        for a, b in zip(got["bd"], want["bd"]):
+            assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("steps", [1, 2, 3, 9])
+def test_written_outside_nodes_are_zeroed_like_the_reference(oracle, built_library, steps):
+    """Fields written by the caller (non-zero everywhere, outside nodes included): the first two
+    steps must run the full sweep so that the outside nodes end up 0 in both fields, as in the
+    reference; afterwards the lists take over."""
+    mask = np.zeros((12, 36, 140), dtype=bool)
+    mask[2:10, 3:30, 5:60] = True
+    mesh = _mesh(mask, built_library)
+    rng = np.random.default_rng(8)
+    init = (rng.normal(size=mesh.num_nodes) * 1e-3, rng.normal(size=mesh.num_nodes) * 1e-3)
+    case = dict(mesh=mesh, steps=steps, source_kind=0, source_node=0, signal=np.zeros(steps),
+                recv=[mesh.compute_index(20, 10, 5)], init=init)
+    want = run_oracle(oracle, case, np.float64, threads=2)
+    got = run_engine(case, "f64")
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    outside = ~mask.reshape(-1) & (mesh.nodes["boundary_type"] == 0)
+    assert np.all(want["previous" if steps == 1 else "current"][outside] == 0) or steps == 1
+    if steps >= 2:
+        assert np.all(got["current"][outside] == 0) and np.all(got["previous"][outside] == 0)
+
+
+def test_write_value_into_an_outside_node_mid_run(oracle, built_library):
+    from wayverb_amd import engine as E
+    mask = np.zeros((12, 36, 140), dtype=bool)
+    mask[2:10, 3:30, 5:60] = True
+    mesh = _mesh(mask, built_library)
+    outside_node = mesh.compute_index(130, 30, 6)
+    assert mesh.nodes["boundary_type"][outside_node] == 0
+    src = mesh.compute_index(20, 10, 5)
+    sig = np.zeros(40)
+    sig[0] = 1.0
+    eng = E.Engine(mesh, precision="f64")
+    try:
+        eng.set_source(E.SOURCE_HARD, src, sig)
+        eng.run_steps(5)                      # lists in use
+        eng.write_value(outside_node, 3.25, E.BUF_CURRENT)
+        eng.write_value(outside_node, -1.5, E.BUF_PREVIOUS)
+        assert eng.read_value(outside_node, E.BUF_CURRENT) == 3.25
+        eng.run_steps(1)
+        # one step later `current` (the old `previous`, rewritten) is 0 there, `previous` still has the 3.25
+        assert eng.read_value(outside_node, E.BUF_CURRENT) == 0.0
+        assert eng.read_value(outside_node, E.BUF_PREVIOUS) == 3.25
+        eng.run_steps(1)
+        assert eng.read_value(outside_node, E.BUF_CURRENT) == 0.0
+        assert eng.read_value(outside_node, E.BUF_PREVIOUS) == 0.0
+        eng.run_steps(6)
+        got = eng.read_field(E.BUF_CURRENT)
+    finally:
+        eng.close()
+    # the outside node never feeds an inside node here, so the room evolves as if untouched
+    case = dict(mesh=mesh, steps=13, source_kind=1, source_node=src, signal=sig[:13], recv=[src], init=None)
+    want = run_oracle(oracle, case, np.float64, threads=2)
+    assert got.tobytes() == want["current"].tobytes()

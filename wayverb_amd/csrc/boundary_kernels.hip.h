@@ -319,6 +319,29 @@ __global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs 
     if (flag) atomicOr(a.static_flag, flag);
 }
 
+// Which workgroup tiles of the sweep hold at least one node the sweep updates (class inside or
+// re-entrant): one thread per tile of `tile_rows` x `tile_cols` nodes of one plane.
+struct TileActivityArgs {
+    const uint8_t* cls;
+    uint8_t* active;  // [nz][tiles_y][tiles_x]
+    int ny, nz, pitch, cls_pitch;
+    int tile_rows, tile_cols, tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256) tile_activity_kernel(const TileActivityArgs a) {
+    const int64_t n = (int64_t)a.nz * a.tiles_y * a.tiles_x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int tx = (int)(t % a.tiles_x);
+    const int ty = (int)((t / a.tiles_x) % a.tiles_y);
+    const int z = (int)(t / ((int64_t)a.tiles_x * a.tiles_y));
+    uint32_t any = 0;
+    for (int y = ty * a.tile_rows; y < min((ty + 1) * a.tile_rows, a.ny); ++y)
+        for (int x = tx * a.tile_cols; x < min((tx + 1) * a.tile_cols, a.pitch); x += 4)
+            any |= a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)] & 0x55u;  // bit 0 of a class: inside / re-entrant
+    a.active[t] = any ? 1 : 0;
+}
+
 // ---- field I/O for wv_read_field / wv_write_field: compact host layout (nx per row) <-> stored
 // layout (pitch per row), with f32 <-> f64 conversion when the element types differ
 template <typename Dst, typename Src>

@@ -118,6 +118,10 @@ struct StreamArgs {
     int total_tiles, tiles_per_xcd;
     // plane-sweep kernel only: rows per XCD stripe, tiles per stripe-plane, passes over z
     int stripe_rows, tiles_y_stripe, passes;
+    // optional work list (rooms that leave part of the mesh outside): workgroup j of XCD k takes
+    // tile_list[list_start[k] + j] = stripe << 48 | wave mask << 40 | z << 20 | tile-in-stripe-plane
+    const uint64_t* tile_list;
+    uint32_t list_start[9];
 };
 
 template <typename Real>

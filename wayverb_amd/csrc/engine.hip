@@ -353,6 +353,7 @@ public:
 
     // variant 2 (default): plane sweep, L2-resident z reuse; 0: register z-march; 1: naive
     void plan_stream() {
+        lists_built_ = false;  // tile shapes may change
         StreamPlan& p = plan_;
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
@@ -435,6 +436,113 @@ public:
     }
 
     // the pressure update of planes [z0, z1)
+    // Work lists for the plane sweep (variant 2).  A workgroup tile takes part only if it holds an
+    // inside or re-entrant node: outside nodes are 0 and stay 0, boundary nodes belong to the
+    // boundary kernel.  Whole stripes are dealt to the 8 XCDs heaviest first (each XCD still
+    // sweeps its stripes plane by plane, so the z reuse in its L2 is unchanged); a mesh that is
+    // almost all room (a box) keeps the arithmetic mapping.
+    int build_tile_lists() {
+        if (lists_built_) return WV_OK;
+        lists_built_ = true;
+        if (tile_list_) {
+            (void)hipFree(tile_list_);
+            tile_list_ = nullptr;
+        }
+        if (plan_.variant != 2 || env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0) return WV_OK;
+        // activity per wave tile (ry rows x one wave of columns); a workgroup tile is nwy x nwx of them
+        const int wave_cols = 64 * (16 / (int)sizeof(Real));
+        const int wtiles_x = plan_.tiles_x * plan_.nwx;
+        const int wtiles_y = (ny_ + plan_.ry - 1) / plan_.ry;
+        const int tile_rows = plan_.ry * plan_.nwy;
+        const int tiles_y = (ny_ + tile_rows - 1) / tile_rows;
+        const int64_t n_tiles = (int64_t)nz_ * wtiles_y * wtiles_x;
+        ScopedDevice act_mem;
+        WV_HIP(hipMalloc(&act_mem.p, (size_t)n_tiles));
+        wv::TileActivityArgs t{};
+        t.cls = cls_;
+        t.active = static_cast<uint8_t*>(act_mem.p);
+        t.ny = ny_;
+        t.nz = nz_;
+        t.pitch = pitch_;
+        t.cls_pitch = cls_pitch_;
+        t.tile_rows = plan_.ry;
+        t.tile_cols = wave_cols;
+        t.tiles_x = wtiles_x;
+        t.tiles_y = wtiles_y;
+        hipLaunchKernelGGL(wv::tile_activity_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream_, t);
+        WV_HIP(hipGetLastError());
+        std::vector<uint8_t> active((size_t)n_tiles);
+        WV_HIP(hipMemcpyAsync(active.data(), act_mem.p, (size_t)n_tiles, hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+
+        const int stripes = (ny_ + plan_.stripe_rows - 1) / plan_.stripe_rows;
+        const int tys = plan_.tiles_y_stripe;
+        // wave mask of workgroup tile (z, ty, tx): bit wy * nwx + wx
+        auto wave_mask = [&](int z, int ty, int tx) -> uint32_t {
+            uint32_t m = 0;
+            for (int wy = 0; wy < plan_.nwy; ++wy) {
+                const int wty = ty * plan_.nwy + wy;
+                if (wty >= wtiles_y) break;
+                for (int wx = 0; wx < plan_.nwx; ++wx) {
+                    const int wtx = tx * plan_.nwx + wx;
+                    if (wtx < wtiles_x && active[((size_t)z * wtiles_y + wty) * wtiles_x + wtx]) m |= 1u << (wy * plan_.nwx + wx);
+                }
+            }
+            return m;
+        };
+        std::vector<uint64_t> per_stripe((size_t)stripes, 0);
+        uint64_t total_active = 0, total = 0;
+        for (int z = z_begin_; z < z_end_; ++z)
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < plan_.tiles_x; ++tx) {
+                    const uint64_t on = (uint64_t)__builtin_popcount(wave_mask(z, ty, tx));
+                    per_stripe[(size_t)(ty / tys)] += on;
+                    total_active += on;
+                    total += (uint64_t)(plan_.nwx * plan_.nwy);
+                }
+        if (total_active * 100 >= total * 92 || stripes >= (1 << 16) || nz_ >= (1 << 20) ||
+            (int64_t)plan_.tiles_x * tys >= (1 << 20) || plan_.nwx * plan_.nwy > 8)
+            return WV_OK;  // (nearly) everything is room: the arithmetic mapping is as good
+
+        // heaviest stripe first onto the least loaded XCD
+        std::vector<int> order((size_t)stripes);
+        for (int i = 0; i < stripes; ++i) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return per_stripe[(size_t)a] > per_stripe[(size_t)b]; });
+        std::vector<std::vector<int>> mine(8);
+        uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int sidx : order) {
+            int best = 0;
+            for (int k = 1; k < 8; ++k)
+                if (load[k] < load[best]) best = k;
+            mine[(size_t)best].push_back(sidx);
+            load[best] += per_stripe[(size_t)sidx];
+        }
+        std::vector<uint64_t> list;
+        list.reserve((size_t)total_active / 2 + 16);
+        list_longest_ = 0;
+        for (int k = 0; k < 8; ++k) {
+            list_start_[k] = (uint32_t)list.size();
+            for (int sidx : mine[(size_t)k])
+                for (int z = z_begin_; z < z_end_; ++z)
+                    for (int tyl = 0; tyl < tys; ++tyl) {
+                        const int ty = sidx * tys + tyl;
+                        if (ty >= tiles_y) break;
+                        for (int tx = 0; tx < plan_.tiles_x; ++tx) {
+                            const uint32_t m = wave_mask(z, ty, tx);
+                            if (m)
+                                list.push_back(((uint64_t)sidx << 48) | ((uint64_t)m << 40) | ((uint64_t)z << 20) |
+                                               (uint64_t)(tyl * plan_.tiles_x + tx));
+                        }
+                    }
+            list_longest_ = std::max<uint32_t>(list_longest_, (uint32_t)list.size() - list_start_[k]);
+        }
+        list_start_[8] = (uint32_t)list.size();
+        if (list.empty()) return WV_OK;
+        WV_HIP(hipMalloc((void**)&tile_list_, list.size() * sizeof(uint64_t)));
+        WV_HIP(hipMemcpy(tile_list_, list.data(), list.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        return WV_OK;
+    }
+
     int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed) {
         if (z0 >= z1) return WV_OK;
         wv::StreamArgs<Real> a{};
@@ -457,6 +565,17 @@ public:
             a.tiles_y_stripe = plan_.tiles_y_stripe;
             a.passes = plan_.passes;
             grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+            // rooms that leave much of the mesh outside: visit only the tiles with something to
+            // update -- valid while the outside nodes hold zeros in both fields (outside_dirty_)
+            if (z0 == z_begin_ && z1 == z_end_ && outside_dirty_ == 0) {
+                int rc = build_tile_lists();
+                if (rc) return rc;
+                if (tile_list_) {
+                    a.tile_list = tile_list_;
+                    for (int k = 0; k < 9; ++k) a.list_start[k] = list_start_[k];
+                    grid = 8u * list_longest_;
+                }
+            }
         } else if (plan_.variant == 0) {
             a.zc = std::min(plan_.zc, z1 - z0);
             a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
@@ -568,6 +687,8 @@ public:
             if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) return rc;
         }
         WV_HIP(hipGetLastError());
+        // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
+        if (outside_dirty_ > 0 && outside_dirty_ < (1 << 30)) --outside_dirty_;
         return WV_OK;
     }
 
@@ -722,6 +843,15 @@ public:
     int write_value(int buffer_id, uint64_t index, double v) override {
         if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
         const Real tmp = (Real)v;
+        if (tmp != 0 && outside_dirty_ < 2) {
+            // a non-zero value in an outside node is zeroed by the next two full sweeps
+            const uint64_t x = index % (uint64_t)nx_, q = index / (uint64_t)nx_;
+            uint8_t byte = 0;
+            WV_HIP(hipMemcpyAsync(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
+                                  1, hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_NONE) outside_dirty_ = 2;
+        }
         WV_HIP(hipMemcpyAsync(buffer(buffer_id) + stored_index(index), &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
         return WV_OK;
@@ -762,6 +892,7 @@ public:
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
     int write_field(int buffer_id, const void* src, int elem_size) override {
+        outside_dirty_ = std::max(outside_dirty_, 2);  // the caller may have put anything in the outside nodes
         if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true);
         if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
@@ -807,6 +938,7 @@ public:
     }
 
     int device_buffer(int buffer_id, void** p) override {
+        outside_dirty_ = 1 << 30;  // raw access: stop assuming anything about the outside nodes
         *p = buffer(buffer_id);
         return WV_OK;
     }
@@ -848,7 +980,7 @@ private:
         events_.clear();
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
-        void* ptrs[] = {ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
+        void* ptrs[] = {tile_list_, ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
                         zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -867,6 +999,11 @@ private:
     int cls_pitch_ = 0;
     uint32_t n1_ = 0, n2_ = 0, n3_ = 0, n_entries_ = 0, n_slots_ = 0, n_coeffs_ = 0;
     uint32_t* bnode_ = nullptr;
+    uint64_t* tile_list_ = nullptr;   // sweep work list (build_tile_lists), null = arithmetic mapping
+    uint32_t list_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t list_longest_ = 0;
+    bool lists_built_ = false;
+    int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
     uint8_t* btype_ = nullptr;
     double* fmem_ = nullptr;

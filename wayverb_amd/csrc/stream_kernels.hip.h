@@ -332,13 +332,24 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
 
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
-    const int per_plane = a.tiles_x * a.tiles_y_stripe;
-    const int tl = j % per_plane;
-    j /= per_plane;
-    const int nzr = a.z_end - a.z_begin;
-    const int z = a.z_begin + j % nzr;
-    const int pass = j / nzr;
-    const int stripe = pass * 8 + xcd;
+    int tl, z, stripe;
+    if (a.tile_list) {
+        // only the tiles that hold a node this kernel updates (engine.hip, build_tile_lists)
+        const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
+        if ((uint32_t)j >= count) return;
+        const uint64_t e = a.tile_list[first + (uint32_t)j];
+        if (!((e >> 40) & (1u << wave))) return;  // nothing to update in this wave's rows
+        tl = (int)(e & 0xFFFFFu);
+        z = (int)((e >> 20) & 0xFFFFFu);
+        stripe = (int)(e >> 48);
+    } else {
+        const int per_plane = a.tiles_x * a.tiles_y_stripe;
+        tl = j % per_plane;
+        j /= per_plane;
+        const int nzr = a.z_end - a.z_begin;
+        z = a.z_begin + j % nzr;
+        stripe = (j / nzr) * 8 + xcd;
+    }
     const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
 
     const int y_lo = stripe * a.stripe_rows;

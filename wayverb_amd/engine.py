@@ -46,7 +46,7 @@ class WvMesh(C.Structure):
 class WvOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
-                ("stream_variant", C.c_int32), ("reserved_", C.c_int32 * 9)]
+                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("reserved_", C.c_int32 * 8)]
 
 
 class WaveguideError(RuntimeError):
@@ -241,7 +241,7 @@ class Engine:
     """One `run` worth of device state: the buffers of waveguide.h:43-76."""
 
     def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
-                 flag_interval=0, stream_variant=2):
+                 flag_interval=0, stream_variant=2, all_tiles=False):
         self.lib = load_library()
         self.mesh = mesh
         self.precision = precision
@@ -263,6 +263,7 @@ class Engine:
         opt.ghost_hi = int(ghost_hi)
         opt.flag_interval = flag_interval
         opt.stream_variant = stream_variant
+        opt.all_tiles = 1 if all_tiles else 0
         handle = C.c_void_p()
         _check(self.lib.wv_create(C.byref(wm), C.byref(opt), C.byref(handle)))
         self.h = handle
