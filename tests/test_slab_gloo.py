@@ -22,10 +22,10 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_exchange_matches_single_domain(world):
+@pytest.mark.parametrize("world,room", [(2, "box"), (3, "box"), (2, "blob"), (3, "L")])
+def test_slab_exchange_matches_single_domain(world, room):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
-               OMP_NUM_THREADS="1")
+               OMP_NUM_THREADS="1", WV_SLAB_ROOM=room)
     procs = []
     for rank in range(world):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
@@ -34,7 +34,7 @@ def test_slab_exchange_matches_single_domain(world):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
-    assert "SLAB_OK world=%d" % world in outs[0]
+    assert "SLAB_OK world=%d room=%s" % (world, room) in outs[0]
 
 
 def test_layout_covers_every_plane_once():
