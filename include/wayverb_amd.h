@@ -110,7 +110,10 @@ typedef struct wv_options {
      * that hold inside nodes (outside nodes are 0 and stay 0; wv_write_field / wv_write_value
      * re-enable the full sweep until they are 0 again).  1: always visit every tile. */
     int32_t all_tiles;
-    int32_t reserved_[8];
+    /* 1: wv_mesh::nodes is a device pointer on `device` (what wv_scene_mesh_create_engine passes);
+     * the boundary index and coefficient arrays are host arrays either way */
+    int32_t nodes_on_device;
+    int32_t reserved_[7];
 } wv_options;
 
 typedef struct wv_engine wv_engine;
@@ -264,6 +267,27 @@ int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const float min_c
                            const float* vertices, uint32_t n_vertices, uint32_t* b1, uint64_t capacity_1,
                            uint32_t* b2, uint64_t capacity_2, uint32_t* b3, uint64_t capacity_3,
                            uint64_t counts[3]);
+
+/* The same three stages chained on the device (compute_mesh, src/waveguide/src/mesh.cpp:54-141, as
+ * one unit): nothing but the scene goes up and nothing comes down unless asked for.
+ *   wv_scene_mesh_create         inside flags -> node types -> numbering -> surfaces per filter, all in
+ *                                HBM on `device` (-1 = current); counts[] = rows of the 1-D/2-D/3-D
+ *                                boundary arrays; "No boundaries." like the reference when one is 0
+ *   wv_scene_mesh_fetch          host copies (any pointer may be NULL): nodes [nx*ny*nz], b1 [c0][1],
+ *                                b2 [c1][2], b3 [c2][3] -- identical to the three-call path above
+ *   wv_scene_mesh_create_engine  wv_create on the device-resident nodes (options->device is
+ *                                overridden by the scene mesh's device)
+ */
+typedef struct wv_scene_mesh wv_scene_mesh;
+int wv_scene_mesh_create(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3], float spacing,
+                         const uint32_t* voxel_index, uint64_t n_voxel_words, const float aabb_min[3],
+                         const float aabb_max[3], uint32_t side, const uint32_t* triangles, uint32_t n_triangles,
+                         const float* vertices, uint32_t n_vertices, int32_t device, wv_scene_mesh** out,
+                         uint64_t counts[3]);
+int wv_scene_mesh_fetch(const wv_scene_mesh* sm, wv_condensed_node* nodes, uint32_t* b1, uint32_t* b2, uint32_t* b3);
+int wv_scene_mesh_create_engine(const wv_scene_mesh* sm, const wv_coefficients_canonical* coefficients,
+                                uint32_t num_coefficients, const wv_options* options, wv_engine** out);
+void wv_scene_mesh_destroy(wv_scene_mesh* sm);
 
 /* ---- boundary filter design, host side --------------------------------- */
 /* arbitrary_magnitude_filter<6> (src/waveguide/include/waveguide/arbitrary_magnitude_filter.h:63-95):

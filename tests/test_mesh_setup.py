@@ -447,3 +447,71 @@ def test_malformed_scenes_are_refused_before_any_device_work(built_library):
     nodes = np.zeros(dims[0] * dims[1] * dims[2], dtype=M.condensed_node_dtype)
     with pytest.raises(E.WaveguideError, match="missing vertex"):
         E.boundary_index_data(dims, aabb[0], 0.3, nodes, bad_t, v)
+
+
+# ---- the whole chain resident on the device ------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_scene_mesh_on_device_equals_the_staged_chain(oracle, built_library, name):
+    """wv_scene_mesh_create (one call, nothing leaves HBM) against the restatement of the three
+    stages: same nodes, same boundary arrays."""
+    from wayverb_amd import engine as E
+    v, t = _scenes()[name]
+    t = _multi_surface(t)
+    spacing = 0.09
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    sm = E.SceneMesh(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    nodes, b = sm.fetch()
+    mask = oracle.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v).astype(bool)
+    o_nodes, _ = oracle.classify(mask)
+    want = oracle.boundary_index_data(o_nodes, dims, aabb[0], spacing, t, v)
+    assert nodes.tobytes() == o_nodes.tobytes()
+    assert sm.counts == tuple(x.shape[0] for x in want)
+    for got, w in zip(b, want):
+        assert np.array_equal(got, w)
+    # and the staged GPU path gives the same thing
+    g_nodes, _ = E.classify_nodes(E.nodes_inside(dims, aabb[0], spacing, vox, aabb, 32, t, v))
+    gb = E.boundary_index_data(dims, aabb[0], spacing, g_nodes, t, v)
+    assert g_nodes.tobytes() == nodes.tobytes() and all(np.array_equal(x, y) for x, y in zip(gb, b))
+    sm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_engine_on_device_resident_nodes(oracle, built_library, tag, dtype):
+    """wv_scene_mesh_create_engine: the node array never visits the host, the run matches the
+    oracle stepping the fetched mesh."""
+    from wayverb_amd import engine as E
+    v, t = _scenes()["L"]
+    t = _multi_surface(t, 3)
+    spacing = 0.125
+    aabb, dims = _grid_for(v, spacing)
+    vox = E.voxelise(v, t, aabb, 32)
+    sm = E.SceneMesh(dims, aabb[0], spacing, vox, aabb, 32, t, v)
+    coeffs = np.zeros(3, dtype=M.coefficients_dtype)
+    coeffs[0] = M.flat_coefficients(0.05)
+    coeffs[1] = M.flat_coefficients(0.4)
+    coeffs[2] = M.passive_peak_filter_coefficients(np.random.default_rng(3), 1)[0]
+    nodes, b = sm.fetch()
+    mesh = M.Mesh(dims, nodes, coeffs, b[0], b[1], b[2], spacing=spacing)
+    inside = np.nonzero(nodes["boundary_type"] == M.ID_INSIDE)[0]
+    src, rcv = int(inside[len(inside) // 3]), int(inside[2 * len(inside) // 3])
+    steps = 120
+    sig = np.zeros(steps)
+    sig[0] = 1.0
+    eng = sm.engine(coeffs, precision=tag)
+    sm.close()                                   # the engine owns everything it needs
+    try:
+        done, trace = E.run_fast(eng, E.SOURCE_HARD, src, sig, [rcv])
+        cur = eng.read_field(E.BUF_CURRENT)
+        bd = [eng.read_boundary_data(d) for d in (1, 2, 3)]
+    finally:
+        eng.close()
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=src, signal=sig, recv=[rcv], init=None)
+    want = run_oracle(oracle, case, dtype, threads=4)
+    assert done == steps and want["flag"] == 0 and np.abs(want["trace"]).max() > 0
+    assert np.array_equal(trace.astype(dtype), want["trace"])
+    assert cur.tobytes() == want["current"].tobytes()
+    for a, w in zip(bd, want["bd"]):
+        assert a.tobytes() == w.tobytes()

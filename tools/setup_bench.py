@@ -41,6 +41,20 @@ def main():
     (nodes, counts), out["classify_gpu_s"] = timed(E.classify_nodes, mask)
     b, out["boundary_index_data_gpu_s"] = timed(E.boundary_index_data, dims, lo, spacing, nodes, t, v)
     out["boundary_nodes"] = [int(x.shape[0]) for x in b]
+    # the same chain resident on the device, and an engine built on it without a host round trip
+    from wayverb_amd import mesh as M
+    sm, out["scene_mesh_resident_gpu_s"] = timed(E.SceneMesh, dims, lo, spacing, vox, (lo, hi), 32, t, v)
+    coeffs = M.bench_materials()
+    eng, out["engine_from_resident_nodes_s"] = timed(sm.engine, np.concatenate([coeffs, coeffs[:1]]))
+    eng.close()
+    mesh = M.Mesh(dims, nodes, np.concatenate([coeffs, coeffs[:1]]), b[0], b[1], b[2])
+    eng, out["engine_from_host_nodes_s"] = timed(E.Engine, mesh)
+    eng.close()
+    if not args.no_cpu:
+        r_nodes, rb = sm.fetch()
+        out["resident_identical_to_staged"] = bool(r_nodes.tobytes() == nodes.tobytes()
+                                                   and all(np.array_equal(x, y) for x, y in zip(rb, b)))
+    sm.close()
     if not args.no_cpu:
         from oracle.oracle import Oracle
         o = Oracle()

@@ -225,6 +225,68 @@ struct DeviceArray {
 
 }  // namespace
 
+namespace wv {
+
+// The three finder kernels on arrays that already live on the device (stream-ordered).  lists[d] /
+// lens[d]: node indices of the 1-D-or-re-entrant, 2-D and 3-D nodes in node order; slot_of_entry:
+// row of out1 each entry of lists[0] writes; out1/out2/out3 zero-filled by the caller.
+// Shared with scene_mesh.hip.
+hipError_t boundary_surfaces_on_device(const wv_condensed_node* d_nodes, int nx, int ny, int nz,
+                                       const float min_corner[3], float spacing, const uint64_t* const lists[3],
+                                       const uint64_t lens[3], const uint32_t* d_slot_of_entry, const float* d_corners,
+                                       const uint32_t* d_surface, uint32_t n_triangles, uint32_t* d_out1,
+                                       uint32_t* d_out2, uint32_t* d_out3, hipStream_t stream) {
+    NearestArgs na{};
+    na.node_of_entry = lists[0];
+    na.slot_of_entry = d_slot_of_entry;
+    na.corners = d_corners;
+    na.surface = d_surface;
+    na.out1 = d_out1;
+    na.n_entries = lens[0];
+    na.n_triangles = n_triangles;
+    na.nx = nx;
+    na.ny = ny;
+    na.min_corner = {min_corner[0], min_corner[1], min_corner[2]};
+    na.spacing = spacing;
+    if (na.n_entries)
+        hipLaunchKernelGGL(nearest_surface_kernel, dim3((unsigned)((na.n_entries + kBlock - 1) / kBlock)), dim3(kBlock),
+                           0, stream, na);
+    GatherArgs ga{};
+    ga.nodes = d_nodes;
+    ga.out1 = d_out1;
+    ga.nx = nx;
+    ga.ny = ny;
+    ga.nz = nz;
+    ga.node_of_entry = lists[1];
+    ga.out = d_out2;
+    ga.n_entries = lens[1];
+    if (ga.n_entries)
+        hipLaunchKernelGGL(gather_surfaces_kernel<2>, dim3((unsigned)((ga.n_entries + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, stream, ga);
+    ga.node_of_entry = lists[2];
+    ga.out = d_out3;
+    ga.n_entries = lens[2];
+    if (ga.n_entries)
+        hipLaunchKernelGGL(gather_surfaces_kernel<3>, dim3((unsigned)((ga.n_entries + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, stream, ga);
+    return hipGetLastError();
+}
+
+// triangles {surface, v0, v1, v2} + cl_float3 vertices -> 9 corner floats + surface per triangle
+void pack_triangles(const uint32_t* triangles, uint32_t n_triangles, const float* vertices, std::vector<float>& corners,
+                    std::vector<uint32_t>& surface) {
+    corners.resize((size_t)n_triangles * 9);
+    surface.resize(n_triangles);
+    for (uint32_t t = 0; t < n_triangles; ++t) {
+        surface[t] = triangles[4 * (size_t)t];
+        for (int k = 0; k < 3; ++k)
+            for (int e = 0; e < 3; ++e)
+                corners[(size_t)t * 9 + k * 3 + e] = vertices[4 * (size_t)triangles[4 * (size_t)t + 1 + k] + e];
+    }
+}
+
+}  // namespace wv
+
 extern "C" int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3], float spacing,
                                       wv_condensed_node* nodes, const uint32_t* triangles, uint32_t n_triangles,
                                       const float* vertices, uint32_t n_vertices, uint32_t* b1, uint64_t capacity_1,
@@ -301,14 +363,9 @@ extern "C" int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const 
     if (capacity_1 < true_1d || capacity_2 < c[1] || capacity_3 < c[2] || !b1 || !b2 || !b3)
         return wv::fail_with(WV_E_INVALID_ARGUMENT, "boundary index arrays too small (see counts)");
 
-    std::vector<float> corners((size_t)n_triangles * 9);
-    std::vector<uint32_t> surface(n_triangles);
-    for (uint32_t t = 0; t < n_triangles; ++t) {
-        surface[t] = triangles[4 * (size_t)t];
-        for (int k = 0; k < 3; ++k)
-            for (int e = 0; e < 3; ++e)
-                corners[(size_t)t * 9 + k * 3 + e] = vertices[4 * (size_t)triangles[4 * (size_t)t + 1 + k] + e];
-    }
+    std::vector<float> corners;
+    std::vector<uint32_t> surface;
+    wv::pack_triangles(triangles, n_triangles, vertices, corners, surface);
 
     DeviceArray<wv_condensed_node> d_nodes;
     DeviceArray<uint64_t> d_list[3];
@@ -328,37 +385,10 @@ extern "C" int wv_boundary_index_data(int32_t nx, int32_t ny, int32_t nz, const 
     if (rc == hipSuccess) rc = hipMemset(d_out3.p, 0, (size_t)c[2] * 3 * sizeof(uint32_t));
     if (rc != hipSuccess) return wv::fail_with(WV_E_HIP, hipGetErrorString(rc));
 
-    NearestArgs na{};
-    na.node_of_entry = d_list[0].p;
-    na.slot_of_entry = d_slot1.p;
-    na.corners = d_corners.p;
-    na.surface = d_surface.p;
-    na.out1 = d_out1.p;
-    na.n_entries = list[0].size();
-    na.n_triangles = n_triangles;
-    na.nx = nx;
-    na.ny = ny;
-    na.min_corner = {min_corner[0], min_corner[1], min_corner[2]};
-    na.spacing = spacing;
-    hipLaunchKernelGGL(nearest_surface_kernel, dim3((unsigned)((na.n_entries + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       0, na);
-    GatherArgs ga{};
-    ga.nodes = d_nodes.p;
-    ga.out1 = d_out1.p;
-    ga.nx = nx;
-    ga.ny = ny;
-    ga.nz = nz;
-    ga.node_of_entry = d_list[1].p;
-    ga.out = d_out2.p;
-    ga.n_entries = list[1].size();
-    hipLaunchKernelGGL(gather_surfaces_kernel<2>, dim3((unsigned)((ga.n_entries + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, 0, ga);
-    ga.node_of_entry = d_list[2].p;
-    ga.out = d_out3.p;
-    ga.n_entries = list[2].size();
-    hipLaunchKernelGGL(gather_surfaces_kernel<3>, dim3((unsigned)((ga.n_entries + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, 0, ga);
-    rc = hipGetLastError();
+    const uint64_t* lists[3] = {d_list[0].p, d_list[1].p, d_list[2].p};
+    const uint64_t lens[3] = {list[0].size(), list[1].size(), list[2].size()};
+    rc = wv::boundary_surfaces_on_device(d_nodes.p, nx, ny, nz, min_corner, spacing, lists, lens, d_slot1.p, d_corners.p,
+                                         d_surface.p, n_triangles, d_out1.p, d_out2.p, d_out3.p, 0);
     std::vector<uint32_t> first(c[0]);
     if (rc == hipSuccess) rc = hipMemcpy(first.data(), d_out1.p, (size_t)c[0] * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (rc == hipSuccess) rc = hipMemcpy(b2, d_out2.p, (size_t)c[1] * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost);

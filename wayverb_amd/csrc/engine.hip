@@ -168,18 +168,22 @@ public:
         WV_HIP(hipMemsetAsync(status_, 0, 4 * sizeof(int), stream_));
         static_flag_dev_ = status_ + 1;
 
-        // nodes are staged through a bounded device buffer, whole x-rows at a time
+        // host nodes are staged through a bounded device buffer, whole x-rows at a time; nodes that
+        // already live on this device (wv_scene_mesh_create_engine) are classified where they are
         {
+            const bool resident = opt.nodes_on_device != 0;
             const int64_t rows_total = (int64_t)ny_ * nz_;
-            const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(32 << 20) / nx_);
+            const int64_t rows_per_chunk = resident ? rows_total : std::max<int64_t>(1, (int64_t)(32 << 20) / nx_);
             ScopedDevice stage_mem;
-            WV_HIP(hipMalloc(&stage_mem.p, (size_t)rows_per_chunk * nx_ * sizeof(wv::NodeRec)));
-            wv::NodeRec* stage = static_cast<wv::NodeRec*>(stage_mem.p);
+            if (!resident) WV_HIP(hipMalloc(&stage_mem.p, (size_t)rows_per_chunk * nx_ * sizeof(wv::NodeRec)));
+            const wv::NodeRec* stage = resident ? reinterpret_cast<const wv::NodeRec*>(m.nodes)
+                                                : static_cast<const wv::NodeRec*>(stage_mem.p);
             for (int64_t row = 0; row < rows_total; row += rows_per_chunk) {
                 const int64_t rows = std::min(rows_per_chunk, rows_total - row);
                 const int64_t first = row * nx_, cnt = rows * nx_;
-                WV_HIP(hipMemcpyAsync(stage, m.nodes + first, (size_t)cnt * sizeof(wv::NodeRec),
-                                      hipMemcpyHostToDevice, stream_));
+                if (!resident)
+                    WV_HIP(hipMemcpyAsync(stage_mem.p, m.nodes + first, (size_t)cnt * sizeof(wv::NodeRec),
+                                          hipMemcpyHostToDevice, stream_));
                 wv::SetupArgs a{};
                 a.nodes = stage;
                 a.first_row = row;

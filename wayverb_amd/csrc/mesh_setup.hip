@@ -14,6 +14,7 @@
 // neighbour flags come from the byte mask through L2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -82,7 +83,15 @@ __global__ void __launch_bounds__(256) node_boundary_type_kernel(const uint8_t* 
 
 namespace wv {
 int fail_with(int code, const std::string& msg);  // engine.hip
+
+// `set_node_boundary_type` on device arrays (stream-ordered); shared with scene_mesh.hip
+hipError_t node_types_on_device(const uint8_t* d_inside, int32_t* d_type, int nx, int ny, int nz, hipStream_t stream) {
+    const size_t n = (size_t)nx * ny * nz;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(node_boundary_type_kernel, dim3(grid), dim3(256), 0, stream, d_inside, d_type, nx, ny, nz);
+    return hipGetLastError();
 }
+}  // namespace wv
 
 extern "C" int wv_classify_nodes(int32_t nx, int32_t ny, int32_t nz, const uint8_t* inside, wv_condensed_node* nodes,
                                  uint64_t counts[3]) {

@@ -284,6 +284,54 @@ extern "C" int wv_voxelise(const float* vertices, uint32_t n_vertices, const uin
     return WV_OK;
 }
 
+namespace wv {
+
+// shared with scene_mesh.hip: the checks a scene must pass before a kernel follows its indices
+int validate_scene(const uint32_t* voxel_index, uint64_t n_voxel_words, uint32_t side, const uint32_t* triangles,
+                   uint32_t n_triangles, uint32_t n_vertices) {
+    for (uint32_t t = 0; t < n_triangles; ++t)
+        for (int k = 1; k < 4; ++k)
+            if (triangles[4 * (size_t)t + k] >= n_vertices)
+                return fail_with(WV_E_INVALID_ARGUMENT, "triangle refers to a missing vertex");
+    if (!voxel_index) return WV_OK;
+    if (n_voxel_words < (uint64_t)side * side * side) return fail_with(WV_E_INVALID_ARGUMENT, "voxel array too short");
+    for (uint64_t cell = 0, cells = (uint64_t)side * side * side; cell < cells; ++cell) {
+        const uint64_t off = voxel_index[cell];
+        if (off >= n_voxel_words || off + 1 + voxel_index[off] > n_voxel_words)
+            return fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list outside the array");
+        for (uint32_t k = 0; k < voxel_index[off]; ++k)
+            if (voxel_index[off + 1 + k] >= n_triangles)
+                return fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list refers to a missing triangle");
+    }
+    return WV_OK;
+}
+
+// `set_node_inside` on arrays that already live on the device (stream-ordered, no synchronisation)
+hipError_t nodes_inside_on_device(int nx, int ny, int nz, const float min_corner[3], float spacing,
+                                  const uint32_t* d_voxel_index, const float aabb_min[3], const float aabb_max[3],
+                                  uint32_t side, const uint32_t* d_triangles, const float* d_vertices, uint8_t* d_inside,
+                                  hipStream_t stream) {
+    InsideArgs a{};
+    a.inside = d_inside;
+    a.nx = nx;
+    a.ny = ny;
+    a.nz = nz;
+    a.min_corner = {min_corner[0], min_corner[1], min_corner[2]};
+    a.spacing = spacing;
+    a.voxel_index = d_voxel_index;
+    a.c0 = {aabb_min[0], aabb_min[1], aabb_min[2]};
+    a.c1 = {aabb_max[0], aabb_max[1], aabb_max[2]};
+    a.side = side;
+    a.triangles = d_triangles;
+    a.vertices = d_vertices;
+    const size_t n = (size_t)nx * ny * nz;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(node_inside_kernel, dim3(grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace wv
+
 // `set_node_inside` over all nodes of the mesh described by (nx, ny, nz, min_corner, spacing).
 extern "C" int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float min_corner[3], float spacing,
                                const uint32_t* voxel_index, uint64_t n_voxel_words, const float aabb_min[3],
@@ -293,50 +341,26 @@ extern "C" int wv_nodes_inside(int32_t nx, int32_t ny, int32_t nz, const float m
         !inside || side < 1 || n_voxel_words < (uint64_t)side * side * side)
         return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument");
     // the kernel follows these indices without checks: refuse a malformed scene here
-    for (uint32_t t = 0; t < n_triangles; ++t)
-        for (int k = 1; k < 4; ++k)
-            if (triangles[4 * (size_t)t + k] >= n_vertices)
-                return wv::fail_with(WV_E_INVALID_ARGUMENT, "triangle refers to a missing vertex");
-    for (uint64_t cell = 0, cells = (uint64_t)side * side * side; cell < cells; ++cell) {
-        const uint64_t off = voxel_index[cell];
-        if (off >= n_voxel_words || off + 1 + voxel_index[off] > n_voxel_words)
-            return wv::fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list outside the array");
-        for (uint32_t k = 0; k < voxel_index[off]; ++k)
-            if (voxel_index[off + 1 + k] >= n_triangles)
-                return wv::fail_with(WV_E_INVALID_ARGUMENT, "voxel array: list refers to a missing triangle");
-    }
+    if (int rc = wv::validate_scene(voxel_index, n_voxel_words, side, triangles, n_triangles, n_vertices)) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return wv::fail_with(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
     const size_t n = (size_t)nx * ny * nz;
-    InsideArgs a{};
+    uint8_t* d_inside = nullptr;
     uint32_t *d_vox = nullptr, *d_tri = nullptr;
     float* d_vert = nullptr;
-    hipError_t rc = hipMalloc((void**)&a.inside, n);
+    hipError_t rc = hipMalloc((void**)&d_inside, n);
     if (rc == hipSuccess) rc = hipMalloc((void**)&d_vox, n_voxel_words * sizeof(uint32_t));
     if (rc == hipSuccess) rc = hipMalloc((void**)&d_tri, (size_t)std::max(n_triangles, 1u) * 16);
     if (rc == hipSuccess) rc = hipMalloc((void**)&d_vert, (size_t)std::max(n_vertices, 1u) * 16);
     if (rc == hipSuccess) rc = hipMemcpy(d_vox, voxel_index, n_voxel_words * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (rc == hipSuccess && n_triangles) rc = hipMemcpy(d_tri, triangles, (size_t)n_triangles * 16, hipMemcpyHostToDevice);
     if (rc == hipSuccess && n_vertices) rc = hipMemcpy(d_vert, vertices, (size_t)n_vertices * 16, hipMemcpyHostToDevice);
-    if (rc == hipSuccess) {
-        a.nx = nx;
-        a.ny = ny;
-        a.nz = nz;
-        a.min_corner = {min_corner[0], min_corner[1], min_corner[2]};
-        a.spacing = spacing;
-        a.voxel_index = d_vox;
-        a.c0 = {aabb_min[0], aabb_min[1], aabb_min[2]};
-        a.c1 = {aabb_max[0], aabb_max[1], aabb_max[2]};
-        a.side = side;
-        a.triangles = d_tri;
-        a.vertices = d_vert;
-        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 65536);
-        hipLaunchKernelGGL(node_inside_kernel, dim3(grid), dim3(256), 0, 0, a);
-        rc = hipGetLastError();
-    }
-    if (rc == hipSuccess) rc = hipMemcpy(inside, a.inside, n, hipMemcpyDeviceToHost);
-    (void)hipFree(a.inside);
+    if (rc == hipSuccess)
+        rc = wv::nodes_inside_on_device(nx, ny, nz, min_corner, spacing, d_vox, aabb_min, aabb_max, side, d_tri, d_vert,
+                                        d_inside, 0);
+    if (rc == hipSuccess) rc = hipMemcpy(inside, d_inside, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_inside);
     (void)hipFree(d_vox);
     (void)hipFree(d_tri);
     (void)hipFree(d_vert);

@@ -31,7 +31,8 @@ EXPORTS = [
     "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
-    "wv_frequency_domain_filter", "wv_postprocess_waveguide",
+    "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
+    "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy",
 ]
 
 
@@ -46,7 +47,7 @@ class WvMesh(C.Structure):
 class WvOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
-                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("reserved_", C.c_int32 * 8)]
+                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("reserved_", C.c_int32 * 7)]
 
 
 class WaveguideError(RuntimeError):
@@ -416,3 +417,88 @@ def run_fast(engine, source_kind, source_node, signal, receivers, keep_going=lam
         if done == 0:
             break
     return done_total, engine.fetch_receivers(first, done_total)
+
+
+class _ResidentMesh:
+    """What Engine's buffer helpers need to know about a mesh whose nodes never came to the host."""
+
+    def __init__(self, dims, counts):
+        self.dims = dims
+        self.num_nodes = dims[0] * dims[1] * dims[2]
+        self.bidx = [np.broadcast_to(np.uint32(0), (counts[d], d + 1)) for d in range(3)]
+        self.nodes = None
+
+
+class SceneMesh:
+    """wv_scene_mesh: the scene -> mesh chain run on the device, results resident in HBM.
+    `fetch()` brings (nodes, [b1, b2, b3]) to the host; `engine()` builds an Engine on the
+    device-resident nodes without that round trip."""
+
+    def __init__(self, dims, min_corner, spacing, voxel_index, aabb, side, triangles, vertices, device=-1):
+        self.lib = load_library()
+        L = self.lib
+        L.wv_scene_mesh_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                           C.c_uint32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.wv_scene_mesh_fetch.argtypes = [C.c_void_p] * 5
+        L.wv_scene_mesh_create_engine.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(WvOptions),
+                                                  C.POINTER(C.c_void_p)]
+        L.wv_scene_mesh_destroy.argtypes = [C.c_void_p]
+        L.wv_scene_mesh_destroy.restype = None
+        self.dims = tuple(int(d) for d in dims)
+        nx, ny, nz = self.dims
+        v = np.ascontiguousarray(vertices, dtype=np.float32)
+        t = np.ascontiguousarray(triangles, dtype=np.uint32)
+        vox = np.ascontiguousarray(voxel_index, dtype=np.uint32)
+        mc = np.ascontiguousarray(min_corner, dtype=np.float32)
+        a0 = np.ascontiguousarray(aabb[0], dtype=np.float32)
+        a1 = np.ascontiguousarray(aabb[1], dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        counts = (C.c_uint64 * 3)()
+        h = C.c_void_p()
+        _check(L.wv_scene_mesh_create(nx, ny, nz, p(mc), float(spacing), p(vox), vox.shape[0], p(a0), p(a1), int(side),
+                                      p(t), t.shape[0], p(v), v.shape[0], int(device), C.byref(h), counts))
+        self.h = h
+        self.counts = tuple(int(c) for c in counts)
+        self.spacing = float(spacing)
+        self.min_corner = mc
+
+    def fetch(self, nodes=True):
+        nx, ny, nz = self.dims
+        n = np.zeros(nx * ny * nz, dtype=M.condensed_node_dtype) if nodes else None
+        b = [np.zeros((self.counts[d], d + 1), dtype=np.uint32) for d in range(3)]
+        _check(self.lib.wv_scene_mesh_fetch(self.h, n.ctypes.data_as(C.c_void_p) if nodes else None,
+                                            *[x.ctypes.data_as(C.c_void_p) for x in b]))
+        return n, b
+
+    def engine(self, coefficients, precision="f64", **kw):
+        """An Engine on the device-resident nodes.  Its .mesh holds no node array."""
+        coeffs = np.ascontiguousarray(coefficients, dtype=M.coefficients_dtype)
+        opt = WvOptions()
+        self.lib.wv_default_options(C.byref(opt))
+        opt.precision = PRECISION_F32 if precision == "f32" else PRECISION_F64
+        opt.flag_interval = kw.get("flag_interval", 0)
+        opt.stream_variant = kw.get("stream_variant", 2)
+        opt.all_tiles = 1 if kw.get("all_tiles", False) else 0
+        handle = C.c_void_p()
+        _check(self.lib.wv_scene_mesh_create_engine(self.h, coeffs.ctypes.data_as(C.c_void_p), coeffs.shape[0],
+                                                    C.byref(opt), C.byref(handle)))
+        eng = Engine.__new__(Engine)
+        eng.lib = self.lib
+        eng.mesh = _ResidentMesh(self.dims, self.counts)
+        eng.precision = precision
+        eng.dtype = np.float32 if precision == "f32" else np.float64
+        eng.h = handle
+        eng.n_recv = 0
+        return eng
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wv_scene_mesh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
