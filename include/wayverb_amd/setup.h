@@ -163,24 +163,20 @@ voxels_and_mesh compute_voxels_and_mesh(const Context& cc, const core::scene_dat
     const ivec3 dim{(int)((c1[0] - c0[0]) / mesh_spacing), (int)((c1[1] - c0[1]) / mesh_spacing),
                     (int)((c1[2] - c0[2]) / mesh_spacing)};  // mesh.cpp:65-71
     const size_t n = (size_t)dim.x * dim.y * dim.z;
-    std::vector<uint8_t> inside(n);
-    detail::check(wv_nodes_inside(dim.x, dim.y, dim.z, c0, mesh_spacing, voxels.data(), words, c0, c1, side, tris,
-                                  n_tris, verts, n_verts, inside.data()));
-    std::vector<condensed_node> nodes(n);
-    uint64_t first[3] = {0, 0, 0};
-    detail::check(wv_classify_nodes(dim.x, dim.y, dim.z, inside.data(), nodes.data(), first));
-    boundary_index_data bid;
-    bid.b1.resize(std::max<uint64_t>(first[0], 1));
-    bid.b2.resize(std::max<uint64_t>(first[1], 1));
-    bid.b3.resize(std::max<uint64_t>(first[2], 1));
+    // inside flags -> node types -> numbering -> surfaces per filter, chained on the device; the
+    // host copies below are what `mesh` (and through it `run`) hold, as in the reference
+    wv_scene_mesh* sm = nullptr;
     uint64_t counts[3] = {0, 0, 0};
-    if (wv_boundary_index_data(dim.x, dim.y, dim.z, c0, mesh_spacing, nodes.data(), tris, n_tris, verts, n_verts,
-                               &bid.b1[0].array[0], bid.b1.size(), &bid.b2[0].array[0], bid.b2.size(),
-                               &bid.b3[0].array[0], bid.b3.size(), counts) != WV_OK)
-        throw std::runtime_error{wv_last_error()};  // "No boundaries."
+    if (wv_scene_mesh_create(dim.x, dim.y, dim.z, c0, mesh_spacing, voxels.data(), words, c0, c1, side, tris, n_tris,
+                             verts, n_verts, detail::device_of(cc), &sm, counts) != WV_OK)
+        throw std::runtime_error{wv_last_error()};  // e.g. "No boundaries."
+    std::unique_ptr<wv_scene_mesh, void (*)(wv_scene_mesh*)> guard{sm, wv_scene_mesh_destroy};
+    std::vector<condensed_node> nodes(n);
+    boundary_index_data bid;
     bid.b1.resize(counts[0]);
     bid.b2.resize(counts[1]);
     bid.b3.resize(counts[2]);
+    detail::check(wv_scene_mesh_fetch(sm, nodes.data(), &bid.b1[0].array[0], &bid.b2[0].array[0], &bid.b3[0].array[0]));
 
     std::vector<coefficients_canonical> coefficients;  // mesh.cpp:126-138
     const double fs = 1 / config::time_step(speed_of_sound, mesh_spacing);

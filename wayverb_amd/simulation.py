@@ -89,9 +89,13 @@ def compute_voxels_and_mesh(vertices, triangles, surface_absorptions, anchor, sa
     side = 1 << octree_depth
     vox = E.voxelise(vertices, triangles, (c0, c1), side)
     dims = tuple(int(v) for v in ((c1 - c0) / spacing).astype(np.int32))     # mesh.cpp:65-71
-    mask = E.nodes_inside(dims, c0, float(spacing), vox, (c0, c1), side, triangles, vertices)
-    nodes, _ = E.classify_nodes(mask)
-    b = E.boundary_index_data(dims, c0, float(spacing), nodes, triangles, vertices)
+    # inside flags -> node types -> numbering -> surfaces per filter, chained in HBM (one call);
+    # the host copy is what the Mesh object and the source / receiver placement checks read
+    sm = E.SceneMesh(dims, c0, float(spacing), vox, (c0, c1), side, triangles, vertices)
+    try:
+        nodes, b = sm.fetch()
+    finally:
+        sm.close()
     n_surfaces = int(triangles[:, 0].max()) + 1
     absorptions = np.asarray(surface_absorptions, dtype=np.float64).reshape(-1, 8)
     if absorptions.shape[0] < n_surfaces:
