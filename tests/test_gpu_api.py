@@ -138,7 +138,8 @@ def test_exhausted_source_ends_the_run(built_library):
     eng.close()
 
 
-def test_rccl_halo_exchange_loopback_on_one_gpu(built_library):
+@pytest.mark.parametrize("pad_x", [0, 240])
+def test_rccl_halo_exchange_loopback_on_one_gpu(built_library, pad_x):
     """The RCCL path on real hardware, as far as one GPU allows: a communicator of one rank whose
     slab is its own neighbour on both sides (periodic in z).  Exercises dlopen'd RCCL, grouped
     ncclSend/ncclRecv on the halo stream, the faces-first / interior-overlapped step and its
@@ -148,6 +149,12 @@ def test_rccl_halo_exchange_loopback_on_one_gpu(built_library):
     rng = np.random.default_rng(8)
     nodes, counts = E.make_box_nodes(nx, ny, 64, z_begin=20, z_count=nz, number_from=21, number_to=20 + nz - 1)
     coeffs = M.passive_peak_filter_coefficients(rng, 1)
+    if pad_x:
+        # the same room in a mesh that is mostly outside: the slab's interior launch then walks
+        # work lists instead of every tile (boundary_index order is unchanged by padding rows)
+        wide = np.zeros((nz, ny, nx + pad_x), dtype=M.condensed_node_dtype)
+        wide[:, :, :nx] = nodes.reshape(nz, ny, nx)
+        nodes, nx = np.ascontiguousarray(wide.reshape(-1)), nx + pad_x
     mesh = M.Mesh((nx, ny, nz), nodes, coeffs, *[np.zeros((counts[d], d + 1), dtype=np.uint32) for d in range(3)])
     live = (mesh.nodes["boundary_type"] != 0)
     plane = nx * ny

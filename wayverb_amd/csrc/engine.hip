@@ -445,9 +445,11 @@ public:
     // boundary kernel.  Whole stripes are dealt to the 8 XCDs heaviest first (each XCD still
     // sweeps its stripes plane by plane, so the z reuse in its L2 is unchanged); a mesh that is
     // almost all room (a box) keeps the arithmetic mapping.
-    int build_tile_lists() {
+    int build_tile_lists(int z0, int z1) {
         if (lists_built_) return WV_OK;
         lists_built_ = true;
+        lists_z0_ = z0;
+        lists_z1_ = z1;
         if (tile_list_) {
             (void)hipFree(tile_list_);
             tile_list_ = nullptr;
@@ -496,7 +498,7 @@ public:
         };
         std::vector<uint64_t> per_stripe((size_t)stripes, 0);
         uint64_t total_active = 0, total = 0;
-        for (int z = z_begin_; z < z_end_; ++z)
+        for (int z = z0; z < z1; ++z)
             for (int ty = 0; ty < tiles_y; ++ty)
                 for (int tx = 0; tx < plan_.tiles_x; ++tx) {
                     const uint64_t on = (uint64_t)__builtin_popcount(wave_mask(z, ty, tx));
@@ -527,7 +529,7 @@ public:
         for (int k = 0; k < 8; ++k) {
             list_start_[k] = (uint32_t)list.size();
             for (int sidx : mine[(size_t)k])
-                for (int z = z_begin_; z < z_end_; ++z)
+                for (int z = z0; z < z1; ++z)
                     for (int tyl = 0; tyl < tys; ++tyl) {
                         const int ty = sidx * tys + tyl;
                         if (ty >= tiles_y) break;
@@ -571,10 +573,11 @@ public:
             grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
             // rooms that leave much of the mesh outside: visit only the tiles with something to
             // update -- valid while the outside nodes hold zeros in both fields (outside_dirty_)
-            if (z0 == z_begin_ && z1 == z_end_ && outside_dirty_ == 0) {
-                int rc = build_tile_lists();
+            // (built for the engine's big launch: all owned planes, or the interior planes of a slab)
+            if ((int64_t)(z1 - z0) * 2 > (int64_t)(z_end_ - z_begin_) && outside_dirty_ == 0) {
+                int rc = build_tile_lists(z0, z1);
                 if (rc) return rc;
-                if (tile_list_) {
+                if (tile_list_ && z0 == lists_z0_ && z1 == lists_z1_) {
                     a.tile_list = tile_list_;
                     for (int k = 0; k < 9; ++k) a.list_start[k] = list_start_[k];
                     grid = 8u * list_longest_;
@@ -1007,6 +1010,7 @@ private:
     uint32_t list_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t list_longest_ = 0;
     bool lists_built_ = false;
+    int lists_z0_ = 0, lists_z1_ = 0;  // plane range the lists were built for
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
     uint8_t* btype_ = nullptr;
