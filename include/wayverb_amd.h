@@ -105,7 +105,8 @@ typedef struct wv_options {
     /* the error flag is brought to the host every `flag_interval` steps of wv_run
      * (1 = after every step, like waveguide.h:100-101; 0 = once per wv_run call) */
     int32_t flag_interval;
-    int32_t stream_variant; /* 2 = plane sweep (default), 0 = register z-march, 1 = naive */
+    int32_t stream_variant; /* 2 = plane sweep, y halos through LDS (default); kept for measurement:
+                             * 3 = plane sweep without LDS, 0 = register z-march, 1 = naive */
     /* 0 (default): when a room leaves part of the mesh outside, the sweep visits only the tiles
      * that hold inside nodes (outside nodes are 0 and stay 0; wv_write_field / wv_write_value
      * re-enable the full sweep until they are 0 again).  1: always visit every tile. */

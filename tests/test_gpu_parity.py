@@ -51,7 +51,7 @@ def test_engine_matches_golden(name, tag):
 
 VARIANTS = [dict(WV_STREAM_VARIANT=1)] + \
     [dict(WV_STREAM_VARIANT=v, WV_STREAM_RY=ry, WV_STREAM_NWX=nwx, WV_STREAM_NWY=nwy, WV_STREAM_ZCHUNKS=knob)
-     for v in (0, 2)
+     for v in (0, 2, 3)
      for ry, nwx, nwy, knob in ((2, 1, 1, 1), (2, 1, 4, 3), (4, 2, 2, 5), (4, 1, 4, 0), (2, 8, 1, 2), (4, 4, 2, 28),
                                 (2, 4, 1, 8), (4, 1, 1, 16))]
 

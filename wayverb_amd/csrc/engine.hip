@@ -324,7 +324,7 @@ public:
 
     // -------------------------------------------------------------------------------------------
     int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) override {
-        if (variant < 0 || variant > 2) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
+        if (variant < 0 || variant > 3) return fail(WV_E_INVALID_ARGUMENT, "unknown stream variant");
         tune_variant_ = variant;
         tune_ry_ = ry;
         tune_nwx_ = nwx;
@@ -362,15 +362,16 @@ public:
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
         p.variant = tune_variant_ >= 0 ? tune_variant_ : env_int("WV_STREAM_VARIANT", opt_.stream_variant);
-        if (p.variant < 0 || p.variant > 2) p.variant = 2;
+        if (p.variant < 0 || p.variant > 3) p.variant = 2;
         p.ry = tune_ry_ > 0 ? tune_ry_ : env_int("WV_STREAM_RY", 4);
-        // measured best shapes (profiles/r01/sweep_engine_*): fp64 1x4 waves, fp32 4x2
-        p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", sizeof(Real) == 4 ? 4 : 1);
-        p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", sizeof(Real) == 4 ? 2 : 4);
+        // measured best shape (profiles/r01/variant_scan_*): 1 x 4 waves (a 4-wave column shares its
+        // y halos through LDS) in both precisions
+        p.nwx = tune_nwx_ > 0 ? tune_nwx_ : env_int("WV_STREAM_NWX", 1);
+        p.nwy = tune_nwy_ > 0 ? tune_nwy_ : env_int("WV_STREAM_NWY", 4);
         if (p.ry != 2 && p.ry != 4) p.ry = 4;
         {
             const int key = p.nwx * 10 + p.nwy;
-            const int ok[] = {11, 14, 22, 41, 42, 81};
+            const int ok[] = {11, 14, 18, 22, 24, 41, 42, 81};
             bool found = false;
             for (int k : ok) found = found || k == key;
             if (!found) {
@@ -383,7 +384,7 @@ public:
         p.block = 64u * (unsigned)(p.nwx * p.nwy);
         const int owned = z_end_ - z_begin_;
         const int64_t knob = tune_zchunks_ > 0 ? tune_zchunks_ : env_int("WV_STREAM_ZCHUNKS", 0);
-        if (p.variant == 2) {
+        if (p.variant == 2 || p.variant == 3) {
             // stripe height: three `cur` planes of a stripe should sit comfortably in one XCD's
             // 4 MiB L2 (measured best at 0.75-1.5 MiB), at least 8 stripes so every XCD has one
             const int tile_rows = p.ry * p.nwy;
@@ -422,6 +423,9 @@ public:
         if (plan_.variant == 2) {
             hipLaunchKernelGGL((wv::stream_sweep_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
                                stream_, a);
+        } else if (plan_.variant == 3) {
+            hipLaunchKernelGGL((wv::stream_sweep_nolds_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                               stream_, a);
         } else {
             hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
                                stream_, a);
@@ -435,6 +439,8 @@ public:
             case 41: launch_shape<RY, 4, 1>(a, grid); break;
             case 42: launch_shape<RY, 4, 2>(a, grid); break;
             case 81: launch_shape<RY, 8, 1>(a, grid); break;
+            case 18: launch_shape<RY, 1, 8>(a, grid); break;
+            case 24: launch_shape<RY, 2, 4>(a, grid); break;
             default: launch_shape<RY, 1, 4>(a, grid); break;
         }
     }
@@ -454,7 +460,7 @@ public:
             (void)hipFree(tile_list_);
             tile_list_ = nullptr;
         }
-        if (plan_.variant != 2 || env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0) return WV_OK;
+        if ((plan_.variant != 2 && plan_.variant != 3) || env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0) return WV_OK;
         // activity per wave tile (ry rows x one wave of columns); a workgroup tile is nwy x nwx of them
         const int wave_cols = 64 * (16 / (int)sizeof(Real));
         const int wtiles_x = plan_.tiles_x * plan_.nwx;
@@ -566,7 +572,7 @@ public:
         a.tiles_x = plan_.tiles_x;
         a.tiles_y = plan_.tiles_y;
         unsigned grid = plan_.grid;
-        if (plan_.variant == 2) {
+        if (plan_.variant == 2 || plan_.variant == 3) {
             a.stripe_rows = plan_.stripe_rows;
             a.tiles_y_stripe = plan_.tiles_y_stripe;
             a.passes = plan_.passes;

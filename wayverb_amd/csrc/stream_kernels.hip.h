@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 2 ("sweep", the default): plane sweep with L2-resident z-reuse.
+// Variant 3 ("sweep without LDS", kept as a cross-check of variant 2): plane sweep with L2-resident
+// z-reuse; every wave loads its own halo rows.  The structure below is shared by variant 2.
 //
 // Measured on MI355X (tools/stream_bench.hip, profiles/): HBM delivers ~6.5 TB/s to short-lived
 // workgroups that are dispatched in address order (the chip-wide set of in-flight addresses is
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
 constexpr int X_SWEEP = X_NT_STORE | X_NT_PREV | X_STORE_ALL;
 
 template <typename Real, int RY, int NWX, int NWY, int X = X_SWEEP>
-__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
+__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_nolds_kernel(const StreamArgs<Real> a) {
     using V = typename Vec16<Real>::type;
     constexpr int WX = TileIO<Real>::WX;
     constexpr bool NTP = (X & X_NT_PREV) != 0;
@@ -386,6 +387,112 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
             bool skip = false;
             const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r],
                                               bad, skip);
+            store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
+        }
+    }
+    if (__any(bad != 0)) {
+        if (bad) atomicOr(a.flag, bad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2, the product kernel: the sweep above with the y halos of plane z staged through LDS.
+//
+// A wave needs rows y0-1 and y0+RY of the middle plane besides its own RY rows.  In the kernel
+// above it loads them (L2 hits: the neighbouring wave of the same workgroup loads the same rows as
+// its own).  Here every wave publishes its first and last row in LDS, one barrier, and the
+// neighbours pick them up: global loads of the middle plane drop from RY+2 to RY rows per wave
+// (only the workgroup's outer halo rows still come from L2).  Measured at 1024^3 fp64: 4.38 ->
+// 4.15 ms (73.5 -> 77.6 % of the HBM peak): the sweep is limited by the request rate into
+// L2 / the fabric, not by DRAM, so every load that does not have to be issued counts.
+//
+// With a work list (rooms that leave part of the mesh outside) whole workgroups are skipped by
+// the list and single waves by the entry's wave mask; a skipped wave publishes nothing, so its
+// neighbours load that halo row themselves.
+// ---------------------------------------------------------------------------------------------
+template <typename Real, int RY, int NWX, int NWY>
+__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
+    using V = typename Vec16<Real>::type;
+    constexpr int WX = TileIO<Real>::WX;
+    constexpr int X = X_SWEEP;
+    __shared__ V halo[NWY][NWX][2][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wx = wave % NWX, wy = wave / NWX;
+
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    int tl, z, stripe;
+    uint32_t mask = ~0u;  // which waves of this workgroup have something to update
+    if (a.tile_list) {
+        const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
+        if ((uint32_t)j >= count) return;  // the whole workgroup leaves together
+        const uint64_t e = a.tile_list[first + (uint32_t)j];
+        mask = (uint32_t)(e >> 40) & 0xFFu;
+        tl = (int)(e & 0xFFFFFu);
+        z = (int)((e >> 20) & 0xFFFFFu);
+        stripe = (int)(e >> 48);
+    } else {
+        const int per_plane = a.tiles_x * a.tiles_y_stripe;
+        tl = j % per_plane;
+        j /= per_plane;
+        const int nzr = a.z_end - a.z_begin;
+        z = a.z_begin + j % nzr;
+        stripe = (j / nzr) * 8 + xcd;
+    }
+    const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
+
+    const int y_lo = stripe * a.stripe_rows;
+    const int y_hi = min(y_lo + a.stripe_rows, a.ny);
+    const int x0 = (tx * NWX + wx) * WX;
+    const int y0 = y_lo + (tyl * NWY + wy) * RY;
+    auto row_wave_active = [&](int wyy) {  // wave (wx, wyy) of this workgroup: inside the stripe and not masked out
+        return y_lo + (tyl * NWY + wyy) * RY < y_hi && ((mask >> (wyy * NWX + wx)) & 1u);
+    };
+    const bool active = x0 < a.pitch && row_wave_active(wy);  // idle waves still meet the barrier
+    const bool from_lo = wy > 0 && row_wave_active(wy - 1);      // row y0-1 is wave wy-1's last row
+    const bool from_hi = wy + 1 < NWY && row_wave_active(wy + 1);  // row y0+RY is wave wy+1's first row
+
+    const TileIO<Real> io(a, lane, min(x0, a.pitch - WX));
+    V below[RY], mid[RY + 2], above[RY], pv[RY];
+    uint32_t cl[RY];
+    Real mid_e = 0;
+    if (active) {
+        // ---- everything this tile needs from memory, issued back to back
+        // (the rows that go through LDS first: they are needed before the barrier)
+#pragma unroll
+        for (int r = 0; r < RY; ++r) mid[r + 1] = io.template cur_row<false>(y0 + r, z);  // L2: was z+1 a plane ago
+        if (!from_lo) mid[0] = io.template cur_row<false>(y0 - 1, z);
+        if (!from_hi) mid[RY + 1] = io.template cur_row<false>(y0 + RY, z);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) above[r] = io.template cur_row<false>(y0 + r, z + 1);  // first touch: HBM
+        static_assert(RY <= 4 && 4 % RY == 0, "a tile's rows must sit inside one class-map row group");
+        const uint32_t clw = io.cls_word(y0, z);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool live = y0 + r < y_hi;
+            pv[r] = live ? io.template prev_row<true>(y0 + r, z) : (V)(Real(0));
+            cl[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
+        }
+        mid_e = io.template edges<RY>(y0, z);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) below[r] = io.template cur_row<false>(y0 + r, z - 1);  // L2: last use
+        halo[wy][wx][0][lane] = mid[1];
+        halo[wy][wx][1][lane] = mid[RY];
+    }
+    __syncthreads();
+    if (!active) return;
+    if (from_lo) mid[0] = halo[wy - 1][wx][1][lane];
+    if (from_hi) mid[RY + 1] = halo[wy + 1][wx][0][lane];
+
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        if (y0 + r < y_hi) {
+            bool skip = false;
+            const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r], bad,
+                                              skip);
             store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
         }
     }
