@@ -36,6 +36,9 @@ python bench.py > gpurun_out/$R/bench_n1.json 2> gpurun_out/$R/bench_n1.err; tai
 python bench.py --precision f32 --no-cpu-baseline --no-small > gpurun_out/$R/bench_n1_f32.json 2>/dev/null
 python bench.py --nx 256 --ny 256 --nz 256 --no-cpu-baseline --no-small --steps 10000 --warmup 500 > gpurun_out/$R/bench_256cubed_10k_steps.json 2>/dev/null; tail -1 gpurun_out/$R/bench_256cubed_10k_steps.json | cut -c1-200
 python bench.py --nx 1000 --ny 1000 --nz 1000 --no-cpu-baseline --no-small > gpurun_out/$R/bench_1000cubed.json 2>/dev/null
-python tools/sweep_stream.py --steps 10 --out gpurun_out/$R/sweep_engine_1024_f64.json > /dev/null 2>&1
+
 python tools/setup_bench.py --n 768 > gpurun_out/$R/setup_bench_768.json 2>/dev/null
+python tools/variant_scan.py 1024 f64 2>/dev/null | grep variant > gpurun_out/$R/variant_scan_f64.txt
+python tools/variant_scan.py 1024 f32 2>/dev/null | grep variant > gpurun_out/$R/variant_scan_f32.txt
+{ python tools/room_bench.py 768 2>/dev/null | tail -2; WV_TILE_LISTS=0 python tools/room_bench.py 768 2>/dev/null | tail -1; } > gpurun_out/$R/room_bench_sphere_768.txt
 ls gpurun_out/$R
