@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64) filter_test_2_kernel(const float* input, f
 }
 
 template <typename Real, int D>
-__device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint32_t k, uint32_t entry,
+__device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t k, uint32_t entry,
                                               uint32_t slot_base, uint32_t n_d, int& bad) {
     const uint32_t idx = a.bnode[entry];
     if (idx == INVALID_NODE) return;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint3
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         slot[i] = slot_base + (uint32_t)i * n_d + k;
-        cf[i] = a.coeffs + (size_t)a.cidx[slot[i]] * 14;
+        cf[i] = coeffs + (size_t)a.cidx[slot[i]] * 14;
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = a.fmem[(size_t)j * a.n_slots + slot[i]];
     }
@@ -152,24 +152,35 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, uint3
 
 // entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
 template <typename Real>
-__device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, uint32_t e, int& bad) {
+__device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t e, int& bad) {
     if (e < a.n1) {
-        boundary_node<Real, 1>(a, e, e, 0u, a.n1, bad);
+        boundary_node<Real, 1>(a, coeffs, e, e, 0u, a.n1, bad);
     } else if (e < a.n1 + a.n2) {
-        boundary_node<Real, 2>(a, e - a.n1, e, a.n1, a.n2, bad);
+        boundary_node<Real, 2>(a, coeffs, e - a.n1, e, a.n1, a.n2, bad);
     } else if (e < a.n1 + a.n2 + a.n3) {
-        boundary_node<Real, 3>(a, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
+        boundary_node<Real, 3>(a, coeffs, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
     }
 }
 
-template <typename Real>
+// LDSC: the coefficient table (14 doubles per surface) is staged in LDS by the workgroup first --
+// a lane reads 14 coefficients per filter and step, which are 14 requests into L1/L2 when they
+// come from global memory and none when they come from LDS (scenes have a handful of materials).
+constexpr uint32_t kMaxLdsCoefficientSets = 256;  // 28 KiB
+
+template <typename Real, bool LDSC>
 __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a) {
+    __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
+    if (LDSC) {
+        for (uint32_t w = threadIdx.x; w < a.n_coeffs * 14u; w += 256) s_coeffs[w] = a.coeffs[w];
+        __syncthreads();
+    }
+    const double* coeffs = LDSC ? s_coeffs : a.coeffs;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     int bad = 0;
     if (a.order) {
-        if (t < a.n_order) boundary_entry<Real>(a, a.order[t], bad);
+        if (t < a.n_order) boundary_entry<Real>(a, coeffs, a.order[t], bad);
     } else {
-        boundary_entry<Real>(a, t, bad);
+        boundary_entry<Real>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
 }

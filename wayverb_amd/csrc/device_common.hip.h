@@ -93,6 +93,7 @@ struct BoundaryArgs {
     double* fmem;            // [6][n_slots] filter memories, structure-of-arrays
     const uint32_t* cidx;    // [n_slots] coefficient (surface) index per filter
     const double* coeffs;    // [n_coeffs][14] = {b[7], a[7]}
+    uint32_t n_coeffs;
     uint32_t n1, n2, n3;     // entries per dimensionality; entry order: all 1D, all 2D, all 3D
     uint32_t n_slots;        // n1 + 2 n2 + 3 n3
     int nx, ny, nz;

@@ -622,6 +622,7 @@ public:
         b.fmem = fmem_;
         b.cidx = cidx_;
         b.coeffs = coeffs_;
+        b.n_coeffs = n_coeffs_;
         b.n1 = n1_;
         b.n2 = n2_;
         b.n3 = n3_;
@@ -651,7 +652,10 @@ public:
             n = b.n_order;
             if (!n) return WV_OK;
         }
-        hipLaunchKernelGGL(wv::boundary_kernel<Real>, dim3((n + 255) / 256), dim3(256), 0, stream_, b);
+        if (n_coeffs_ <= wv::kMaxLdsCoefficientSets && env_int("WV_BOUNDARY_LDS", 1) != 0)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, b);
+        else
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, b);
         return WV_OK;
     }
 
