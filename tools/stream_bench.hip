@@ -246,7 +246,7 @@ static void run_sweep(Ctx& c, const char* name, int stripe_rows) {
         wv::StreamArgs<double> b = a;
         b.prev = prev;
         b.cur = cur;
-        hipLaunchKernelGGL((wv::stream_sweep_kernel<double, RY, NWX, NWY, X>), dim3(grid), dim3(64 * NWX * NWY), 0, c.s, b);
+        hipLaunchKernelGGL((wv::stream_sweep_nolds_kernel<double, RY, NWX, NWY, X>), dim3(grid), dim3(64 * NWX * NWY), 0, c.s, b);
     });
     const double bytes = 24.0 * c.nx * c.ny * c.nz;
     printf("{\"kernel\": \"sweep\", \"name\": \"%s\", \"ry\": %d, \"nwx\": %d, \"nwy\": %d, \"x\": %d, \"stripe_rows\": %d, \"ms\": %.4f, \"alg_gbs\": %.1f}\n",
