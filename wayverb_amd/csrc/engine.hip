@@ -248,7 +248,7 @@ public:
             WV_HIP(hipMemcpy(btype.data(), btype_, (size_t)n_entries_, hipMemcpyDeviceToHost));
             const uint32_t nd[3] = {n1_, n2_, n3_};
             const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
-            std::vector<uint64_t> key(n_entries_);
+            std::vector<std::pair<uint64_t, uint32_t>> keyed(n_entries_);  // (sort key, entry): ties keep list order
             std::vector<uint32_t> by_pos(n_entries_);
             uint32_t off = 0;
             for (int d = 0; d < 3; ++d) {
@@ -261,11 +261,10 @@ public:
                         const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
                         kk = (brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63);
                     }
-                    key[off + k] = kk;
-                    by_pos[off + k] = off + k;
+                    keyed[off + k] = {kk, off + k};
                 }
-                std::sort(by_pos.begin() + off, by_pos.begin() + off + nd[d],
-                          [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+                std::sort(keyed.begin() + off, keyed.begin() + off + nd[d]);
+                for (uint32_t k = 0; k < nd[d]; ++k) by_pos[off + k] = keyed[off + k].second;
                 off += nd[d];
             }
             std::vector<uint32_t> bnode2(n_entries_);
