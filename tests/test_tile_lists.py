@@ -106,3 +106,20 @@ def test_write_value_into_an_outside_node_mid_run(oracle, built_library):
     case = dict(mesh=mesh, steps=13, source_kind=1, source_node=src, signal=sig[:13], recv=[src], init=None)
     want = run_oracle(oracle, case, np.float64, threads=2)
     assert got.tobytes() == want["current"].tobytes()
+
+
+def test_source_in_an_outside_node(oracle, built_library):
+    """Degenerate but legal: a hard source sitting in an outside node.  The reference keeps zeroing
+    that node's `previous`; the engine must not leave stale samples there."""
+    mask = np.zeros((12, 36, 140), dtype=bool)
+    mask[2:10, 3:30, 5:60] = True
+    mesh = _mesh(mask, built_library)
+    node = mesh.compute_index(120, 20, 6)
+    steps = 7
+    sig = np.arange(1, steps + 1, dtype=np.float64)
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=node, signal=sig, recv=[node], init=None)
+    want = run_oracle(oracle, case, np.float64, threads=2)
+    got = run_engine(case, "f64")
+    assert np.array_equal(got["trace"], want["trace"])
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()

@@ -802,6 +802,14 @@ public:
         if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
         if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
         source_node_ = stored_index(node);
+        {
+            // a source in an outside node keeps writing non-zero values there: no work lists then
+            const uint64_t x = node % (uint64_t)nx_, q = node / (uint64_t)nx_;
+            uint8_t byte = 0;
+            WV_HIP(hipMemcpy(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
+                             1, hipMemcpyDeviceToHost));
+            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_NONE) outside_dirty_ = 1 << 30;
+        }
         signal_len_ = n;
         WV_HIP(hipMalloc((void**)&signal_, std::max<uint64_t>(n, 1) * sizeof(double)));
         if (n) WV_HIP(hipMemcpy(signal_, signal, n * sizeof(double), hipMemcpyHostToDevice));
