@@ -167,8 +167,14 @@ __device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, cons
 // come from global memory and none when they come from LDS (scenes have a handful of materials).
 constexpr uint32_t kMaxLdsCoefficientSets = 256;  // 28 KiB
 
+template <typename Real>
+__device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32_t t, uint32_t width);  // below
+
+// `next`: when next.flag is non-null the last workgroup also does the NEXT step's source injection /
+// receiver gather (on `prev`, which is that step's `current`).  Only legal when none of those nodes
+// is a boundary node -- then they were final when the sweep before this launch ended (engine.hip).
 template <typename Real, bool LDSC>
-__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a) {
+__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
         for (uint32_t w = threadIdx.x; w < a.n_coeffs * 14u; w += 256) s_coeffs[w] = a.coeffs[w];
@@ -183,15 +189,16 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
         boundary_entry<Real>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
+    if (next.flag && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
 }
 
 // ---- source injection + receiver gather: the pre/post callbacks, device resident -------------
 // hard source:  current[node] = sample              (preprocessor/hard_source.h:21)
 // soft source:  current[node] = current[node] + s   (preprocessor/soft_source.h:21-24)
 // receivers read the same `current` afterwards      (waveguide.h:121)
+// every thread of the workgroup calls this; `width` threads share the receivers
 template <typename Real>
-__global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a) {
-    const uint32_t t = threadIdx.x;
+__device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32_t t, uint32_t width) {
     if (t == 0) *a.flag = a.flag_init;  // waveguide.h:82 (write_value(error_flag, id_success)) + static bits
     Real injected = 0;
     const bool has_source = a.source_kind != 0;
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a)
         const Real s = (Real)a.signal[a.signal_pos];
         injected = (a.source_kind == 1) ? s : (Real)(a.cur[a.source_node] + s);
     }
-    for (uint32_t r = t; r < a.n_recv; r += 64) {
+    for (uint32_t r = t; r < a.n_recv; r += width) {
         const uint64_t node = a.recv[r];
         Real v = 0;
         if (node != ~0ull) v = (has_source && node == a.source_node) ? injected : a.cur[node];
@@ -207,6 +214,11 @@ __global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a)
     }
     __syncthreads();
     if (t == 0 && has_source) a.cur[a.source_node] = injected;
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(64) pre_post_kernel(const PrePostArgs<Real> a) {
+    pre_post_body<Real>(a, threadIdx.x, 64);
 }
 
 // ---- set-up (once per wv_create) ---------------------------------------------------------------

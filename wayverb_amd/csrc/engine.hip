@@ -639,9 +639,12 @@ public:
 
     // Boundary nodes of planes [z0, z1).  MUST be enqueued after the streaming launch that covers
     // those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
-    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1) {
+    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1,
+                        const wv::PrePostArgs<Real>* next = nullptr) {
         if (!n_entries_ || z0 >= z1) return WV_OK;
         wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
+        wv::PrePostArgs<Real> nx{};  // flag == nullptr: nothing fused
+        if (next) nx = *next;
         uint32_t n = n_entries_;
         if (z0 > z_begin_ || z1 < z_end_) {
             const int rc = build_plane_order();
@@ -652,14 +655,35 @@ public:
             if (!n) return WV_OK;
         }
         if (n_coeffs_ <= wv::kMaxLdsCoefficientSets && env_int("WV_BOUNDARY_LDS", 1) != 0)
-            hipLaunchKernelGGL((wv::boundary_kernel<Real, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, b);
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, b, nx);
         else
-            hipLaunchKernelGGL((wv::boundary_kernel<Real, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, b);
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, b, nx);
         return WV_OK;
     }
 
     // One loop body: [pre/post on device] + pressure update + boundary update; flag -> flags_[slot]
-    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) {
+    // reset a step's flag word to the mesh-static bits (setup_validate_kernel), inject the source
+    // sample into `cur`, gather the receivers from it
+    wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const {
+        const bool io = with_pre_post && (n_recv_ || source_live);
+        wv::PrePostArgs<Real> pp{};
+        pp.cur = cur;
+        pp.signal = signal_;
+        pp.signal_pos = signal_pos;
+        pp.source_node = source_node_;
+        pp.source_kind = io && source_live ? source_kind_ : 0;
+        pp.recv = recv_nodes_;
+        pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
+        pp.n_recv = io ? n_recv_ : 0;
+        pp.flag = flags_ + slot;
+        pp.flag_init = static_flag_;
+        return pp;
+    }
+
+    // `fuse_next`: the step after this one (slot + 1, same batch) gets its pre/post work done by
+    // this step's boundary launch instead of a launch of its own -- one launch less per step,
+    // which is what small meshes are bound by.
+    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, bool fuse_next = false) {
         Real* prev = field_[cur_ ^ 1];
         Real* cur = field_[cur_];
         int* flag = flags_ + slot;
@@ -667,23 +691,11 @@ public:
         std::string cerr;
         // ghost planes of `cur` come from the exchange issued at the end of the previous step
         if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-        {
-            // one small launch: reset this step's flag word to the mesh-static bits
-            // (setup_validate_kernel), inject the source sample, gather the receivers
-            const bool io = with_pre_post && (n_recv_ || source_live);
-            wv::PrePostArgs<Real> pp{};
-            pp.cur = cur;
-            pp.signal = signal_;
-            pp.signal_pos = signal_pos;
-            pp.source_node = source_node_;
-            pp.source_kind = io && source_live ? source_kind_ : 0;
-            pp.recv = recv_nodes_;
-            pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
-            pp.n_recv = io ? n_recv_ : 0;
-            pp.flag = flag;
-            pp.flag_init = static_flag_;
+        if (!pre_post_done_) {
+            const wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
+        pre_post_done_ = false;
         // Order on the one compute stream: a plane's sweep, then that plane's boundary nodes.
         if (comm_) {
             // slab faces first, so that their exchange overlaps the interior update
@@ -700,7 +712,14 @@ public:
             if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
         } else {
             if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
-            if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) return rc;
+            if (fuse_next && n_entries_) {
+                // the next step's `current` is this step's `prev`
+                const wv::PrePostArgs<Real> nx = pre_post_args(prev, slot + 1, true, signal_pos + 1, source_live);
+                if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_, &nx))) return rc;
+                pre_post_done_ = true;
+            } else if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) {
+                return rc;
+            }
         }
         WV_HIP(hipGetLastError());
         // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
@@ -748,8 +767,10 @@ public:
                 if (left == 0) break;
                 batch = std::min(batch, left);
             }
+            const bool can_fuse = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
             for (uint64_t i = 0; i < batch; ++i) {
-                int rc = enqueue_step((int)i, true, signal_pos_ + i, source_kind_ != WV_SOURCE_NONE);
+                int rc = enqueue_step((int)i, true, signal_pos_ + i, source_kind_ != WV_SOURCE_NONE,
+                                      can_fuse && i + 1 < batch);
                 if (rc) return rc;
                 cur_ ^= 1;
             }
@@ -798,6 +819,7 @@ public:
         source_kind_ = kind;
         signal_len_ = 0;
         signal_pos_ = 0;
+        io_plain_known_ = false;
         if (kind == WV_SOURCE_NONE) return WV_OK;
         if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
         if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
@@ -828,6 +850,7 @@ public:
         recv_log_.clear();
         recv_first_step_ = steps_done;
         n_recv_ = n;
+        io_plain_known_ = false;
         if (!n) return WV_OK;
         for (uint32_t i = 0; i < n; ++i)
             if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
@@ -838,6 +861,33 @@ public:
         WV_HIP(hipMemcpy(recv_nodes_, stored.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
         WV_HIP(hipMalloc((void**)&recv_out_, (size_t)kRing * n * sizeof(Real)));
         return WV_OK;
+    }
+
+    // true when neither the source nor any receiver sits on a boundary node: those nodes are then
+    // final once a step's sweep has run, before its boundary launch (which may serve them early)
+    bool io_nodes_plain() {
+        if (io_plain_known_) return io_plain_;
+        io_plain_known_ = true;
+        io_plain_ = false;
+        if (n_recv_ > 64) return false;  // not worth a class lookup per receiver
+        std::vector<uint64_t> stored;
+        if (source_kind_ != WV_SOURCE_NONE) stored.push_back(source_node_);
+        if (n_recv_) {
+            std::vector<uint64_t> r(n_recv_);
+            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (uint64_t v : r)
+                if (v != ~0ull) stored.push_back(v);
+        }
+        for (uint64_t idx : stored) {
+            const uint64_t x = idx % (uint64_t)pitch_, q = idx / (uint64_t)pitch_;
+            uint8_t byte = 0;
+            if (hipMemcpy(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
+                          1, hipMemcpyDeviceToHost) != hipSuccess)
+                return false;
+            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_BOUNDARY) return false;
+        }
+        io_plain_ = true;
+        return true;
     }
 
     int fetch_receivers(uint64_t first, uint64_t n, double* dst) override {
@@ -1028,6 +1078,8 @@ private:
     uint32_t list_longest_ = 0;
     bool lists_built_ = false;
     int lists_z0_ = 0, lists_z1_ = 0;  // plane range the lists were built for
+    bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
+    bool io_plain_known_ = false, io_plain_ = false;
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
     uint8_t* btype_ = nullptr;
