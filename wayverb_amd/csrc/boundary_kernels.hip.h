@@ -203,7 +203,7 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
     Real injected = 0;
     const bool has_source = a.source_kind != 0;
     if (has_source) {
-        const Real s = (Real)a.signal[a.signal_pos];
+        const Real s = (Real)a.signal[a.signal_pos + (a.signal_base ? *a.signal_base : 0ull)];
         injected = (a.source_kind == 1) ? s : (Real)(a.cur[a.source_node] + s);
     }
     for (uint32_t r = t; r < a.n_recv; r += width) {

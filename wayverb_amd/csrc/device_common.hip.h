@@ -129,7 +129,8 @@ template <typename Real>
 struct PrePostArgs {
     Real* cur;
     const double* signal;    // device copy of the source signal
-    uint64_t signal_pos;     // sample index for this step
+    uint64_t signal_pos;     // sample index for this step (relative to *signal_base when that is set)
+    const uint64_t* signal_base;  // device scalar: lets a captured batch of steps be replayed further along the signal
     uint64_t source_node;
     int source_kind;         // 0 none, 1 hard, 2 soft
     const uint64_t* recv;    // [n_recv]

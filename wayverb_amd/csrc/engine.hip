@@ -670,6 +670,7 @@ public:
         pp.cur = cur;
         pp.signal = signal_;
         pp.signal_pos = signal_pos;
+        pp.signal_base = graph_capturing_ ? signal_base_dev_ : nullptr;
         pp.source_node = source_node_;
         pp.source_kind = io && source_live ? source_kind_ : 0;
         pp.recv = recv_nodes_;
@@ -755,6 +756,50 @@ public:
         return WV_OK;
     }
 
+    // Capture (once per batch shape) and replay a batch of `batch` steps.
+    int replay_batch(uint64_t batch, bool source_live, bool can_fuse) {
+        const GraphKey key{batch, cur_, source_live, can_fuse, n_recv_, source_node_, source_kind_, (uint64_t)(uintptr_t)signal_,
+                           (uint64_t)(uintptr_t)recv_nodes_, lists_built_ && tile_list_ != nullptr};
+        if (!graph_exec_ || !(key == graph_key_)) {
+            if (graph_exec_) {
+                (void)hipGraphExecDestroy(graph_exec_);
+                graph_exec_ = nullptr;
+            }
+            if (!signal_base_dev_) WV_HIP(hipMalloc((void**)&signal_base_dev_, sizeof(uint64_t)));
+            // whatever synchronises must happen before the capture starts
+            if (plan_.variant == 2 || plan_.variant == 3) {
+                int rc = build_tile_lists(z_begin_, z_end_);
+                if (rc) return rc;
+            }
+            (void)io_nodes_plain();
+            const int cur_before = cur_;
+            hipGraph_t graph = nullptr;
+            WV_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            graph_capturing_ = true;
+            int rc = WV_OK;
+            for (uint64_t i = 0; i < batch && rc == WV_OK; ++i) {
+                rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch);
+                cur_ ^= 1;
+            }
+            graph_capturing_ = false;
+            const hipError_t end = hipStreamEndCapture(stream_, &graph);
+            cur_ = cur_before;
+            if (rc != WV_OK) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            WV_HIP(end);
+            const hipError_t inst = hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            WV_HIP(inst);
+            graph_key_ = key;
+        }
+        WV_HIP(hipMemcpyAsync(signal_base_dev_, &signal_pos_, sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+        WV_HIP(hipGraphLaunch(graph_exec_, stream_));
+        // batch is even: the fields are back in their roles
+        return WV_OK;
+    }
+
     int run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) override {
         uint64_t completed = 0;
         int32_t flag = 0;
@@ -768,11 +813,22 @@ public:
                 batch = std::min(batch, left);
             }
             const bool can_fuse = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
-            for (uint64_t i = 0; i < batch; ++i) {
-                int rc = enqueue_step((int)i, true, signal_pos_ + i, source_kind_ != WV_SOURCE_NONE,
-                                      can_fuse && i + 1 < batch);
+            const bool source_live = source_kind_ != WV_SOURCE_NONE;
+            // Small meshes are bound by launches, not bytes: a full batch of steps is captured once
+            // into a hipGraph and replayed (the only thing that differs between batches, the
+            // position in the source signal, comes from a device scalar).  Even batch lengths only,
+            // so that the two fields are back in their roles after every replay.
+            const bool use_graph = graph_mode_ != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
+                                   stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
+            if (use_graph) {
+                int rc = replay_batch(batch, source_live, can_fuse);
                 if (rc) return rc;
-                cur_ ^= 1;
+            } else {
+                for (uint64_t i = 0; i < batch; ++i) {
+                    int rc = enqueue_step((int)i, true, signal_pos_ + i, source_live, can_fuse && i + 1 < batch);
+                    if (rc) return rc;
+                    cur_ ^= 1;
+                }
             }
             WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
             if (n_recv_) {
@@ -1054,7 +1110,8 @@ private:
         events_.clear();
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
-        void* ptrs[] = {tile_list_, ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
+        if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+        void* ptrs[] = {signal_base_dev_, tile_list_, ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
                         zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -1078,6 +1135,27 @@ private:
     uint32_t list_longest_ = 0;
     bool lists_built_ = false;
     int lists_z0_ = 0, lists_z1_ = 0;  // plane range the lists were built for
+    struct GraphKey {
+        uint64_t batch;
+        int cur;
+        bool source_live, can_fuse;
+        uint32_t n_recv;
+        uint64_t source_node;
+        int source_kind;
+        uint64_t signal_ptr, recv_ptr;
+        bool lists;
+        bool operator==(const GraphKey& o) const {
+            return batch == o.batch && cur == o.cur && source_live == o.source_live && can_fuse == o.can_fuse &&
+                   n_recv == o.n_recv && source_node == o.source_node && source_kind == o.source_kind &&
+                   signal_ptr == o.signal_ptr && recv_ptr == o.recv_ptr && lists == o.lists;
+        }
+    };
+    hipGraphExec_t graph_exec_ = nullptr;
+    GraphKey graph_key_{};
+    uint64_t* signal_base_dev_ = nullptr;
+    bool graph_capturing_ = false;
+    int graph_mode_ = env_int("WV_GRAPH", 0);
+    uint64_t graph_max_nodes_ = 64ull << 20;
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
     bool io_plain_known_ = false, io_plain_ = false;
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
