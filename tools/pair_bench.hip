@@ -51,6 +51,7 @@ struct Args {
     double* out1;        // t+1
     double* out2;        // t+2 (pair kernel only)
     int ny, nz, stripe_rows, strips_per_stripe;
+    int nz_total;  // single2_kernel: planes in the field (nz then counts plane pairs)
 };
 
 struct Tile {
@@ -150,6 +151,48 @@ __global__ void __launch_bounds__(64 * NW) single_kernel(const Args a) {
     for (int r = 0; r < RY; ++r)
         if (t.y0 + r < a.ny)
             t.store(a.out1, t.y0 + r, t.z, step_row(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], el[r], er[r]));
+}
+
+// ---- one step, two planes per workgroup: plane z+1's `below` is plane z's `mid` ----------------------
+// (does issuing fewer loads per output row pay?  28 row loads per 8 output rows instead of 2 x 18)
+__global__ void __launch_bounds__(64 * NW) single2_kernel(const Args a) {
+    __shared__ double sl[2 * RY][NW], sr[2 * RY][NW];
+    Tile t;
+    bool alive = map_block(a, t);
+    const int z = t.z * 2;  // the grid is launched over plane pairs
+    t.nz = a.nz_total;
+    alive = alive && z < a.nz_total;
+    V m0[RY + 2], m1[RY + 2], below[RY], above[RY], p0[RY], p1[RY];
+#pragma unroll
+    for (int r = 0; r < RY + 2; ++r) {
+        m0[r] = alive ? t.load(a.cur, t.y0 - 1 + r, z) : (V)(0.0);
+        m1[r] = alive ? t.load(a.cur, t.y0 - 1 + r, z + 1) : (V)(0.0);
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        above[r] = alive ? t.load(a.cur, t.y0 + r, z + 2) : (V)(0.0);
+        p0[r] = alive ? t.load(a.prev, t.y0 + r, z, true) : (V)(0.0);
+        p1[r] = alive ? t.load(a.prev, t.y0 + r, z + 1, true) : (V)(0.0);
+        below[r] = alive ? t.load(a.cur, t.y0 + r, z - 1) : (V)(0.0);
+    }
+    V own[2 * RY];
+    double el[2 * RY], er[2 * RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        own[r] = m0[r + 1];
+        own[RY + r] = m1[r + 1];
+    }
+    exchange_edges<2 * RY>(own, el, er, t.lane, t.wave, sl, sr);
+    if (!alive) return;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        if (t.y0 + r < a.ny) {
+            t.store(a.out1, t.y0 + r, z, step_row(m0[r + 1], m0[r], m0[r + 2], below[r], m1[r + 1], p0[r], el[r], er[r]));
+            if (z + 1 < a.nz_total)
+                t.store(a.out1, t.y0 + r, z + 1,
+                        step_row(m1[r + 1], m1[r], m1[r + 2], m0[r + 1], above[r], p1[r], el[RY + r], er[RY + r]));
+        }
+    }
 }
 
 // ---- two steps per pass --------------------------------------------------------------------------
@@ -266,6 +309,25 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms_single, e0, e1));
+        {
+            // one step with two planes per workgroup (grid over nz / 2 plane pairs; map_block's z = pair index)
+            Args h = a;
+            h.out1 = C;   // scratch here: the pair pass below overwrites it
+            Args g = h;
+            g.nz = (nz + 1) / 2;   // map_block cycles over this many "planes"
+            g.nz_total = nz;
+            float ms2 = 0;
+            const unsigned grid2 = 8u * passes * ((nz + 1) / 2) * (stripe_rows / RY);
+            for (int it = 0; it < iters + 2; ++it) {
+                if (it == 2) CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(single2_kernel, dim3(grid2), dim3(64 * NW), 0, 0, g);
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms2, e0, e1));
+            printf("stripe %3d  one step, 1 plane per workgroup %.3f ms   2 planes per workgroup %.3f ms\n", stripe_rows,
+                   ms_single / iters / 2, ms2 / iters);
+        }
         Args p = a;
         p.out1 = A1;
         p.out2 = C;
