@@ -227,3 +227,28 @@ def test_restored_filter_state_lands_on_the_right_nodes(oracle, built_library, t
     for a, b in zip(got_bd, o_bd):
         assert np.array_equal(a["filter_memory"], b["filter_memory"])
         assert np.array_equal(a["coefficient_index"], b["coefficient_index"])
+
+
+def test_create_run_destroy_does_not_leak_device_memory(built_library):
+    import torch
+    mesh = M.box_mesh(48, 40, 36, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
+    sig = np.zeros(64)
+    sig[0] = 1.0
+
+    def cycle():
+        eng = E.Engine(mesh, precision="f64")
+        eng.set_source(E.SOURCE_HARD, mesh.compute_index(24, 20, 18), sig)
+        eng.set_receivers([mesh.compute_index(27, 20, 18)])
+        eng.run_steps(32)
+        eng.read_boundary_data(1)
+        eng.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 40 engine life cycles" % (free0 - free1)
