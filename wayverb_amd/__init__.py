@@ -4,6 +4,7 @@
   mesh        the reference's data contract (condensed_node, boundary_data, coefficients) + test meshes
   slab        z-slab decomposition across ranks
   scene       triangle scenes (OBJ reader, generators), adjusted boundary
+  wayfile     wayverb `.way` project bundles (config.json + model.model)
   filters     wall filter design (host C++ in the library)
   postprocess receiver traces -> audio
   simulation  compute_voxels_and_mesh / canonical / impulse_response
