@@ -42,3 +42,47 @@ def test_reference_concert_hall_bundle():
     assert np.allclose(by_name["DefaultMaterial"]["absorption"], 0.05)
     assert np.allclose(by_name["FrontColor"]["absorption"], [0.30, 0.30, 0.45, 0.65, 0.56, 0.59, 0.71, 0.71])
     assert v.shape[0] == 214 and t.shape[0] == 322 and len(absorptions) == 1
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DEMO), reason="needs /root/reference")
+def test_concert_hall_configuration_builds_and_steps_on_the_cpu_chain(oracle, built_library):
+    """BASELINE configs[4] up to the hot path, through the CPU restatements (the GPU box has no
+    reference tree): bundle -> adjusted boundary around the receiver -> inside flags -> node types
+    -> surfaces per filter -> designed wall filters -> 60 oracle steps from the calibrated impulse.
+    Source and receiver land on inside nodes and the run raises no error flag."""
+    from helpers import run_oracle
+    from wayverb_amd import engine as E
+    from wayverb_amd import filters as F
+    from wayverb_amd import mesh as M
+    from wayverb_amd import scene as S
+    from wayverb_amd import simulation as sim
+    cfg, v, t, absorptions = W.read_way(REF_DEMO)
+    wg = cfg["waveguide"]["single"]
+    fs = sim.compute_sampling_frequency(wg["cutoff"], wg["usable_portion"])
+    spacing = np.float32(sim.grid_spacing(340.0, 1.0 / fs))
+    assert float(spacing) == pytest.approx(0.4417, abs=1e-4)                      # SURVEY.md App. E
+    receiver, source = cfg["receivers"][0]["position"], cfg["sources"][0]["position"]
+    c0, c1 = S.compute_adjusted_boundary(v[:, :3].min(axis=0), v[:, :3].max(axis=0), np.float32(receiver), spacing)
+    dims = tuple(int(d) for d in ((c1 - c0) / spacing).astype(np.int32))
+    vox = E.voxelise(v, t, (c0, c1), 32)
+    mask = oracle.nodes_inside(dims, c0, float(spacing), vox, (c0, c1), 32, t, v).astype(bool)
+    nodes, _ = oracle.classify(mask)
+    b = oracle.boundary_index_data(nodes, dims, c0, float(spacing), t, v)
+    coeffs = np.zeros(len(absorptions), dtype=M.coefficients_dtype)
+    for i, a in enumerate(absorptions):
+        coeffs[i] = F.surface_coefficients(a, 340.0, float(spacing))
+    mesh = M.Mesh(dims, nodes, coeffs, b[0], b[1], b[2], spacing=float(spacing))
+    vm = sim.VoxelsAndMesh(vox, (c0, c1), 32, v, t, mesh, c0)
+    src, rcv = vm.compute_index(source), vm.compute_index(receiver)
+    assert nodes["boundary_type"][src] & M.ID_INSIDE and nodes["boundary_type"][rcv] & M.ID_INSIDE
+    assert 0.2 < mask.mean() < 0.8 and 15000 < vm.estimate_volume() < 40000     # a hall of some 10^4 m^3
+    steps = 60
+    sig = np.zeros(steps)
+    sig[0] = np.float32(M.rectilinear_calibration_factor(mesh.spacing, 400.0))
+    case = dict(mesh=mesh, steps=steps, source_kind=1, source_node=src, signal=sig,
+                recv=[rcv] + mesh.compute_neighbors(rcv), init=None)
+    out = run_oracle(oracle, case, np.float32, threads=4)
+    assert out["flag"] == 0
+    # 20 m away at 0.44 m per node and one node per step along an axis: nothing has arrived after 60 steps... or has it
+    dist_nodes = np.abs(np.array(vm.compute_locator(source)) - np.array(vm.compute_locator(receiver))).sum()
+    assert (np.abs(out["trace"][:, 0]).max() > 0) == (dist_nodes <= steps)
