@@ -882,11 +882,9 @@ public:
         source_node_ = stored_index(node);
         {
             // a source in an outside node keeps writing non-zero values there: no work lists then
-            const uint64_t x = node % (uint64_t)nx_, q = node / (uint64_t)nx_;
-            uint8_t byte = 0;
-            WV_HIP(hipMemcpy(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
-                             1, hipMemcpyDeviceToHost));
-            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_NONE) outside_dirty_ = 1 << 30;
+            uint32_t cls = 0;
+            WV_HIP(class_of(node % (uint64_t)nx_, node / (uint64_t)nx_, &cls));
+            if (cls == wv::CLS_NONE) outside_dirty_ = 1 << 30;
         }
         signal_len_ = n;
         WV_HIP(hipMalloc((void**)&signal_, std::max<uint64_t>(n, 1) * sizeof(double)));
@@ -930,17 +928,15 @@ public:
         if (source_kind_ != WV_SOURCE_NONE) stored.push_back(source_node_);
         if (n_recv_) {
             std::vector<uint64_t> r(n_recv_);
-            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+                return false;
             for (uint64_t v : r)
                 if (v != ~0ull) stored.push_back(v);
         }
         for (uint64_t idx : stored) {
-            const uint64_t x = idx % (uint64_t)pitch_, q = idx / (uint64_t)pitch_;
-            uint8_t byte = 0;
-            if (hipMemcpy(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
-                          1, hipMemcpyDeviceToHost) != hipSuccess)
-                return false;
-            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_BOUNDARY) return false;
+            uint32_t cls = 0;
+            if (class_of(idx % (uint64_t)pitch_, idx / (uint64_t)pitch_, &cls) != hipSuccess) return false;
+            if (cls == wv::CLS_BOUNDARY) return false;
         }
         io_plain_ = true;
         return true;
@@ -956,6 +952,16 @@ public:
 
     // -------------------------------------------------------------------------------------------
     Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[cur_ ^ 1]; }
+    // class (CLS_*) of the node at (x, row) of the stored layout, read back from the class map
+    hipError_t class_of(uint64_t x, uint64_t row, uint32_t* cls) {
+        uint8_t byte = 0;
+        const int64_t at = wv::cls_byte_index((int)x, (int)(row % (uint64_t)ny_), (int)(row / (uint64_t)ny_), ny_, cls_pitch_);
+        const hipError_t rc = hipMemcpyAsync(&byte, cls_ + at, 1, hipMemcpyDeviceToHost, stream_);
+        if (rc != hipSuccess) return rc;
+        const hipError_t rs = hipStreamSynchronize(stream_);
+        *cls = (byte >> ((x & 3) * 2)) & 3u;
+        return rs;
+    }
     // caller's node index (x + y*nx + z*nx*ny) -> position in the stored (row-padded) field
     uint64_t stored_index(uint64_t node) const {
         const uint64_t x = node % (uint64_t)nx_, row = node / (uint64_t)nx_;
@@ -975,12 +981,9 @@ public:
         const Real tmp = (Real)v;
         if (tmp != 0 && outside_dirty_ < 2) {
             // a non-zero value in an outside node is zeroed by the next two full sweeps
-            const uint64_t x = index % (uint64_t)nx_, q = index / (uint64_t)nx_;
-            uint8_t byte = 0;
-            WV_HIP(hipMemcpyAsync(&byte, cls_ + wv::cls_byte_index((int)x, (int)(q % (uint64_t)ny_), (int)(q / (uint64_t)ny_), ny_, cls_pitch_),
-                                  1, hipMemcpyDeviceToHost, stream_));
-            WV_HIP(hipStreamSynchronize(stream_));
-            if (((byte >> ((x & 3) * 2)) & 3u) == wv::CLS_NONE) outside_dirty_ = 2;
+            uint32_t cls = 0;
+            WV_HIP(class_of(index % (uint64_t)nx_, index / (uint64_t)nx_, &cls));
+            if (cls == wv::CLS_NONE) outside_dirty_ = 2;
         }
         WV_HIP(hipMemcpyAsync(buffer(buffer_id) + stored_index(index), &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
@@ -1111,8 +1114,8 @@ private:
         for (int i = 0; i < 2; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-        void* ptrs[] = {signal_base_dev_, tile_list_, ref_to_pos_, cls_, bnode_, btype_, fmem_, cidx_, status_, coeffs_, flags_, scratch_, signal_, recv_nodes_, recv_out_,
-                        zorder_};
+        void* ptrs[] = {signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+                        status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (flags_host_) (void)hipHostFree(flags_host_);
