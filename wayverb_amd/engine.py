@@ -270,6 +270,18 @@ class Engine:
         self.h = handle
         self.n_recv = 0
 
+    @classmethod
+    def from_handle(cls, handle, mesh, precision):
+        """Wrap an engine the library has already created (SceneMesh.engine)."""
+        eng = cls.__new__(cls)
+        eng.lib = load_library()
+        eng.mesh = mesh
+        eng.precision = precision
+        eng.dtype = np.float32 if precision == "f32" else np.float64
+        eng.h = handle
+        eng.n_recv = 0
+        return eng
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.wv_destroy(self.h)
@@ -483,14 +495,7 @@ class SceneMesh:
         handle = C.c_void_p()
         _check(self.lib.wv_scene_mesh_create_engine(self.h, coeffs.ctypes.data_as(C.c_void_p), coeffs.shape[0],
                                                     C.byref(opt), C.byref(handle)))
-        eng = Engine.__new__(Engine)
-        eng.lib = self.lib
-        eng.mesh = _ResidentMesh(self.dims, self.counts)
-        eng.precision = precision
-        eng.dtype = np.float32 if precision == "f32" else np.float64
-        eng.h = handle
-        eng.n_recv = 0
-        return eng
+        return Engine.from_handle(handle, _ResidentMesh(self.dims, self.counts), precision)
 
     def close(self):
         if getattr(self, "h", None):
