@@ -269,6 +269,116 @@ __global__ void __launch_bounds__(64 * NW) pair_kernel(const Args a) {
     }
 }
 
+// ---- two steps per pass, register-resident z-march -------------------------------------------------
+// One workgroup owns a strip of RY rows x 1024 columns and marches it through `zc` planes.  It keeps
+// three planes of `current` (RY+4 rows) and three planes of t+1 (RY+2 rows) in registers, so per
+// plane it loads one plane of `current` (RY+4 rows) and one of `previous` (RY+2 rows) and stores one
+// plane of t+1 and one of t+2: 14 row loads + 8 row stores per RY = 4 output rows and TWO steps.
+struct MarchArgs {
+    const double* prev;
+    const double* cur;
+    double* out1;
+    double* out2;
+    int ny, nz, zc, chunks;
+    int xcd_map;
+};
+
+__global__ void __launch_bounds__(64 * NW) pair_march_kernel(const MarchArgs a) {
+    __shared__ double sl[2 * RY + 2][NW], sr[2 * RY + 2][NW];
+    Tile t;
+    t.lane = threadIdx.x & 63;
+    t.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    t.ny = a.ny;
+    t.nz = a.nz;
+    t.col = (int64_t)t.wave * 128 + t.lane * 2;
+    // XCD k (= blockIdx % 8) takes a contiguous eighth of the strips, so that the y rings two neighbouring
+    // strips both need are fetched once into that XCD's L2 (the strips march in step)
+    const int strips = a.ny / RY, per_xcd = (strips + 7) / 8;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int strip = a.xcd_map ? xcd * per_xcd + j % per_xcd : (int)(blockIdx.x / a.chunks);
+    const int chunk = a.xcd_map ? j / per_xcd : (int)(blockIdx.x % a.chunks);
+    if (strip >= strips || chunk >= a.chunks) return;
+    const int y0 = strip * RY;
+    const int zb = chunk * a.zc, ze = min(zb + a.zc, a.nz);
+    t.y0 = y0;
+
+    auto load_b = [&](V (&dst)[RY + 4], int z) {
+#pragma unroll
+        for (int q = 0; q < RY + 4; ++q) dst[q] = t.load(a.cur, y0 - 2 + q, z);
+    };
+    // t+1 on plane z (rows y0-1 .. y0+RY) from b(z-1), b(z), b(z+1) and `previous`(z); el/er: x edges of b(z) rows
+    auto level1 = [&](V (&dst)[RY + 2], const V (&bm)[RY + 4], const V (&b0)[RY + 4], const V (&bp)[RY + 4], int z,
+                      const double* el, const double* er) {
+#pragma unroll
+        for (int q = 0; q < RY + 2; ++q) {
+            const int y = y0 - 1 + q;
+            const V pv = t.load(a.prev, y, z, true);
+            dst[q] = (y >= 0 && y < a.ny && z >= 0 && z < a.nz)
+                             ? step_row(b0[q + 1], b0[q], b0[q + 2], bm[q + 1], bp[q + 1], pv, el[q], er[q])
+                             : (V)(0.0);
+        }
+    };
+
+    V b_lo[RY + 4], b_mid[RY + 4], b_hi[RY + 4];  // `current` on planes z-1, z, z+1 while producing t+1(z)
+    V t_prev[RY + 2], t_cur[RY + 2], t_next[RY + 2];
+    V rows[2 * RY + 2];
+    double el[2 * RY + 2], er[2 * RY + 2];
+
+    // prologue: t+1 on planes zb-1 and zb
+    load_b(b_lo, zb - 2);
+    load_b(b_mid, zb - 1);
+    load_b(b_hi, zb);
+#pragma unroll
+    for (int q = 0; q < RY + 2; ++q) rows[q] = b_mid[q + 1];
+#pragma unroll
+    for (int q = RY + 2; q < 2 * RY + 2; ++q) rows[q] = (V)(0.0);
+    exchange_edges<2 * RY + 2>(rows, el, er, t.lane, t.wave, sl, sr);
+    level1(t_prev, b_lo, b_mid, b_hi, zb - 1, el, er);
+#pragma unroll
+    for (int q = 0; q < RY + 4; ++q) {
+        b_lo[q] = b_mid[q];
+        b_mid[q] = b_hi[q];
+    }
+    load_b(b_hi, zb + 1);
+#pragma unroll
+    for (int q = 0; q < RY + 2; ++q) rows[q] = b_mid[q + 1];
+    exchange_edges<2 * RY + 2>(rows, el, er, t.lane, t.wave, sl, sr);
+    level1(t_cur, b_lo, b_mid, b_hi, zb, el, er);
+
+    for (int z = zb; z < ze; ++z) {
+        // now: b_lo = b(z-1), b_mid = b(z), b_hi = b(z+1); t_prev = t+1(z-1), t_cur = t+1(z)
+        V b_nn[RY + 4];
+        load_b(b_nn, z + 2);
+        // one exchange for both levels: x edges of b(z+1) rows (for t+1(z+1)) and of t+1(z) tile rows (for t+2(z))
+#pragma unroll
+        for (int q = 0; q < RY + 2; ++q) rows[q] = b_hi[q + 1];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) rows[RY + 2 + r] = t_cur[r + 1];
+        exchange_edges<2 * RY + 2>(rows, el, er, t.lane, t.wave, sl, sr);
+        level1(t_next, b_mid, b_hi, b_nn, z + 1, el, er);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            if (y0 + r < a.ny) {
+                t.store(a.out1, y0 + r, z, t_cur[r + 1]);
+                t.store(a.out2, y0 + r, z,
+                        step_row(t_cur[r + 1], t_cur[r], t_cur[r + 2], t_prev[r + 1], t_next[r + 1], b_mid[r + 2], el[RY + 2 + r],
+                                 er[RY + 2 + r]));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RY + 2; ++q) {
+            t_prev[q] = t_cur[q];
+            t_cur[q] = t_next[q];
+        }
+#pragma unroll
+        for (int q = 0; q < RY + 4; ++q) {
+            b_lo[q] = b_mid[q];
+            b_mid[q] = b_hi[q];
+            b_hi[q] = b_nn[q];
+        }
+    }
+}
+
 __global__ void init_kernel(double* p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t h = (uint32_t)i * 2654435761u + seed;
@@ -346,13 +456,42 @@ int main(int argc, char** argv) {
     // agreement (bit for bit) on a sample of planes
     std::vector<double> h1((size_t)NX * ny), h2((size_t)NX * ny);
     int bad = 0;
-    for (int z : {0, 1, nz / 2, nz - 2, nz - 1}) {
-        for (auto pr : {std::make_pair(S1, A1), std::make_pair(S2, C)}) {
-            CK(hipMemcpy(h1.data(), pr.first + (int64_t)z * ny * NX, h1.size() * 8, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(h2.data(), pr.second + (int64_t)z * ny * NX, h2.size() * 8, hipMemcpyDeviceToHost));
-            if (memcmp(h1.data(), h2.data(), h1.size() * 8) != 0) ++bad;
+    // the z-march form of the pair pass (after the plane-sweep pair pass has been checked below, A1 / C are reused)
+    auto check = [&](const char* what) {
+        int wrong = 0;
+        for (int z : {0, 1, nz / 2, nz / 2 + 1, nz - 2, nz - 1}) {
+            for (auto pr : {std::make_pair(S1, A1), std::make_pair(S2, C)}) {
+                CK(hipMemcpy(h1.data(), pr.first + (int64_t)z * ny * NX, h1.size() * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(h2.data(), pr.second + (int64_t)z * ny * NX, h2.size() * 8, hipMemcpyDeviceToHost));
+                if (memcmp(h1.data(), h2.data(), h1.size() * 8) != 0) ++wrong;
+            }
         }
+        printf(wrong ? "MISMATCH: %s differs from two single steps on %d sampled planes\n"
+                     : "%s == two single steps (sampled planes, bitwise)%.0d\n",
+               what, wrong);
+        return wrong;
+    };
+    bad += check("plane-sweep pair pass");
+    for (int cfg = 0; cfg < 8; ++cfg) {
+        const int zc = (const int[]){1024, 128, 64, 32}[cfg % 4], xcd_map = cfg / 4;
+        if (zc > nz && zc != 1024) continue;
+        CK(hipMemset(A1, 0xFF, N * 8));
+        CK(hipMemset(C, 0xFF, N * 8));
+        MarchArgs m{A, B, A1, C, ny, nz, std::min(zc, nz), (nz + std::min(zc, nz) - 1) / std::min(zc, nz), xcd_map};
+        const unsigned grid = xcd_map ? 8u * (unsigned)(((ny / RY + 7) / 8) * m.chunks) : (unsigned)((ny / RY) * m.chunks);
+        float ms = 0;
+        for (int it = 0; it < iters + 2; ++it) {
+            if (it == 2) CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(pair_march_kernel, dim3(grid), dim3(64 * NW), 0, 0, m);
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipGetLastError());
+        printf("z-march pair pass, %4d planes per workgroup, strips %s: %.3f ms per pair  (%.1f Gnode-updates/s)\n", m.zc,
+               xcd_map ? "grouped per XCD" : "round robin", ms / iters, 2.0 * N / (ms / iters) / 1e6);
+        bad += check("z-march pair pass");
     }
-    printf(bad ? "MISMATCH between two single steps and the pair pass (%d planes)\n" : "pair pass == two single steps (sampled planes, bitwise)%.0d\n", bad);
+    printf("done, %d mismatching checks\n", bad);
     return bad ? 1 : 0;
 }
