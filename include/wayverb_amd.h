@@ -126,7 +126,10 @@ typedef struct wv_engine wv_engine;
 int wv_create(const wv_mesh* mesh, const wv_options* options, wv_engine** out);
 void wv_destroy(wv_engine* e);
 const char* wv_last_error(void);
-/* Fills `options` with defaults (F64, current device, no ghosts, flag_interval 1). */
+/* Fills `options` with defaults: F64 pressures (the default of every layer above this ABI too; F32 is
+ * the reference's cl_float storage, bit for bit), the calling thread's current device, no ghosts,
+ * flag_interval 0 (the flag words of a wv_run batch are read back once per batch; the step that
+ * raised a flag is still reported exactly, see wv_run). */
 void wv_default_options(wv_options* options);
 
 /* ---- buffer access used by step pre/post-processors ----------------------------------------- */

@@ -35,7 +35,8 @@ def test_hall_impulse_response_end_to_end(oracle, built_library):
     env = W.Environment()
     audio, bands, vm = W.impulse_response(v, t, [PLASTER, WOOD], source, receiver, cutoff=200.0, usable_portion=0.6,
                                           simulation_time=0.3, output_sample_rate=44100.0, environment=env,
-                                          method=P.ATTENUATOR_MICROPHONE, pointing=(0.0, -1.0, 0.0), shape=0.5)
+                                          method=P.ATTENUATOR_MICROPHONE, pointing=(0.0, -1.0, 0.0), shape=0.5,
+                                          precision="f32")     # the reference's pressure type: float oracle below
     mesh = vm.mesh
     # the mesh: a node sits on the receiver; both materials are in use; volume close to the room's
     loc = vm.compute_locator(receiver)

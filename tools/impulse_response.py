@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--rate", type=float, default=44100.0)
     ap.add_argument("--mic-shape", type=float, default=None, help="0 omni .. 1 figure-eight; omit for raw pressure")
     ap.add_argument("--pointing", type=float, nargs=3, default=[0.0, 0.0, 1.0])
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"])
     ap.add_argument("--out", default="ir.wav")
     args = ap.parse_args()
 

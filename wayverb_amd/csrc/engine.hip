@@ -58,6 +58,22 @@ struct ScopedDevice {
     }
 };
 
+// Selects the engine's device for the duration of a public call and restores the caller's: two
+// engines on different GPUs may be driven from one thread (wv_options::device).
+struct DeviceGuard {
+    int before = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&before) == hipSuccess && before != device && device >= 0)
+            switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(before);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct StreamPlan {
     int variant = 2;  // 2 = plane sweep (default), 0 = z-march, 1 = naive
     int ry = 4, nwx = 1, nwy = 4;
@@ -130,7 +146,8 @@ public:
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
             return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
-        if (opt.device >= 0) WV_HIP(hipSetDevice(opt.device));
+        if (opt.device >= count) return fail(WV_E_INVALID_ARGUMENT, "no such HIP device");
+        DeviceGuard guard(opt.device);  // the caller's current device is restored on return
         WV_HIP(hipGetDevice(&device_));
         WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
@@ -741,6 +758,7 @@ public:
 
     // -------------------------------------------------------------------------------------------
     int step(int32_t* flag) override {
+        DeviceGuard guard(device_);
         int rc = enqueue_step(0, false, 0, false);
         if (rc) return rc;
         WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -801,6 +819,7 @@ public:
     }
 
     int run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) override {
+        DeviceGuard guard(device_);
         uint64_t completed = 0;
         int32_t flag = 0;
         const uint64_t interval = opt_.flag_interval > 0 ? (uint64_t)opt_.flag_interval : (uint64_t)kRing;
@@ -866,6 +885,7 @@ public:
 
     // -------------------------------------------------------------------------------------------
     int set_source(int kind, uint64_t node, const double* signal, uint64_t n) override {
+        DeviceGuard guard(device_);
         if (kind != WV_SOURCE_NONE && kind != WV_SOURCE_HARD && kind != WV_SOURCE_SOFT)
             return fail(WV_E_INVALID_ARGUMENT, "unknown source kind");
         if (signal_) {
@@ -893,27 +913,31 @@ public:
     }
 
     int set_receivers(const uint64_t* nodes, uint32_t n) override {
-        if (recv_nodes_) {
-            WV_HIP(hipFree(recv_nodes_));
-            recv_nodes_ = nullptr;
+        DeviceGuard guard(device_);
+        // validate and build the new device buffers first; the engine's state changes only when
+        // nothing can fail any more (a failed call leaves the engine without receivers)
+        if (n && !nodes) return fail(WV_E_INVALID_ARGUMENT, "receiver node list missing");
+        for (uint32_t i = 0; i < n; ++i)
+            if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
+                return fail(WV_E_INVALID_ARGUMENT, "receiver node outside the mesh");
+        ScopedDevice new_nodes, new_out;
+        if (n) {
+            std::vector<uint64_t> stored(n);
+            for (uint32_t i = 0; i < n; ++i) stored[i] = nodes[i] == ~0ull ? ~0ull : stored_index(nodes[i]);
+            WV_HIP(hipMalloc(&new_nodes.p, n * sizeof(uint64_t)));
+            WV_HIP(hipMemcpy(new_nodes.p, stored.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+            WV_HIP(hipMalloc(&new_out.p, (size_t)kRing * n * sizeof(Real)));
         }
-        if (recv_out_) {
-            WV_HIP(hipFree(recv_out_));
-            recv_out_ = nullptr;
-        }
+        WV_HIP(hipStreamSynchronize(stream_));  // nothing in flight reads the old buffers
+        if (recv_nodes_) (void)hipFree(recv_nodes_);
+        if (recv_out_) (void)hipFree(recv_out_);
+        recv_nodes_ = static_cast<uint64_t*>(new_nodes.p);
+        recv_out_ = static_cast<Real*>(new_out.p);
+        new_nodes.p = new_out.p = nullptr;
         recv_log_.clear();
         recv_first_step_ = steps_done;
         n_recv_ = n;
         io_plain_known_ = false;
-        if (!n) return WV_OK;
-        for (uint32_t i = 0; i < n; ++i)
-            if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
-                return fail(WV_E_INVALID_ARGUMENT, "receiver node outside the mesh");
-        std::vector<uint64_t> stored(n);
-        for (uint32_t i = 0; i < n; ++i) stored[i] = nodes[i] == ~0ull ? ~0ull : stored_index(nodes[i]);
-        WV_HIP(hipMalloc((void**)&recv_nodes_, n * sizeof(uint64_t)));
-        WV_HIP(hipMemcpy(recv_nodes_, stored.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
-        WV_HIP(hipMalloc((void**)&recv_out_, (size_t)kRing * n * sizeof(Real)));
         return WV_OK;
     }
 
@@ -969,6 +993,7 @@ public:
     }
 
     int read_value(int buffer_id, uint64_t index, double* v) override {
+        DeviceGuard guard(device_);
         if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
         Real tmp;
         WV_HIP(hipMemcpyAsync(&tmp, buffer(buffer_id) + stored_index(index), sizeof(Real), hipMemcpyDeviceToHost, stream_));
@@ -977,6 +1002,7 @@ public:
         return WV_OK;
     }
     int write_value(int buffer_id, uint64_t index, double v) override {
+        DeviceGuard guard(device_);
         if (index >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "index outside the buffer");
         const Real tmp = (Real)v;
         if (tmp != 0 && outside_dirty_ < 2) {
@@ -1020,11 +1046,13 @@ public:
     }
 
     int read_field(int buffer_id, void* dst, int elem_size) override {
+        DeviceGuard guard(device_);
         if (elem_size == 4) return copy_field<float>(buffer(buffer_id), dst, false);
         if (elem_size == 8) return copy_field<double>(buffer(buffer_id), dst, false);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
     int write_field(int buffer_id, const void* src, int elem_size) override {
+        DeviceGuard guard(device_);
         outside_dirty_ = std::max(outside_dirty_, 2);  // the caller may have put anything in the outside nodes
         if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true);
         if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true);
@@ -1032,11 +1060,17 @@ public:
     }
 
     int boundary_data(int dim, wv_boundary_data* host, bool to_device) override {
+        DeviceGuard guard(device_);
         if (dim < 1 || dim > 3) return fail(WV_E_INVALID_ARGUMENT, "dimensionality must be 1, 2 or 3");
         const uint32_t nd = dim == 1 ? n1_ : (dim == 2 ? n2_ : n3_);
         if (!nd) return WV_OK;
         const uint32_t base = dim == 1 ? 0u : (dim == 2 ? n1_ : n1_ + 2u * n2_);
         const size_t bytes = (size_t)nd * dim * sizeof(wv_boundary_data);
+        if (!host) return fail(WV_E_INVALID_ARGUMENT, "boundary data array missing");
+        if (to_device)  // same rule as wv_create: a filter must name an existing coefficient set
+            for (size_t i = 0; i < (size_t)nd * dim; ++i)
+                if (host[i].coefficient_index >= n_coeffs_)
+                    return fail(WV_E_INVALID_MESH, "coefficient index exceeds the coefficient array length");
         ScopedDevice aos_mem;
         WV_HIP(hipMalloc(&aos_mem.p, bytes));
         uint64_t* aos = static_cast<uint64_t*>(aos_mem.p);
@@ -1060,6 +1094,7 @@ public:
     }
 
     int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) override {
+        DeviceGuard guard(device_);
         if (n != n_coeffs_)
             return fail(WV_E_INVALID_ARGUMENT,
                         "Size of new coefficients vector must be equal to the existing one");  // setup.cpp:43-47
@@ -1077,6 +1112,7 @@ public:
     }
 
     int kernel_time(double* mean_ms, uint64_t* launches) override {
+        DeviceGuard guard(device_);
         if (mean_ms) *mean_ms = time_n_ ? time_ms_ / (double)time_n_ : 0.0;
         if (launches) *launches = time_n_;
         time_ms_ = 0;
@@ -1085,12 +1121,14 @@ public:
     }
 
     int synchronize() override {
+        DeviceGuard guard(device_);
         WV_HIP(hipStreamSynchronize(stream_));
         WV_HIP(hipStreamSynchronize(comm_stream_));
         return WV_OK;
     }
 
     int comm_init(const void* id, int rank, int nranks) override {
+        DeviceGuard guard(device_);
         if (comm_) return fail(WV_E_STATE, "communicator already initialised");
         std::unique_ptr<wv::SlabComm> c(new wv::SlabComm());
         std::string err;
@@ -1101,12 +1139,14 @@ public:
     }
     uint64_t field_pitch() const override { return (uint64_t)pitch_; }
     int comm_destroy() override {
+        DeviceGuard guard(device_);
         comm_.reset();
         return WV_OK;
     }
 
 private:
     void release() {
+        DeviceGuard guard(device_);
         comm_.reset();
         if (stream_) (void)hipStreamSynchronize(stream_);
         for (auto& e : events_) (void)hipEventDestroy(e);
@@ -1124,7 +1164,7 @@ private:
     }
 
     wv_options opt_{};
-    int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = 0;
+    int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = -1;
     uint64_t n_nodes_ = 0, stored_nodes_ = 0, field_bytes_ = 0;
     int pitch_ = 0;
     Real* field_[2] = {nullptr, nullptr};

@@ -107,7 +107,7 @@ def compute_voxels_and_mesh(vertices, triangles, surface_absorptions, anchor, sa
     return VoxelsAndMesh(vox, (c0, c1), side, vertices, triangles, mesh, c0, absorptions)
 
 
-def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulation_time, precision="f32",
+def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulation_time, precision="f64",
               device=-1, keep_going=lambda: True):
     """canonical (single band): hard source at `source`, directional receiver at `receiver`, for
     ceil(sample_rate * simulation_time) steps.  Returns [(directional records, sample_rate,
@@ -149,7 +149,7 @@ def band_edges_hz(bands=8, lo=20.0, hi=20000.0):
 
 
 def canonical_multiband(vm, source, receiver, environment, bands, cutoff, usable_portion, simulation_time,
-                        precision="f32", device=-1, keep_going=lambda: True):
+                        precision="f64", device=-1, keep_going=lambda: True):
     """canonical for multiple_band_constant_spacing_parameters (canonical.h:138-176): one run per
     band with every surface's filter replaced by the flat filter of that band's absorption
     (set_flat_coefficients_for_band, :127-135); band i is valid on [edge_i, edge_i+1)."""
@@ -176,7 +176,7 @@ def canonical_multiband(vm, source, receiver, environment, bands, cutoff, usable
 
 def impulse_response(vertices, triangles, surface_absorptions, source, receiver, cutoff=200.0, usable_portion=0.6,
                      simulation_time=1.0, output_sample_rate=44100.0, environment=None, method=P.ATTENUATOR_NULL,
-                     pointing=(0.0, 0.0, 1.0), shape=0.0, precision="f32", device=-1):
+                     pointing=(0.0, 0.0, 1.0), shape=0.0, precision="f64", device=-1):
     """The waveguide leg of combined::engine (engine.cpp:90-188) end to end: scene -> audio."""
     environment = environment or Environment()
     vm = compute_voxels_and_mesh(vertices, triangles, surface_absorptions, receiver,
