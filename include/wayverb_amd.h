@@ -143,6 +143,10 @@ int wv_write_value(wv_engine* e, int buffer, uint64_t index, double value);
  * preprocessor/gaussian.cpp:50).  elem_size 4 -> float[n], 8 -> double[n]. */
 int wv_read_field(wv_engine* e, int buffer, void* dst, int elem_size);
 int wv_write_field(wv_engine* e, int buffer, const void* src, int elem_size);
+/* The same for planes [z_begin, z_begin + z_count) only: dst / src hold z_count*ny*nx elements.
+ * (A 1024^3 field is 8.6 GB: a visualiser slice or a slab hand-over should not have to move it all.) */
+int wv_read_planes(wv_engine* e, int buffer, int32_t z_begin, int32_t z_count, void* dst, int elem_size);
+int wv_write_planes(wv_engine* e, int buffer, int32_t z_begin, int32_t z_count, const void* src, int elem_size);
 /* Read back / restore boundary filter state in the reference layout boundary_data_array<D>[n_D]. */
 int wv_read_boundary_data(wv_engine* e, int dimensionality, wv_boundary_data* dst);
 int wv_write_boundary_data(wv_engine* e, int dimensionality, const wv_boundary_data* src);
@@ -199,6 +203,18 @@ int wv_comm_unique_id(void* id_bytes /* [WV_UNIQUE_ID_BYTES] */);
 /* Joins a communicator: this engine is slab `rank` of `nranks`, neighbours rank-1 / rank+1. */
 int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks);
 int wv_comm_destroy(wv_engine* e);
+/* On a chain of nranks > 1 every rank must call wv_run with the same n_steps (a rank that holds no
+ * source cannot know where the signal ends); at the end of every batch of steps the per-step flag
+ * words are OR-ed over the ranks (one small all-reduce), so a NaN / Inf / bad-boundary flag raised
+ * on one slab stops all of them at the same step -- the multi-device form of waveguide.h:100-119.
+ *
+ * The same chain inside ONE process (several engines on one GPU, or one per GPU of a node driven
+ * from one thread): engines[r] is slab r, created with ghost_lo = (r > 0), ghost_hi = (r < n - 1);
+ * face planes travel by device-to-device copies instead of RCCL, everything else in a step is the
+ * same code.  Slabs joined this way are stepped together with wv_run_group (same contract as wv_run:
+ * *steps_done and *flag are those of the chain; receivers are fetched per engine as usual). */
+int wv_comm_init_local(wv_engine* const* engines, int32_t n);
+int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_t* steps_done, int32_t* flag);
 
 /* ---- unit kernel of the boundary IIR step ------------------------------------------------------- */
 /* The reference's `filter_test_2` test kernel (src/waveguide/src/cl/filters.cpp:66-75, launched by

@@ -41,3 +41,17 @@ def run_engine(case, precision, **engine_kw):
                     bd=[eng.read_boundary_data(d) for d in (1, 2, 3)])
     finally:
         eng.close()
+
+
+def box_boundary_rows_below(nx, ny, nz, z, d):
+    """Number of D-dimensional boundary nodes of an nx*ny*nz box in planes [0, z) = the boundary_index
+    of the first such node of plane z (set_boundary_index numbers them in node order)."""
+    per_face_plane = {1: (nx - 4) * (ny - 4), 2: 2 * (nx - 4) + 2 * (ny - 4), 3: 4}[d]
+    per_mid_plane = {1: 2 * (nx - 4) + 2 * (ny - 4), 2: 4, 3: 0}[d]
+    total = 0
+    if z > 1:
+        total += per_face_plane
+    total += per_mid_plane * max(0, min(z, nz - 2) - 2)
+    if z > nz - 2:
+        total += per_face_plane
+    return total

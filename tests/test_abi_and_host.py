@@ -75,3 +75,14 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(root, f)).read()
                 assert "oracle" not in text.replace("no CPU fallback", ""), f
+
+
+def test_box_boundary_row_arithmetic(built_library):
+    """helpers.box_boundary_rows_below (used by the full-size 1024^3 GPU test to find a plane's rows in
+    the boundary arrays without building the 8.6 GB node array twice) against wv_make_box_nodes."""
+    from helpers import box_boundary_rows_below
+    from wayverb_amd import engine as E
+    nx, ny, nz = 11, 9, 13
+    for z in range(nz + 1):
+        _, counts = E.make_box_nodes(nx, ny, nz, z_begin=0, z_count=max(z, 1), number_from=0, number_to=z)
+        assert [box_boundary_rows_below(nx, ny, nz, z, d) for d in (1, 2, 3)] == list(counts)

@@ -10,7 +10,7 @@ import pytest
 
 import cases
 from conftest import golden
-from helpers import run_engine, run_oracle, sha
+from helpers import box_boundary_rows_below, run_engine, run_oracle, sha
 from wayverb_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
@@ -195,3 +195,97 @@ def test_iir_unit_kernel_matches_golden(quiet):
     assert sha(out) == str(g["sha_outputs"])
     assert np.array_equal(out[-1], g["last_output"])
     assert np.array_equal(mem, g["final_memory"])
+
+
+# ---- BASELINE configs[2]: the headline mesh at full size -----------------------------------------
+
+class _Window:
+    """Planes [a, b) of a box whose cut planes are ghosts: what wayverb_amd.slab.box_slab_mesh wants."""
+
+    def __init__(self, dims, a, b):
+        nx, ny, nz = dims
+        self.zl0, self.zl1 = a, b
+        self.z0 = a + (1 if a > 0 else 0)
+        self.z1 = b - (1 if b < nz else 0)
+        self.local_dims = (nx, ny, b - a)
+        self.plane = nx * ny
+
+
+def test_config2_1024cubed_full_size(oracle, built_library):
+    """BASELINE configs[2], 1024^3 fp64, at full size through the C ABI:
+    (i)  size-independent property: an x-mirror-symmetric start (all walls one order-6 material) stays
+         bit-exactly mirror symmetric over the whole field (a + b == b + a makes the nx/px swap exact);
+    (ii) bit-equality with the oracle on sampled planes -- both faces, next to them, mid-mesh (where
+         the sweep's y-stripes and z-planes hand over) -- fields AND the filter memories of all six walls.
+         The oracle steps a window of planes around each sample: a cut plane's error travels one plane
+         per step, so S steps leave everything S planes away from a cut exact."""
+    from wayverb_amd import engine as E
+    from wayverb_amd.slab import box_slab_mesh
+    n, S = 1024, 4
+    dims = (n, n, n)
+    rng = np.random.default_rng(5)
+    coeffs = M.passive_peak_filter_coefficients(rng, 1)
+
+    def initial_planes(z0, count):
+        """(previous, current) planes [z0, z0 + count): seeded per plane, symmetric in x, 0 outside the room."""
+        out = np.zeros((2, count, n, n))
+        for k in range(count):
+            z = z0 + k
+            if z == 0 or z == n - 1:
+                continue
+            r = np.random.default_rng([77, z])
+            for f in range(2):
+                half = r.uniform(-0.25, 0.25, (n, n // 2))
+                out[f, k] = np.concatenate([half, half[:, ::-1]], axis=1)
+        out[:, :, 0, :] = out[:, :, n - 1, :] = 0.0
+        out[:, :, :, 0] = out[:, :, :, n - 1] = 0.0
+        return out[0], out[1]
+
+    full = _Window(dims, 0, n)
+    mesh = box_slab_mesh(n, n, n, full, coefficients=coeffs)
+    eng = E.Engine(mesh, precision="f64")
+    mesh.nodes = None
+    chunk = 32
+    for z0 in range(0, n, chunk):
+        p, c = initial_planes(z0, chunk)
+        eng.write_planes(z0, p, E.BUF_PREVIOUS)
+        eng.write_planes(z0, c, E.BUF_CURRENT)
+    done, flag = eng.run_steps(S)
+    assert (done, flag) == (S, 0)
+
+    samples = [[1, 2], [100], [511, 512], [777], [n - 3, n - 2]]
+    keep = {}
+    for z0 in range(0, n, chunk):
+        for buf in (E.BUF_CURRENT, E.BUF_PREVIOUS):
+            got = eng.read_planes(z0, chunk, buf)
+            assert np.array_equal(got, got[:, :, ::-1]), "mirror symmetry lost in planes %d..%d" % (z0, z0 + chunk - 1)
+            for zs in samples:
+                for z in zs:
+                    if z0 <= z < z0 + chunk:
+                        keep[(buf, z)] = got[z - z0].copy()
+    bd = [eng.read_boundary_data(d) for d in (1, 2, 3)]
+    eng.close()
+
+    threads = os.cpu_count() or 8
+    for zs in samples:
+        a, b = max(0, min(zs) - S), min(n, max(zs) + S + 1)
+        w = _Window(dims, a, b)
+        wmesh = box_slab_mesh(n, n, n, w, coefficients=coeffs)
+        o_prev, o_cur = (f.reshape(-1).copy() for f in initial_planes(a, b - a))
+        obd = [wmesh.boundary_data(d) for d in (1, 2, 3)]
+        for _ in range(S):
+            assert oracle.step_range(o_prev, o_cur, wmesh, obd, w.z0 - a, w.z1 - a, threads=threads) == 0
+            o_prev, o_cur = o_cur, o_prev
+        for z in zs:
+            for buf, field in ((E.BUF_CURRENT, o_cur), (E.BUF_PREVIOUS, o_prev)):
+                want = field.reshape(b - a, n, n)[z - a]
+                assert keep[(buf, z)].tobytes() == want.tobytes(), "plane %d differs from the oracle" % z
+            for d in (1, 2, 3):
+                lo, hi = (box_boundary_rows_below(n, n, n, zz, d) for zz in (z, z + 1))
+                first = box_boundary_rows_below(n, n, n, w.z0, d)
+                got_rows = bd[d - 1][lo:hi]["filter_memory"]
+                want_rows = obd[d - 1][lo - first:hi - first]["filter_memory"]
+                assert hi > lo or d == 3
+                assert np.ascontiguousarray(got_rows).tobytes() == np.ascontiguousarray(want_rows).tobytes(), \
+                    "filter memories of plane %d differ (D=%d)" % (z, d)
+                assert np.any(got_rows != 0) or hi == lo

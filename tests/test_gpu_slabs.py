@@ -1,0 +1,191 @@
+"""The engine's multi-slab step on ONE GPU: K engines of this process, joined by
+the in-process transport (wv_comm_init_local) and stepped together (wv_run_group), run exactly the
+step the one-rank-per-GPU RCCL chain runs -- wait for ghosts, face planes (sweep + boundary nodes),
+exchange, interior planes -- only the face planes travel by device-to-device copies instead of
+ncclSend/ncclRecv.  Owned planes, filter memories and receiver traces must equal the single-domain
+engine bit for bit (and, through tests/test_gpu_parity.py, the oracle)."""
+import numpy as np
+import pytest
+
+from wayverb_amd import engine as E
+from wayverb_amd import mesh as M
+from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def materials(rng):
+    return np.concatenate([M.passive_peak_filter_coefficients(rng, 4),
+                           np.array([M.rigid_coefficients(), M.flat_coefficients(0.2)], dtype=M.coefficients_dtype)])
+
+
+def global_mesh(dims, room, rng):
+    coeffs = materials(rng)
+    if room == "box":
+        return M.box_mesh(*dims, coefficients=coeffs, surface_of_face=[0, 1, 2, 3, 4, 5])
+    mask = M.room_mask((dims[2], dims[1], dims[0]), room, seed=5)
+    nodes, counts = E.classify_nodes(mask)
+    return M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=[0, 1, 2, 3, 4, 5])
+
+
+def single_domain(gmesh, precision, gprev, gcur, kind, source, signal, receivers, steps):
+    eng = E.Engine(gmesh, precision=precision)
+    eng.write_field(gprev, E.BUF_PREVIOUS)
+    eng.write_field(gcur, E.BUF_CURRENT)
+    eng.set_source(kind, source, signal)
+    eng.set_receivers(receivers)
+    done, flag = eng.run_steps(steps)
+    out = dict(done=done, flag=flag, trace=eng.fetch_receivers(0, done), cur=eng.read_field(E.BUF_CURRENT),
+               prev=eng.read_field(E.BUF_PREVIOUS), bd=[eng.read_boundary_data(d) for d in (1, 2, 3)])
+    eng.close()
+    return out
+
+
+def slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps, ghost_readers=()):
+    """`ghost_readers`: receiver positions that are recorded by EVERY slab that holds the node, ghost
+    copies included (what a directional receiver on a slab face does with its +-z neighbour)."""
+    engines, layouts, recv_maps = [], [], []
+    for r in range(world):
+        L = SlabLayout(gmesh.dims, r, world)
+        e = E.Engine(slab_mesh(gmesh, L), precision=precision, ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi)
+        plane = L.plane
+        e.write_field(gprev[L.zl0 * plane:L.zl1 * plane], E.BUF_PREVIOUS)
+        e.write_field(gcur[L.zl0 * plane:L.zl1 * plane], E.BUF_CURRENT)
+        src_local, mine = place_source_and_receivers(L, source, receivers)
+        for pos in ghost_readers:
+            loc = L.to_local(receivers[pos])
+            if loc is not None and not L.owns_z(receivers[pos] // plane):
+                mine.append((pos, loc))
+        if src_local is not None:
+            e.set_source(kind, src_local, signal)
+        e.set_receivers([idx for _, idx in mine])
+        engines.append(e)
+        layouts.append(L)
+        recv_maps.append(mine)
+    group = E.LocalSlabGroup(engines)
+    done, flag = group.run_steps(steps)
+    trace = np.full((done, len(receivers)), np.nan)
+    ghost_trace = {}
+    cur, prev, bd = [], [], [[], [], []]
+    for e, L, mine in zip(engines, layouts, recv_maps):
+        assert e.step_count() == done
+        got = e.fetch_receivers(0, done)
+        for col, (pos, _) in enumerate(mine):
+            if L.owns_z(receivers[pos] // L.plane):
+                trace[:, pos] = got[:, col]
+            else:
+                ghost_trace.setdefault(pos, []).append(got[:, col])
+        lo, hi = L.owned_local_range()
+        cur.append(e.read_field(E.BUF_CURRENT)[lo:hi])
+        prev.append(e.read_field(E.BUF_PREVIOUS)[lo:hi])
+        for d in range(3):
+            bd[d].append(e.read_boundary_data(d + 1))
+    group.close()
+    return dict(done=done, flag=flag, trace=trace, ghost_trace=ghost_trace, cur=np.concatenate(cur),
+                prev=np.concatenate(prev), bd=[np.concatenate(b) for b in bd])
+
+
+def boundary_rows(gmesh, d):
+    """Rows of the global boundary array of dimensionality d, in node order (slabs keep one row per
+    boundary node; the global array may also hold the unused rows numbered for re-entrant nodes)."""
+    t = gmesh.nodes["boundary_type"]
+    pc = sum(((t >> bit) & 1) for bit in range(8))
+    is_b = (t & (M.ID_INSIDE | M.ID_REENTRANT)) == 0
+    return gmesh.nodes["boundary_index"][(pc == d) & is_b]
+
+
+def assert_same(got, want, gmesh):
+    assert (got["done"], got["flag"]) == (want["done"], want["flag"])
+    assert got["cur"].tobytes() == want["cur"].tobytes(), "current differs"
+    assert got["prev"].tobytes() == want["prev"].tobytes(), "previous differs"
+    assert got["trace"].tobytes() == want["trace"].tobytes(), "receiver traces differ"
+    for pos, copies in got["ghost_trace"].items():
+        for c in copies:
+            assert c.tobytes() == want["trace"][:, pos].tobytes(), "a ghost copy of receiver %d differs" % pos
+    for d in range(3):
+        rows = boundary_rows(gmesh, d + 1)
+        for field in ("filter_memory", "coefficient_index"):
+            assert got["bd"][d][field].tobytes() == np.ascontiguousarray(want["bd"][d][rows][field]).tobytes(), \
+                "filter state differs (D=%d, %s)" % (d + 1, field)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("world,room,dims", [(2, "box", (16, 14, 24)), (3, "box", (40, 36, 25)), (8, "box", (16, 14, 24)),
+                                             (2, "L", (20, 18, 24)), (3, "blob", (24, 22, 26)), (8, "L", (36, 20, 48))])
+def test_slab_chain_equals_single_domain(built_library, world, room, dims, precision):
+    rng = np.random.default_rng(2024 + world)
+    gmesh = global_mesh(dims, room, rng)
+    dtype = np.float32 if precision == "f32" else np.float64
+    live = gmesh.nodes["boundary_type"] != 0
+    gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    steps = 23
+    signal = rng.uniform(-0.1, 0.1, steps)
+    # the source on a slab face (top owned plane of slab 0): the neighbour's ghost copy must inject too
+    L0 = SlabLayout(dims, 0, world)
+    inside = (gmesh.nodes["boundary_type"] & M.ID_INSIDE) != 0
+    def first_inside(z):
+        idx = np.nonzero(inside[z * L0.plane:(z + 1) * L0.plane])[0]
+        return int(z * L0.plane + idx[len(idx) // 2])
+    source = first_inside(L0.z1 - 1)
+    # receivers: the 7 nodes of a directional receiver centred on the bottom owned plane of slab 1
+    # (its -z neighbour is slab 1's ghost plane), plus one node per slab
+    L1 = SlabLayout(dims, 1, world)
+    centre = first_inside(L1.z0)
+    receivers = [centre] + [n for n in gmesh.compute_neighbors(centre)]
+    assert all(n != 0xFFFFFFFF for n in receivers)
+    for r in range(world):
+        L = SlabLayout(dims, r, world)
+        receivers.append(first_inside(min(max(L.z0, 2), dims[2] - 3)))
+    for kind in (E.SOURCE_SOFT, E.SOURCE_HARD):
+        want = single_domain(gmesh, precision, gprev, gcur, kind, source, signal, receivers, steps)
+        got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps,
+                         ghost_readers=range(7))
+        assert want["done"] == steps and want["flag"] == 0
+        assert_same(got, want, gmesh)
+        assert len(got["ghost_trace"]) >= 1          # at least the -z neighbour was read from a ghost plane
+
+
+def test_a_flag_on_one_slab_stops_the_whole_chain(built_library):
+    """SURVEY.md 8(e) "error-flag OR": waveguide.h:100-119 throws on the step that produced the value;
+    here every slab must stop there, not only the one that saw it."""
+    dims = (16, 14, 24)
+    gmesh = M.box_mesh(*dims)
+    sig = np.zeros(40)
+    sig[0] = 1.0
+    sig[17] = np.inf
+    source = gmesh.compute_index(8, 7, 3)             # lives on slab 0 of 3
+    zeros = np.zeros(gmesh.num_nodes)
+    want = single_domain(gmesh, "f64", zeros, zeros, E.SOURCE_HARD, source, sig, [gmesh.compute_index(8, 7, 20)], 40)
+    got = slab_chain(gmesh, 3, "f64", zeros, zeros, E.SOURCE_HARD, source, sig, [gmesh.compute_index(8, 7, 20)], 40)
+    assert want["done"] == 17 and want["flag"] & M.ERR_INF
+    assert got["done"] == 17 and got["flag"] & M.ERR_INF
+    assert got["trace"].tobytes() == want["trace"].tobytes()
+
+
+def test_grouped_slabs_refuse_to_be_stepped_alone(built_library):
+    gmesh = M.box_mesh(12, 12, 12)
+    engines = []
+    for r in range(2):
+        L = SlabLayout(gmesh.dims, r, 2)
+        engines.append(E.Engine(slab_mesh(gmesh, L), ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi))
+    group = E.LocalSlabGroup(engines)
+    with pytest.raises(E.WaveguideError, match="wv_run_group"):
+        engines[0].run_steps(2)
+    assert group.run_steps(4) == (4, 0)
+    group.close()
+
+
+def test_exhausted_source_ends_a_chain(built_library):
+    gmesh = M.box_mesh(12, 12, 12)
+    engines = []
+    for r in range(3):
+        L = SlabLayout(gmesh.dims, r, 3)
+        e = E.Engine(slab_mesh(gmesh, L), ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi)
+        src = L.to_local(gmesh.compute_index(6, 6, 6))
+        if src is not None:
+            e.set_source(E.SOURCE_HARD, src, np.ones(5))
+        engines.append(e)
+    group = E.LocalSlabGroup(engines)
+    assert group.run_steps(100) == (5, 0)
+    group.close()

@@ -1,5 +1,5 @@
 """`.way` bundles (config.json as cereal writes it + model.model): the reader against a sample bundle
-written for this test, and -- when the reference tree is present -- against its concert-hall demo."""
+written for this test, and against the reference's concert-hall demo bundle (tests/golden/concert.way)."""
 import os
 
 import numpy as np
@@ -9,7 +9,7 @@ from wayverb_amd import wayfile as W
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SAMPLE = os.path.join(HERE, "golden", "sample.way")
-REF_DEMO = "/root/reference/demo/evaluation/receivers/concert.way"
+CONCERT = os.path.join(HERE, "golden", "concert.way")   # the reference's concert-hall demo bundle, committed as data
 
 
 def test_sample_bundle():
@@ -28,10 +28,9 @@ def test_sample_bundle():
     assert absorptions[0] == [0.05] * 8 and absorptions[1][3] == 0.65
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_DEMO), reason="needs /root/reference")
 def test_reference_concert_hall_bundle():
     """BASELINE configs[4]: the facts SURVEY.md App. E lists for the concert-hall demo."""
-    cfg, v, t, absorptions = W.read_way(REF_DEMO)
+    cfg, v, t, absorptions = W.read_way(CONCERT)
     assert len(cfg["sources"]) == 1 and np.allclose(cfg["sources"][0]["position"], [0, 0, 0], atol=1e-5)
     assert np.allclose(cfg["receivers"][0]["position"], [0, 1.47, -20.06], atol=1e-5)
     cap = cfg["receivers"][0]["capsules"][0]
@@ -44,10 +43,9 @@ def test_reference_concert_hall_bundle():
     assert v.shape[0] == 214 and t.shape[0] == 322 and len(absorptions) == 1
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_DEMO), reason="needs /root/reference")
 def test_concert_hall_configuration_builds_and_steps_on_the_cpu_chain(oracle, built_library):
-    """BASELINE configs[4] up to the hot path, through the CPU restatements (the GPU box has no
-    reference tree): bundle -> adjusted boundary around the receiver -> inside flags -> node types
+    """BASELINE configs[4] up to the hot path, through the CPU restatements (tests/test_gpu_concert.py does the same on
+    the GPU): bundle -> adjusted boundary around the receiver -> inside flags -> node types
     -> surfaces per filter -> designed wall filters -> 60 oracle steps from the calibrated impulse.
     Source and receiver land on inside nodes and the run raises no error flag."""
     from helpers import run_oracle
@@ -56,7 +54,7 @@ def test_concert_hall_configuration_builds_and_steps_on_the_cpu_chain(oracle, bu
     from wayverb_amd import mesh as M
     from wayverb_amd import scene as S
     from wayverb_amd import simulation as sim
-    cfg, v, t, absorptions = W.read_way(REF_DEMO)
+    cfg, v, t, absorptions = W.read_way(CONCERT)
     wg = cfg["waveguide"]["single"]
     fs = sim.compute_sampling_frequency(wg["cutoff"], wg["usable_portion"])
     spacing = np.float32(sim.grid_spacing(340.0, 1.0 / fs))

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 
 namespace wv {
@@ -19,6 +20,7 @@ typedef int (*CommDestroyFn)(void*);
 typedef int (*GroupFn)(void);
 typedef int (*SendFn)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*RecvFn)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*ErrStrFn)(int);
 
 struct Rccl {
@@ -29,11 +31,14 @@ struct Rccl {
     GroupFn group_start = nullptr, group_end = nullptr;
     SendFn send = nullptr;
     RecvFn recv = nullptr;
+    AllReduceFn all_reduce = nullptr;
     ErrStrFn err_str = nullptr;
     std::string load_error;
 };
 
-constexpr int kNcclInt8 = 0;  // ncclInt8 / ncclChar
+constexpr int kNcclInt8 = 0;    // ncclInt8 / ncclChar
+constexpr int kNcclUint64 = 5;  // ncclUint64
+constexpr int kNcclSum = 0;     // ncclSum
 
 Rccl& rccl() {
     static Rccl r;
@@ -55,9 +60,10 @@ Rccl& rccl() {
         r.group_end = (GroupFn)dlsym(r.handle, "ncclGroupEnd");
         r.send = (SendFn)dlsym(r.handle, "ncclSend");
         r.recv = (RecvFn)dlsym(r.handle, "ncclRecv");
+        r.all_reduce = (AllReduceFn)dlsym(r.handle, "ncclAllReduce");
         r.err_str = (ErrStrFn)dlsym(r.handle, "ncclGetErrorString");
         if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.group_start || !r.group_end ||
-            !r.send || !r.recv || !r.err_str)
+            !r.send || !r.recv || !r.all_reduce || !r.err_str)
             r.load_error = "librccl is missing an expected symbol";
     });
     return r;
@@ -73,6 +79,29 @@ bool hip_ok(hipError_t rc, const char* what, std::string* err) {
     if (rc == hipSuccess) return true;
     *err = std::string(what) + ": " + hipGetErrorString(rc);
     return false;
+}
+
+// RCCL has no bitwise-OR reduction.  The error_code word has 5 bits (cl/structs.h:8-15): bit b goes
+// to a 12-bit counter at bit 12*b of a 64-bit word, the words are summed over the ranks (no carry
+// into the next counter below 4096 ranks), and a non-zero counter is a set bit again.
+constexpr int kFlagBits = 5, kFlagField = 12;
+
+__global__ void flag_spread_kernel(const int* flags, uint64_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = 0;
+    for (int b = 0; b < kFlagBits; ++b)
+        if ((flags[i] >> b) & 1) v |= 1ull << (kFlagField * b);
+    out[i] = v;
+}
+
+__global__ void flag_gather_kernel(const uint64_t* in, int* flags, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = 0;
+    for (int b = 0; b < kFlagBits; ++b)
+        if ((in[i] >> (kFlagField * b)) & ((1ull << kFlagField) - 1)) f |= 1 << b;
+    flags[i] = f;
 }
 
 }  // namespace
@@ -122,26 +151,116 @@ bool SlabComm::init(const void* id_bytes128, int rank, int nranks, int device, h
     return true;
 }
 
+bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_stream, bool has_lo, bool has_hi,
+                          std::string* err) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) {
+        *err = "rank outside [0, nranks)";
+        return false;
+    }
+    if (has_lo != (rank > 0) || has_hi != (rank + 1 < nranks)) {
+        *err = "ghost_lo/ghost_hi of the engine do not match its position in the slab chain";
+        return false;
+    }
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice", err)) return false;
+    local_ = true;
+    rank_ = rank;
+    nranks_ = nranks;
+    has_lo_ = has_lo;
+    has_hi_ = has_hi;
+    stream_ = comm_stream;
+    for (hipEvent_t* e : {&faces_ready_, &ghosts_ready_, &pushed_lo_, &pushed_hi_, &step_done_})
+        if (!hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    return true;
+}
+
+void SlabComm::set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz) {
+    n_fields_ = n_fields < 4 ? n_fields : 4;
+    for (int i = 0; i < n_fields_; ++i) fields_[i] = fields[i];
+    plane_bytes_ = plane_bytes;
+    nz_ = nz;
+}
+
 SlabComm::~SlabComm() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (comm_) (void)rccl().comm_destroy(comm_);
-    if (faces_ready_) (void)hipEventDestroy(faces_ready_);
-    if (ghosts_ready_) (void)hipEventDestroy(ghosts_ready_);
+    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_, pushed_hi_, step_done_})
+        if (e) (void)hipEventDestroy(e);
+    if (spread_) (void)hipFree(spread_);
+    // a local chain is torn down as a whole (wv_comm_destroy on every engine); unlink anyway
+    if (lo_ && lo_->hi_ == this) lo_->hi_ = nullptr;
+    if (hi_ && hi_->lo_ == this) hi_->lo_ = nullptr;
 }
 
 bool SlabComm::wait_ghosts(hipStream_t compute, std::string* err) {
+    if (local_) {
+        // my ghost planes are written by the neighbours' pushes
+        if (lo_ && lo_->pushed_hi_set_ &&
+            !hip_ok(hipStreamWaitEvent(compute, lo_->pushed_hi_, 0), "hipStreamWaitEvent", err))
+            return false;
+        if (hi_ && hi_->pushed_lo_set_ &&
+            !hip_ok(hipStreamWaitEvent(compute, hi_->pushed_lo_, 0), "hipStreamWaitEvent", err))
+            return false;
+        return true;
+    }
     if (!pending_) return true;
     return hip_ok(hipStreamWaitEvent(compute, ghosts_ready_, 0), "hipStreamWaitEvent", err);
 }
 
-bool SlabComm::exchange_faces(hipStream_t compute, hipEvent_t also, void* field, size_t elem_size, int nx, int ny,
-                              int nz, std::string* err) {
-    Rccl& r = rccl();
-    const size_t plane_bytes = (size_t)nx * ny * elem_size;
-    char* base = static_cast<char*>(field);
+bool SlabComm::step_done(hipStream_t compute, std::string* err) {
+    if (!local_) return true;  // RCCL: the matching ncclRecv is issued by this rank itself, in stream order
+    step_done_set_ = true;
+    return hip_ok(hipEventRecord(step_done_, compute), "hipEventRecord", err);
+}
+
+bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) {
+    if (field < 0 || field >= n_fields_ || !fields_[field] || nz_ < 3) {
+        *err = "exchange_faces: no such field buffer";
+        return false;
+    }
+    const size_t plane_bytes = plane_bytes_;
+    const int nz = nz_;
+    char* base = static_cast<char*>(fields_[field]);
     if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
     if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
-    if (also && !hip_ok(hipStreamWaitEvent(stream_, also, 0), "hipStreamWaitEvent", err)) return false;
+    if (local_) {
+        // push my face planes into the neighbours' ghost planes of the same buffer.  The neighbour
+        // may still be reading that ghost plane (it was part of its `current` one step ago): wait
+        // for the end of its last enqueued step.  Lockstep driving (wv_run_group) guarantees that
+        // every event waited for here has been recorded in host order.
+        if (has_lo_ && lo_) {
+            if (lo_->step_done_set_ &&
+                !hip_ok(hipStreamWaitEvent(stream_, lo_->step_done_, 0), "hipStreamWaitEvent", err))
+                return false;
+            char* dst = static_cast<char*>(lo_->fields_[field]) + (size_t)(lo_->nz_ - 1) * lo_->plane_bytes_;
+            if (lo_->plane_bytes_ != plane_bytes) {
+                *err = "neighbouring slabs disagree about the plane size";
+                return false;
+            }
+            if (!hip_ok(hipMemcpyAsync(dst, base + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, stream_),
+                        "hipMemcpyAsync", err))
+                return false;
+            if (!hip_ok(hipEventRecord(pushed_lo_, stream_), "hipEventRecord", err)) return false;
+            pushed_lo_set_ = true;
+        }
+        if (has_hi_ && hi_) {
+            if (hi_->step_done_set_ &&
+                !hip_ok(hipStreamWaitEvent(stream_, hi_->step_done_, 0), "hipStreamWaitEvent", err))
+                return false;
+            if (hi_->plane_bytes_ != plane_bytes) {
+                *err = "neighbouring slabs disagree about the plane size";
+                return false;
+            }
+            char* dst = static_cast<char*>(hi_->fields_[field]);
+            if (!hip_ok(hipMemcpyAsync(dst, base + (size_t)(nz - 2) * plane_bytes, plane_bytes, hipMemcpyDeviceToDevice,
+                                       stream_),
+                        "hipMemcpyAsync", err))
+                return false;
+            if (!hip_ok(hipEventRecord(pushed_hi_, stream_), "hipEventRecord", err)) return false;
+            pushed_hi_set_ = true;
+        }
+        return true;
+    }
+    Rccl& r = rccl();
     if (loopback_) {
         // sends and receives to the same peer pair up in issue order
         if (!nccl_ok(r.group_start(), "ncclGroupStart", err)) return false;
@@ -173,6 +292,21 @@ bool SlabComm::exchange_faces(hipStream_t compute, hipEvent_t also, void* field,
     if (!hip_ok(hipEventRecord(ghosts_ready_, stream_), "hipEventRecord", err)) return false;
     pending_ = true;
     return true;
+}
+
+bool SlabComm::or_flags(hipStream_t stream, int* flags, int n, std::string* err) {
+    if (local_ || loopback_ || nranks_ < 2 || n <= 0) return true;
+    if (n > kMaxFlags || nranks_ >= (1 << kFlagField)) {
+        *err = "or_flags: too many flag words or ranks";
+        return false;
+    }
+    if (!spread_ && !hip_ok(hipMalloc((void**)&spread_, kMaxFlags * sizeof(uint64_t)), "hipMalloc", err)) return false;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(flag_spread_kernel, dim3(grid), dim3(256), 0, stream, (const int*)flags, spread_, n);
+    if (!nccl_ok(rccl().all_reduce(spread_, spread_, (size_t)n, kNcclUint64, kNcclSum, comm_, stream), "ncclAllReduce", err))
+        return false;
+    hipLaunchKernelGGL(flag_gather_kernel, dim3(grid), dim3(256), 0, stream, (const uint64_t*)spread_, flags, n);
+    return hip_ok(hipGetLastError(), "flag OR kernels", err);
 }
 
 }  // namespace wv

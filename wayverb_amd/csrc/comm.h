@@ -1,18 +1,25 @@
-// comm.h -- z-slab ghost-plane exchange over RCCL (xGMI), one rank per GPU.
+// comm.h -- z-slab ghost-plane exchange, one slab per engine.
 //
 // New design (the reference is single-device).  Memory order is x-fastest,
 // z-slowest (src/waveguide/src/cl/utils.cpp:33-36), so a slab's face plane and a ghost plane are
 // each one contiguous nx*ny run.  Per step, after the two face planes of the new field are
-// final, each rank sends them to its z-1 / z+1 neighbours' ghost planes in one grouped
-// ncclSend/ncclRecv on a dedicated stream while the interior planes are still being updated on
-// the compute stream.  Slab chain = nearest neighbour only: at most 2 of a GPU's 7 xGMI links.
+// final, each slab hands them to its z-1 / z+1 neighbours' ghost planes on a dedicated stream
+// while the interior planes are still being updated on the compute stream.  Slab chain = nearest
+// neighbour only: at most 2 of a GPU's 7 xGMI links.
 //
-// RCCL is resolved at run time (dlopen) so that a process that already loaded a librccl
-// (e.g. through torch.distributed) shares that copy.
+// Two transports behind the same calls (the engine's step is the same code for both):
+//   RCCL   one rank per process / GPU: grouped ncclSend/ncclRecv over xGMI.  RCCL is resolved at
+//          run time (dlopen) so that a process that already loaded a librccl (e.g. through
+//          torch.distributed) shares that copy.
+//   local  all slabs of the chain are engines of THIS process (wv_comm_init_local): device-to-device
+//          copies into the neighbour's ghost plane, ordered with events.  The engines must then be
+//          stepped in lockstep from one host thread (wv_run_group), which is what makes every
+//          event wait refer to a record that has already been enqueued.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdint>
 #include <string>
 
 namespace wv {
@@ -28,26 +35,53 @@ public:
 
     bool init(const void* id_bytes128, int rank, int nranks, int device, hipStream_t comm_stream,
               bool has_lo, bool has_hi, std::string* err);
+    bool init_local(int rank, int nranks, int device, hipStream_t comm_stream, bool has_lo, bool has_hi,
+                    std::string* err);
+    // local transport: the neighbouring slabs' communicators (null at the ends of the chain)
+    void link_local(SlabComm* lo, SlabComm* hi) {
+        lo_ = lo;
+        hi_ = hi;
+    }
+    // The engine's field buffers: base pointers, bytes per plane, planes (ghosts included).
+    void set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz);
 
     // The compute stream must not read ghost planes before the previous exchange has landed.
     bool wait_ghosts(hipStream_t compute, std::string* err);
-    // Faces of `field` (planes 1 and nz-2 when the matching ghost exists) are final on `compute`:
-    // exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
-    // `also` (may be null): a second event the exchange has to wait for (boundary-node stream).
-    bool exchange_faces(hipStream_t compute, hipEvent_t also, void* field, size_t elem_size, int nx, int ny, int nz,
-                        std::string* err);
+    // Faces of field buffer `field` (planes 1 and nz-2 when the matching ghost exists) are final on
+    // `compute`: exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
+    bool exchange_faces(hipStream_t compute, int field, std::string* err);
+    // End of a step on `compute`: this slab has read the ghost planes of the step's `current` field
+    // (the local transport may overwrite them once this has passed).
+    bool step_done(hipStream_t compute, std::string* err);
+    // flags[i] <- bitwise OR of flags[i] over all ranks, i < n <= kMaxFlags, ordered on `stream`.
+    // (RCCL transport; a local group is OR-ed on the host by wv_run_group.)  SURVEY.md 8(e)
+    // "error-flag OR": one rank's NaN must stop every rank at the same step.
+    static constexpr int kMaxFlags = 1024;
+    bool or_flags(hipStream_t stream, int* flags, int n, std::string* err);
 
     int rank() const { return rank_; }
     int nranks() const { return nranks_; }
+    bool is_local() const { return local_; }
 
 private:
     void* comm_ = nullptr;
     int rank_ = 0, nranks_ = 1;
-    bool has_lo_ = false, has_hi_ = false, loopback_ = false;
+    bool has_lo_ = false, has_hi_ = false, loopback_ = false, local_ = false;
     hipStream_t stream_ = nullptr;
     hipEvent_t faces_ready_ = nullptr;
     hipEvent_t ghosts_ready_ = nullptr;
     bool pending_ = false;
+    // field geometry
+    void* fields_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_fields_ = 0, nz_ = 0;
+    size_t plane_bytes_ = 0;
+    // local transport
+    SlabComm *lo_ = nullptr, *hi_ = nullptr;
+    hipEvent_t pushed_lo_ = nullptr, pushed_hi_ = nullptr;  // my face has landed in the lower / upper neighbour
+    hipEvent_t step_done_ = nullptr;
+    bool pushed_lo_set_ = false, pushed_hi_set_ = false, step_done_set_ = false;
+    // flag OR
+    uint64_t* spread_ = nullptr;
 };
 
 }  // namespace wv

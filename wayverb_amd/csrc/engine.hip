@@ -97,6 +97,8 @@ struct wv_engine {
     virtual int write_value(int buffer, uint64_t index, double v) = 0;
     virtual int read_field(int buffer, void* dst, int elem_size) = 0;
     virtual int write_field(int buffer, const void* src, int elem_size) = 0;
+    virtual int read_planes(int buffer, int z0, int planes, void* dst, int elem_size) = 0;
+    virtual int write_planes(int buffer, int z0, int planes, const void* src, int elem_size) = 0;
     virtual int boundary_data(int dim, wv_boundary_data* host, bool to_device) = 0;
     virtual int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) = 0;
     virtual int device_buffer(int buffer, void** p) = 0;
@@ -110,7 +112,15 @@ struct wv_engine {
     virtual int synchronize() = 0;
     virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
+    virtual int comm_init_local(int rank, int nranks) = 0;
+    virtual wv::SlabComm* comm() = 0;
     virtual int comm_destroy() = 0;
+    // a batch of steps in parts, so that a group of slabs can be driven in lockstep (wv_run_group)
+    virtual uint64_t plan_batch(uint64_t remaining) = 0;
+    virtual int enqueue_batch_step(uint64_t i, uint64_t batch) = 0;
+    virtual int collect_batch(uint64_t batch) = 0;
+    virtual const int* batch_flags() const = 0;
+    virtual int commit_batch(uint64_t batch, const int* flags, uint64_t* good, int32_t* flag) = 0;
     virtual uint64_t field_pitch() const = 0;
     uint64_t steps_done = 0;
     bool timing = false;
@@ -724,8 +734,7 @@ public:
             if ((rc = launch_boundary(prev, cur, flag, z_begin_, zi0))) return rc;
             if ((rc = launch_boundary(prev, cur, flag, zi1, z_end_))) return rc;
             WV_HIP(hipGetLastError());
-            if (!comm_->exchange_faces(stream_, nullptr, prev, sizeof(Real), pitch_, ny_, nz_, &cerr))
-                return fail(WV_E_COMM, cerr);
+            if (!comm_->exchange_faces(stream_, cur_ ^ 1, &cerr)) return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
             if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
         } else {
@@ -740,6 +749,7 @@ public:
             }
         }
         WV_HIP(hipGetLastError());
+        if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
         if (outside_dirty_ > 0 && outside_dirty_ < (1 << 30)) --outside_dirty_;
         return WV_OK;
@@ -818,21 +828,80 @@ public:
         return WV_OK;
     }
 
+    // ---- a batch of steps: plan / enqueue / collect / commit ---------------------------------------
+    // How many of `remaining` steps the next batch may take (0: the source signal is exhausted, which
+    // ends the run -- hard_source.h:18-20 returns false).
+    uint64_t plan_batch(uint64_t remaining) override {
+        DeviceGuard guard(device_);
+        const uint64_t interval = opt_.flag_interval > 0 ? (uint64_t)opt_.flag_interval : (uint64_t)kRing;
+        uint64_t batch = std::min<uint64_t>(std::min<uint64_t>(interval, kRing), remaining);
+        if (source_kind_ != WV_SOURCE_NONE) {
+            const uint64_t left = signal_len_ - std::min(signal_len_, signal_pos_);
+            batch = std::min(batch, left);
+        }
+        batch_can_fuse_ = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
+        batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
+        return batch;
+    }
+
+    int enqueue_batch_step(uint64_t i, uint64_t batch) override {
+        DeviceGuard guard(device_);
+        const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_, batch_can_fuse_ && i + 1 < batch);
+        if (rc) return rc;
+        cur_ ^= 1;
+        return WV_OK;
+    }
+
+    // Flag words and receiver rows of the batch to the host.  On an RCCL slab chain the flag words are
+    // OR-ed over the ranks first, so that every rank sees the same first failing step and none is left
+    // waiting in a receive (waveguide.h:100-119 stops the one and only device; here all of them stop).
+    int collect_batch(uint64_t batch) override {
+        DeviceGuard guard(device_);
+        std::string cerr;
+        if (comm_ && !comm_->or_flags(stream_, flags_, (int)batch, &cerr)) return fail(WV_E_COMM, cerr);
+        WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (n_recv_) {
+            recv_stage_.resize((size_t)batch * n_recv_);
+            WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real), hipMemcpyDeviceToHost,
+                                  stream_));
+        }
+        WV_HIP(hipStreamSynchronize(stream_));
+        return drain_timing();
+    }
+    const int* batch_flags() const override { return flags_host_; }
+
+    // `flags[batch]`: this engine's flag words, or their OR over a group of slabs.
+    int commit_batch(uint64_t batch, const int* flags, uint64_t* good_out, int32_t* flag_out) override {
+        uint64_t good = batch;
+        int32_t flag = 0;
+        for (uint64_t i = 0; i < batch; ++i) {
+            if (flags[i]) {
+                good = i;
+                flag = flags[i];
+                break;
+            }
+        }
+        if (n_recv_)
+            for (size_t i = 0; i < (size_t)good * n_recv_; ++i) recv_log_.push_back((double)recv_stage_[i]);
+        steps_done += good;
+        signal_pos_ += good;
+        // fields have advanced past a failing step: like the reference after its throw, the state is
+        // no longer meaningful; keep the buffer roles consistent with `good` swaps
+        if (flag && good < batch && ((batch - good) & 1)) cur_ ^= 1;
+        *good_out = good;
+        *flag_out = flag;
+        return WV_OK;
+    }
+
     int run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) override {
         DeviceGuard guard(device_);
+        if (comm_ && comm_->is_local() && comm_->nranks() > 1)
+            return fail(WV_E_STATE, "slabs joined by wv_comm_init_local are stepped together: use wv_run_group");
         uint64_t completed = 0;
         int32_t flag = 0;
-        const uint64_t interval = opt_.flag_interval > 0 ? (uint64_t)opt_.flag_interval : (uint64_t)kRing;
         while (completed < n_steps && flag == 0) {
-            uint64_t batch = std::min<uint64_t>(std::min<uint64_t>(interval, kRing), n_steps - completed);
-            // an exhausted source ends the run (hard_source.h:18-20 returns false)
-            if (source_kind_ != WV_SOURCE_NONE) {
-                const uint64_t left = signal_len_ - std::min(signal_len_, signal_pos_);
-                if (left == 0) break;
-                batch = std::min(batch, left);
-            }
-            const bool can_fuse = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
-            const bool source_live = source_kind_ != WV_SOURCE_NONE;
+            const uint64_t batch = plan_batch(n_steps - completed);
+            if (batch == 0) break;
             // Small meshes are bound by launches, not bytes: a full batch of steps is captured once
             // into a hipGraph and replayed (the only thing that differs between batches, the
             // position in the source signal, comes from a device scalar).  Even batch lengths only,
@@ -840,43 +909,19 @@ public:
             const bool use_graph = graph_mode_ != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
                                    stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
             if (use_graph) {
-                int rc = replay_batch(batch, source_live, can_fuse);
+                int rc = replay_batch(batch, batch_source_live_, batch_can_fuse_);
                 if (rc) return rc;
             } else {
                 for (uint64_t i = 0; i < batch; ++i) {
-                    int rc = enqueue_step((int)i, true, signal_pos_ + i, source_live, can_fuse && i + 1 < batch);
+                    int rc = enqueue_batch_step(i, batch);
                     if (rc) return rc;
-                    cur_ ^= 1;
                 }
             }
-            WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
-            if (n_recv_) {
-                recv_stage_.resize((size_t)batch * n_recv_);
-                WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real),
-                                      hipMemcpyDeviceToHost, stream_));
-            }
-            WV_HIP(hipStreamSynchronize(stream_));
-            int rc = drain_timing();
+            int rc = collect_batch(batch);
             if (rc) return rc;
-            uint64_t good = batch;
-            for (uint64_t i = 0; i < batch; ++i) {
-                if (flags_host_[i]) {
-                    good = i;
-                    flag = flags_host_[i];
-                    break;
-                }
-            }
-            if (n_recv_) {
-                for (size_t i = 0; i < (size_t)good * n_recv_; ++i) recv_log_.push_back((double)recv_stage_[i]);
-            }
+            uint64_t good = 0;
+            if ((rc = commit_batch(batch, flags_host_, &good, &flag))) return rc;
             completed += good;
-            steps_done += good;
-            signal_pos_ += good;
-            if (flag && good < batch) {
-                // fields have advanced past the failing step: like the reference after its throw,
-                // the state is no longer meaningful; keep buffer roles consistent with `good` swaps
-                if ((batch - good) & 1) cur_ ^= 1;
-            }
         }
         if (done) *done = completed;
         if (flag_out) *flag_out = flag;
@@ -1019,8 +1064,8 @@ public:
     // host field (compact: nx per row, element type Other) <-> stored field (pitch per row, Real),
     // staged through a bounded device buffer in whole rows
     template <typename Other>
-    int copy_field(Real* stored, void* host, bool to_device) {
-        const int64_t rows_total = (int64_t)ny_ * nz_;
+    int copy_field(Real* stored, void* host, bool to_device, int z0, int planes) {
+        const int64_t row0 = (int64_t)z0 * ny_, rows_total = (int64_t)planes * ny_;
         const int64_t rows_per_chunk = std::max<int64_t>(1, (64ll << 20) / nx_);
         ScopedDevice tmp_mem;
         WV_HIP(hipMalloc(&tmp_mem.p, (size_t)std::min(rows_per_chunk, rows_total) * nx_ * sizeof(Other)));
@@ -1030,7 +1075,7 @@ public:
             const int64_t n = rows * nx_;
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
             Other* h = static_cast<Other*>(host) + row * nx_;
-            Real* d = stored + row * pitch_;
+            Real* d = stored + (row0 + row) * pitch_;
             if (to_device) {
                 WV_HIP(hipMemcpyAsync(tmp, h, (size_t)n * sizeof(Other), hipMemcpyHostToDevice, stream_));
                 hipLaunchKernelGGL((wv::pack_rows_kernel<Real, Other>), dim3(grid), dim3(256), 0, stream_, d, pitch_,
@@ -1045,17 +1090,27 @@ public:
         return WV_OK;
     }
 
-    int read_field(int buffer_id, void* dst, int elem_size) override {
+    int read_field(int buffer_id, void* dst, int elem_size) override { return read_planes(buffer_id, 0, nz_, dst, elem_size); }
+    int write_field(int buffer_id, const void* src, int elem_size) override {
+        return write_planes(buffer_id, 0, nz_, src, elem_size);
+    }
+    int read_planes(int buffer_id, int z0, int planes, void* dst, int elem_size) override {
         DeviceGuard guard(device_);
-        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), dst, false);
-        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), dst, false);
+        if (z0 < 0 || planes < 0 || (int64_t)z0 + planes > nz_) return fail(WV_E_INVALID_ARGUMENT, "plane range outside the mesh");
+        if (!planes) return WV_OK;
+        if (!dst) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), dst, false, z0, planes);
+        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), dst, false, z0, planes);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
-    int write_field(int buffer_id, const void* src, int elem_size) override {
+    int write_planes(int buffer_id, int z0, int planes, const void* src, int elem_size) override {
         DeviceGuard guard(device_);
+        if (z0 < 0 || planes < 0 || (int64_t)z0 + planes > nz_) return fail(WV_E_INVALID_ARGUMENT, "plane range outside the mesh");
+        if (!planes) return WV_OK;
+        if (!src) return fail(WV_E_INVALID_ARGUMENT, "null argument");
         outside_dirty_ = std::max(outside_dirty_, 2);  // the caller may have put anything in the outside nodes
-        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true);
-        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true);
+        if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true, z0, planes);
+        if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true, z0, planes);
         return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
     }
 
@@ -1134,9 +1189,24 @@ public:
         std::string err;
         if (!c->init(id, rank, nranks, device_, comm_stream_, opt_.ghost_lo != 0, opt_.ghost_hi != 0, &err))
             return fail(WV_E_COMM, err);
+        return adopt_comm(std::move(c));
+    }
+    int comm_init_local(int rank, int nranks) override {
+        DeviceGuard guard(device_);
+        if (comm_) return fail(WV_E_STATE, "communicator already initialised");
+        std::unique_ptr<wv::SlabComm> c(new wv::SlabComm());
+        std::string err;
+        if (!c->init_local(rank, nranks, device_, comm_stream_, opt_.ghost_lo != 0, opt_.ghost_hi != 0, &err))
+            return fail(WV_E_COMM, err);
+        return adopt_comm(std::move(c));
+    }
+    int adopt_comm(std::unique_ptr<wv::SlabComm> c) {
+        void* fields[2] = {field_[0], field_[1]};
+        c->set_fields(fields, 2, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
         comm_ = std::move(c);
         return WV_OK;
     }
+    wv::SlabComm* comm() override { return comm_.get(); }
     uint64_t field_pitch() const override { return (uint64_t)pitch_; }
     int comm_destroy() override {
         DeviceGuard guard(device_);
@@ -1200,6 +1270,7 @@ private:
     int graph_mode_ = env_int("WV_GRAPH", 0);
     uint64_t graph_max_nodes_ = 64ull << 20;
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
+    bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
@@ -1298,6 +1369,14 @@ int wv_write_field(wv_engine* e, int buffer, const void* src, int elem_size) {
     WV_NEED(e);
     return e->write_field(buffer, src, elem_size);
 }
+int wv_read_planes(wv_engine* e, int buffer, int32_t z_begin, int32_t z_count, void* dst, int elem_size) {
+    WV_NEED(e);
+    return e->read_planes(buffer, z_begin, z_count, dst, elem_size);
+}
+int wv_write_planes(wv_engine* e, int buffer, int32_t z_begin, int32_t z_count, const void* src, int elem_size) {
+    WV_NEED(e);
+    return e->write_planes(buffer, z_begin, z_count, src, elem_size);
+}
 int wv_read_boundary_data(wv_engine* e, int dim, wv_boundary_data* dst) {
     WV_NEED(e);
     return e->boundary_data(dim, dst, false);
@@ -1372,6 +1451,57 @@ int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks) {
 int wv_comm_destroy(wv_engine* e) {
     WV_NEED(e);
     return e->comm_destroy();
+}
+
+int wv_comm_init_local(wv_engine* const* engines, int32_t n) {
+    if (!engines || n < 1) return fail(WV_E_INVALID_ARGUMENT, "no engines");
+    for (int i = 0; i < n; ++i) WV_NEED(engines[i]);
+    for (int i = 0; i < n; ++i) {
+        const int rc = engines[i]->comm_init_local(i, n);
+        if (rc != WV_OK) {
+            for (int k = 0; k < i; ++k) (void)engines[k]->comm_destroy();
+            return rc;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        engines[i]->comm()->link_local(i > 0 ? engines[i - 1]->comm() : nullptr, i + 1 < n ? engines[i + 1]->comm() : nullptr);
+    return WV_OK;
+}
+
+int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_t* steps_done, int32_t* flag_out) {
+    if (!engines || n < 1) return fail(WV_E_INVALID_ARGUMENT, "no engines");
+    for (int i = 0; i < n; ++i) WV_NEED(engines[i]);
+    uint64_t completed = 0;
+    int32_t flag = 0;
+    std::vector<int> ored;
+    while (completed < n_steps && flag == 0) {
+        // the shortest batch any slab allows (the slab that holds the source knows when it ends)
+        uint64_t batch = n_steps - completed;
+        for (int k = 0; k < n; ++k) batch = std::min(batch, engines[k]->plan_batch(n_steps - completed));
+        if (batch == 0) break;
+        // lockstep: step i of every slab is enqueued before step i + 1 of any (comm.h, local transport)
+        for (uint64_t i = 0; i < batch; ++i)
+            for (int k = 0; k < n; ++k) {
+                const int rc = engines[k]->enqueue_batch_step(i, batch);
+                if (rc) return rc;
+            }
+        ored.assign((size_t)batch, 0);
+        for (int k = 0; k < n; ++k) {
+            const int rc = engines[k]->collect_batch(batch);
+            if (rc) return rc;
+            const int* f = engines[k]->batch_flags();
+            for (uint64_t i = 0; i < batch; ++i) ored[(size_t)i] |= f[i];
+        }
+        uint64_t good = 0;
+        for (int k = 0; k < n; ++k) {
+            const int rc = engines[k]->commit_batch(batch, ored.data(), &good, &flag);
+            if (rc) return rc;
+        }
+        completed += good;
+    }
+    if (steps_done) *steps_done = completed;
+    if (flag_out) *flag_out = flag;
+    return WV_OK;
 }
 
 int wv_field_pitch(wv_engine* e, uint64_t* pitch_elements) {

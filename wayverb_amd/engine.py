@@ -24,11 +24,11 @@ UNIQUE_ID_BYTES = 128
 
 EXPORTS = [
     "wv_create", "wv_destroy", "wv_last_error", "wv_default_options", "wv_read_value", "wv_write_value",
-    "wv_read_field", "wv_write_field", "wv_read_boundary_data", "wv_write_boundary_data",
+    "wv_read_field", "wv_write_field", "wv_read_planes", "wv_write_planes", "wv_read_boundary_data", "wv_write_boundary_data",
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
+    "wv_comm_destroy", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
     "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
@@ -90,6 +90,8 @@ def load_library():
     lib.wv_write_value.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_double]
     lib.wv_read_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.wv_write_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.wv_read_planes.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
+    lib.wv_write_planes.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     lib.wv_read_boundary_data.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.wv_write_boundary_data.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.wv_set_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -111,6 +113,8 @@ def load_library():
     lib.wv_comm_unique_id.argtypes = [C.c_void_p]
     lib.wv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.wv_comm_destroy.argtypes = [C.c_void_p]
+    lib.wv_comm_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+    lib.wv_run_group.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     lib.wv_make_box_nodes.argtypes = [C.c_int32] * 7 + [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
@@ -313,6 +317,21 @@ class Engine:
         assert values.shape == (self.mesh.num_nodes,) and values.dtype in (np.float32, np.float64)
         _check(self.lib.wv_write_field(self.h, buffer, values.ctypes.data_as(C.c_void_p), values.dtype.itemsize))
 
+    def read_planes(self, z_begin, z_count, buffer=BUF_CURRENT, dtype=None):
+        """Planes [z_begin, z_begin + z_count) of a field as [z_count, ny, nx]."""
+        dtype = np.dtype(dtype or self.dtype)
+        nx, ny, _ = self.mesh.dims
+        out = np.empty((z_count, ny, nx), dtype=dtype)
+        _check(self.lib.wv_read_planes(self.h, buffer, z_begin, z_count, out.ctypes.data_as(C.c_void_p), dtype.itemsize))
+        return out
+
+    def write_planes(self, z_begin, values, buffer=BUF_CURRENT):
+        values = np.ascontiguousarray(values)
+        nx, ny, _ = self.mesh.dims
+        assert values.shape[1:] == (ny, nx) and values.dtype in (np.float32, np.float64)
+        _check(self.lib.wv_write_planes(self.h, buffer, z_begin, values.shape[0], values.ctypes.data_as(C.c_void_p),
+                                        values.dtype.itemsize))
+
     def read_boundary_data(self, d):
         out = np.zeros((self.mesh.bidx[d - 1].shape[0], d), dtype=M.boundary_data_dtype)
         if out.size:
@@ -398,6 +417,30 @@ class Engine:
     def comm_init(self, id_bytes, rank, nranks):
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(id_bytes)
         _check(self.lib.wv_comm_init(self.h, buf, rank, nranks))
+
+
+class LocalSlabGroup:
+    """A z-slab chain whose slabs are engines of this process (wv_comm_init_local / wv_run_group):
+    `engines[r]` is slab r.  Same step code as the one-rank-per-GPU RCCL chain, other transport."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.lib = load_library()
+        self._handles = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        _check(self.lib.wv_comm_init_local(self._handles, len(self.engines)))
+
+    def run_steps(self, n_steps):
+        done = C.c_uint64()
+        flag = C.c_int32()
+        _check(self.lib.wv_run_group(self._handles, len(self.engines), int(n_steps), C.byref(done), C.byref(flag)))
+        return done.value, flag.value
+
+    def close(self):
+        for e in self.engines:
+            if e.h:
+                self.lib.wv_comm_destroy(e.h)
+        for e in self.engines:
+            e.close()
 
 
 def run(engine, pre, post, keep_going=lambda: True):
