@@ -20,6 +20,8 @@
 //     voxelised_scene_data templates; `voxels_and_mesh::voxels` is the flattened voxel array the
 //     device kernels walk (what scene_buffers uploads), not the octree object.
 //   - microphone / null attenuators only (the HRTF tables are not part of this engine).
+//   - `voxels_and_mesh` here is what the single- and multi-band `canonical` overloads take by value, as in
+//     the reference (canonical.h:100-110,138-148).
 #pragma once
 
 #include "waveguide.h"
@@ -136,10 +138,11 @@ inline double estimate_volume(const mesh& m) {  // mesh.cpp:40-49
 /// compute_voxels_and_mesh (mesh.cpp:143-159): octree depth 5 over the adjusted boundary, inside
 /// flags, node types, boundary indices, one impedance filter per surface.  All node work runs on
 /// the GPU selected by `cc`.
-template <typename Context>
-voxels_and_mesh compute_voxels_and_mesh(const Context& cc, const core::scene_data& scene, const vec3& anchor,
+template <typename Context, typename Vec3>
+voxels_and_mesh compute_voxels_and_mesh(const Context& cc, const core::scene_data& scene, const Vec3& anchor_position,
                                         double sample_rate, double speed_of_sound) {
     (void)cc;
+    const vec3 anchor{(float)anchor_position.x, (float)anchor_position.y, (float)anchor_position.z};
     if (scene.vertices.empty() || scene.triangles.empty()) throw std::runtime_error{"empty scene"};
     const float mesh_spacing = (float)config::grid_spacing(speed_of_sound, 1 / sample_rate);
     core::box bounds{vec3{scene.vertices[0].x, scene.vertices[0].y, scene.vertices[0].z},
@@ -211,10 +214,10 @@ inline void set_flat_coefficients_for_band(voxels_and_mesh& vm, size_t band) {
 }
 
 /// canonical.h:138-176: one run per band with flat per-band wall filters
-template <typename Context, typename PressureCallback>
+template <typename Context, typename Vec3, typename Environment, typename PressureCallback>
 std::experimental::optional<std::vector<bandpass_band>> canonical(
-        const Context& cc, voxels_and_mesh voxelised, const vec3& source, const vec3& receiver,
-        const core::environment& environment, const multiple_band_constant_spacing_parameters& sim_params,
+        const Context& cc, voxels_and_mesh voxelised, const Vec3& source, const Vec3& receiver,
+        const Environment& environment, const multiple_band_constant_spacing_parameters& sim_params,
         double simulation_time, const std::atomic_bool& keep_going, PressureCallback&& pressure_callback) {
     const auto edges = band_edges_hz();
     std::vector<bandpass_band> ret;
@@ -222,7 +225,7 @@ std::experimental::optional<std::vector<bandpass_band>> canonical(
         set_flat_coefficients_for_band(voxelised, band);
         if (auto rendered = detail::canonical_impl(cc, voxelised.mesh, simulation_time, source, receiver, environment,
                                                    keep_going, pressure_callback)) {
-            ret.push_back(bandpass_band{std::move(*rendered), edges[band], edges[band + 1]});
+            ret.push_back(bandpass_band{std::move(*rendered), util::make_range(edges[band], edges[band + 1])});
         } else {
             return std::experimental::nullopt;
         }
@@ -249,8 +252,8 @@ inline std::vector<float> postprocess_impl(const std::vector<bandpass_band>& res
     std::vector<wv_waveguide_band> bands;
     for (const auto& r : results) {
         keep.push_back(to_abi(r.band));
-        bands.push_back(wv_waveguide_band{keep.back().data(), keep.back().size(), r.band.sample_rate, r.valid_hz_min,
-                                          r.valid_hz_max});
+        bands.push_back(wv_waveguide_band{keep.back().data(), keep.back().size(), r.band.sample_rate,
+                                          r.valid_hz.get_min(), r.valid_hz.get_max()});
     }
     uint64_t n = 0;
     auto call = [&](float* out, uint64_t cap) {

@@ -16,12 +16,20 @@
 //   - step callbacks receive `waveguide::queue&` / `waveguide::buffer&` handles instead of
 //     cl::CommandQueue / cl::Buffer.  Callers written with generic lambdas
 //     (`[](auto& queue, const auto& buffer, auto step)`, as every call site in the reference is)
-//     compile unchanged; the core:: helper overloads below accept the handles.
-//   - `compute_context` carries a HIP device ordinal.  `run` is templated on the context type and
-//     ignores any other context (e.g. the OpenCL one the ray tracer keeps using).
+//     compile unchanged; the core:: helper overloads below accept the handles.  A caller that is
+//     pinned to the OpenCL types -- src/combined/include/combined/waveguide_base.h:47-59 type-erases
+//     its pressure callback as std::function<void(cl::CommandQueue&, const cl::Buffer&, size_t,
+//     size_t)> -- includes wayverb_amd/cl_mirror.h as well and gets exactly those (a float mirror of
+//     the field in a real cl::Buffer, refreshed before each call).
+//   - the context, mesh, position and environment parameters are template parameters: the
+//     reference's own core::compute_context (OpenCL context + device, the ray tracer keeps using it),
+//     glm::vec3 and core::environment are accepted as they are; compat_core.h provides stand-ins
+//     for translation units outside the reference tree, and defines nothing when
+//     WAYVERB_AMD_HAVE_REFERENCE_CORE says the real headers are there.
 //   - `run_device` / `canonical` keep the source and the receivers on the GPU: no per-step PCIe
 //     round trip.  `run` with arbitrary callbacks synchronises every step, like the
-//     reference does.
+//     reference does; so does `canonical` when its pressure callback can see the field (the
+//     reference's 4-argument form) unless the callback is wrapped in `progress_only`.
 #pragma once
 
 #include <algorithm>
@@ -35,67 +43,14 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
 #include "../wayverb_amd.h"
+#include "compat_core.h"
 
 namespace wayverb {
-namespace core {
-
-namespace exceptions {  // src/core/include/core/exceptions.h:9-30
-class exception : public std::runtime_error {
-public:
-    using std::runtime_error::runtime_error;
-};
-class suspicious_value : public exception {
-public:
-    using exception::exception;
-};
-class value_is_nan final : public suspicious_value {
-public:
-    using suspicious_value::suspicious_value;
-};
-class value_is_inf final : public suspicious_value {
-public:
-    using suspicious_value::suspicious_value;
-};
-}  // namespace exceptions
-
-struct environment final {  // src/core/include/core/environment.h:6-13
-    double speed_of_sound{340.0};
-    double acoustic_impedance{400.0};
-};
-constexpr double get_ambient_density(const environment& s) { return s.acoustic_impedance / s.speed_of_sound; }
-
-/// Stand-in for core::compute_context (src/core/include/core/cl/common.h:13-22): which HIP device.
-struct compute_context final {
-    int device{-1};
-};
-
-template <typename T, typename Ret = typename T::return_type>
-class callback_accumulator final {  // src/core/include/core/callback_accumulator.h:8-28
-public:
-    callback_accumulator(T t) : postprocessor_{std::move(t)} {}
-    template <typename... Ts>
-    callback_accumulator(Ts&&... ts) : postprocessor_{std::forward<Ts>(ts)...} {}
-    template <typename... Ts>
-    void operator()(Ts&&... ts) {
-        output_.emplace_back(postprocessor_(std::forward<Ts>(ts)...));
-    }
-    const std::vector<Ret>& get_output() const { return output_; }
-
-private:
-    std::vector<Ret> output_;
-    T postprocessor_;
-};
-template <typename T>
-auto make_callback_accumulator(T t) {
-    return callback_accumulator<T>{std::move(t)};
-}
-
-}  // namespace core
-
 namespace waveguide {
 
 // ---- engine plumbing ----------------------------------------------------------------------------
@@ -214,6 +169,12 @@ struct ivec3 final {
     int x, y, z;
 };
 
+namespace detail {
+// a position is anything with floating-point members x, y, z: `vec3` above, glm::vec3 in the reference tree
+template <typename V>
+using enable_if_position = typename std::enable_if<std::is_floating_point<decltype(std::declval<V>().x)>::value, int>::type;
+}  // namespace detail
+
 struct mesh_descriptor final {  // mesh_descriptor.h:14-20
     vec3 min_corner;
     ivec3 dimensions;
@@ -227,11 +188,14 @@ inline ivec3 compute_locator(const mesh_descriptor& d, size_t index) {  // mesh_
     const size_t x = index % d.dimensions.x, q = index / d.dimensions.x;
     return ivec3{(int)x, (int)(q % d.dimensions.y), (int)((q / d.dimensions.y) % d.dimensions.z)};
 }
-inline ivec3 compute_locator(const mesh_descriptor& d, const vec3& v) {  // :22-25, glm::round
-    return ivec3{(int)std::round((v.x - d.min_corner.x) / d.spacing), (int)std::round((v.y - d.min_corner.y) / d.spacing),
-                 (int)std::round((v.z - d.min_corner.z) / d.spacing)};
+template <typename V, detail::enable_if_position<V> = 0>
+ivec3 compute_locator(const mesh_descriptor& d, const V& v) {  // :22-25, glm::round
+    return ivec3{(int)std::round(((float)v.x - d.min_corner.x) / d.spacing),
+                 (int)std::round(((float)v.y - d.min_corner.y) / d.spacing),
+                 (int)std::round(((float)v.z - d.min_corner.z) / d.spacing)};
 }
-inline size_t compute_index(const mesh_descriptor& d, const vec3& pos) {
+template <typename V, detail::enable_if_position<V> = 0>
+size_t compute_index(const mesh_descriptor& d, const V& pos) {
     return compute_index(d, compute_locator(d, pos));
 }
 inline vec3 compute_position(const mesh_descriptor& d, const ivec3& l) {  // :27-30
@@ -349,26 +313,43 @@ inline mesh make_box_mesh(int nx, int ny, int nz, float spacing, coefficients_ca
 
 // ---- engine construction ------------------------------------------------------------------------
 namespace detail {
+// HIP device of a context: its `.device` when that is an ordinal (compat_core.h), else -1 = the calling
+// thread's current device (the reference's context names an OpenCL device, which says nothing here)
 template <typename Context>
-int device_of(const Context&) {
+auto device_of(const Context& cc, int) -> decltype(int{cc.device}) {
+    return cc.device;
+}
+template <typename Context>
+int device_of(const Context&, long) {
     return -1;
 }
-inline int device_of(const core::compute_context& cc) { return cc.device; }
-
 template <typename Context>
-engine_ptr make_engine(const Context& cc, const mesh& m, int precision) {
+int device_of(const Context& cc) {
+    return device_of(cc, 0);
+}
+
+/// `Mesh` is this header's `mesh` or the reference's own (mesh.h:12-26): anything with its accessors
+/// whose element types have the device layouts of cl/structs.h (checked below).
+template <typename Context, typename Mesh>
+engine_ptr make_engine(const Context& cc, const Mesh& m, int precision) {
     const auto& s = m.get_structure();
     const auto& bid = s.get_boundary_index_data();
+    using node_t = typename std::decay<decltype(s.get_condensed_nodes()[0])>::type;
+    using coeff_t = typename std::decay<decltype(s.get_coefficients()[0])>::type;
+    static_assert(sizeof(node_t) == sizeof(wv_condensed_node), "condensed_node layout (cl/structs.h:19-22)");
+    static_assert(sizeof(coeff_t) == sizeof(wv_coefficients_canonical), "coefficients_canonical layout");
+    static_assert(sizeof(bid.b1[0]) == 4 && sizeof(bid.b2[0]) == 8 && sizeof(bid.b3[0]) == 12,
+                  "boundary_index_array<N> layout (cl/boundary_index_array.h:8-11)");
     wv_mesh wm{};
     wm.nx = m.get_descriptor().dimensions.x;
     wm.ny = m.get_descriptor().dimensions.y;
     wm.nz = m.get_descriptor().dimensions.z;
-    wm.nodes = s.get_condensed_nodes().data();
-    wm.coefficients = s.get_coefficients().data();
+    wm.nodes = reinterpret_cast<const wv_condensed_node*>(s.get_condensed_nodes().data());
+    wm.coefficients = reinterpret_cast<const wv_coefficients_canonical*>(s.get_coefficients().data());
     wm.num_coefficients = (uint32_t)s.get_coefficients().size();
-    wm.boundary_indices_1 = bid.b1.empty() ? nullptr : bid.b1.front().array;
-    wm.boundary_indices_2 = bid.b2.empty() ? nullptr : bid.b2.front().array;
-    wm.boundary_indices_3 = bid.b3.empty() ? nullptr : bid.b3.front().array;
+    wm.boundary_indices_1 = bid.b1.empty() ? nullptr : reinterpret_cast<const uint32_t*>(bid.b1.data());
+    wm.boundary_indices_2 = bid.b2.empty() ? nullptr : reinterpret_cast<const uint32_t*>(bid.b2.data());
+    wm.boundary_indices_3 = bid.b3.empty() ? nullptr : reinterpret_cast<const uint32_t*>(bid.b3.data());
     wm.num_boundary_1 = bid.b1.size();
     wm.num_boundary_2 = bid.b2.size();
     wm.num_boundary_3 = bid.b3.size();
@@ -382,16 +363,18 @@ engine_ptr make_engine(const Context& cc, const mesh& m, int precision) {
 }
 }  // namespace detail
 
-/// Pressure storage: WV_PRECISION_F32 reproduces the reference's cl_float fields bit for bit,
-/// WV_PRECISION_F64 is the double-precision engine of the north star.  Process-wide default.
+/// Pressure storage, process-wide.  Default WV_PRECISION_F64 -- the double-precision engine of the
+/// north star, the default of every layer (wv_default_options, the Python binding).  Callbacks see
+/// floats either way (read_value<float>, read_from_buffer<float>).  WV_PRECISION_F32 stores
+/// pressures as the reference does (cl_float) and reproduces its fields bit for bit.
 inline int& default_precision() {
-    static int p = WV_PRECISION_F32;
+    static int p = WV_PRECISION_F64;
     return p;
 }
 
 // ---- run: arbitrary step callbacks (waveguide.h:36-126) -------------------------------------------
-template <typename Context, typename step_preprocessor, typename step_postprocessor>
-size_t run(const Context& cc, const mesh& mesh, step_preprocessor&& pre, step_postprocessor&& post,
+template <typename Context, typename Mesh, typename step_preprocessor, typename step_postprocessor>
+size_t run(const Context& cc, const Mesh& mesh, step_preprocessor&& pre, step_postprocessor&& post,
            const std::atomic_bool& keep_going) {
     auto engine = detail::make_engine(cc, mesh, default_precision());
     const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
@@ -566,8 +549,22 @@ private:
 /// every `batch` steps; keep_going is polled at the same cadence.  Returns completed steps.
 enum class source_kind { hard = WV_SOURCE_HARD, soft = WV_SOURCE_SOFT };
 
-template <typename Context, typename It, typename OnBatch>
-size_t run_device(const Context& cc, const mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
+/// on_batch may also take a fourth argument, the engine (`wv_engine*`): how `canonical` hands the field
+/// to a pressure callback.
+namespace detail {
+template <typename OnBatch>
+auto call_on_batch(OnBatch& f, wv_engine* e, size_t first, size_t n, const std::vector<double>& s, int)
+        -> decltype(f(first, n, s, e), void()) {
+    f(first, n, s, e);
+}
+template <typename OnBatch>
+void call_on_batch(OnBatch& f, wv_engine*, size_t first, size_t n, const std::vector<double>& s, long) {
+    f(first, n, s);
+}
+}  // namespace detail
+
+template <typename Context, typename Mesh, typename It, typename OnBatch>
+size_t run_device(const Context& cc, const Mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
                   const std::vector<uint64_t>& receivers, OnBatch&& on_batch, const std::atomic_bool& keep_going,
                   size_t batch = 256) {
     auto engine = detail::make_engine(cc, mesh, default_precision());
@@ -584,7 +581,7 @@ size_t run_device(const Context& cc, const mesh& mesh, source_kind kind, size_t 
         if (done) {
             samples.resize((size_t)done * receivers.size());
             detail::check(wv_fetch_receivers(engine.get(), done_total, done, samples.data()));
-            on_batch(done_total, (size_t)done, samples);
+            detail::call_on_batch(on_batch, engine.get(), done_total, (size_t)done, samples, 0);
         }
         done_total += (size_t)done;
         detail::throw_for_flag(flag);
@@ -600,7 +597,7 @@ struct band final {  // bandpass_band.h:11-15
 };
 struct bandpass_band final {  // bandpass_band.h:17-20
     waveguide::band band;
-    double valid_hz_min, valid_hz_max;
+    util::range<double> valid_hz;
 };
 struct single_band_parameters final {  // simulation_parameters.h:9-16
     double cutoff;
@@ -609,18 +606,80 @@ struct single_band_parameters final {  // simulation_parameters.h:9-16
 constexpr double compute_sampling_frequency(double cutoff, double usable_portion) {  // :65-68
     return cutoff / (0.25 * usable_portion);
 }
+constexpr double compute_sampling_frequency(const single_band_parameters& p) {  // :70-72
+    return compute_sampling_frequency(p.cutoff, p.usable_portion);
+}
+
+/// Marks a pressure callback that never looks at the field (progress bars): `canonical` then keeps
+/// whole batches of steps on the device instead of synchronising after every step.
+template <typename F>
+struct progress_only_t final {
+    F f;
+};
+template <typename F>
+progress_only_t<typename std::decay<F>::type> progress_only(F&& f) {
+    return {std::forward<F>(f)};
+}
 
 namespace detail {
-/// callback(step, ideal_steps) fires once per completed step, in order.
-template <typename Context, typename Callback>
-std::experimental::optional<band> canonical_impl(const Context& cc, const mesh& mesh, double simulation_time,
-                                                 const vec3& source, const vec3& receiver,
-                                                 const core::environment& environment,
-                                                 const std::atomic_bool& keep_going, Callback&& callback) {
+
+/// How a pressure callback gets to see the field.  This one hands out the engine handles; cl_mirror.h
+/// adds the one for contexts that carry an OpenCL context (real cl::CommandQueue / cl::Buffer).
+class handle_bridge final {
+public:
+    // wv_run has swapped the fields by the time the callback fires: the step's pre-update `current`
+    // (what waveguide.h:121 hands to `post`) is the engine's PREVIOUS buffer now
+    handle_bridge(wv_engine* e, size_t nodes) : queue_{e}, current_{e, WV_BUF_PREVIOUS, nodes} {}
+    bool per_step() const { return true; }  // the callback may read the field: it must be the step's field
+    template <typename Callback>
+    void invoke(Callback& callback, size_t step, size_t steps) {
+        callback(queue_, static_cast<const buffer&>(current_), step, steps);
+    }
+
+private:
+    queue queue_;
+    buffer current_;
+};
+template <typename Context, typename = void>
+struct callback_bridge_for final {  // cl_mirror.h specialises this for contexts with a cl::Context member
+    using type = handle_bridge;
+    static type* make(const Context&, wv_engine* e, size_t nodes) { return new type{e, nodes}; }
+};
+
+// a callback that cannot see the field: (step, steps) only, or wrapped in progress_only
+template <typename Callback, typename = void>
+struct takes_field : std::true_type {};
+template <typename F>
+struct takes_field<progress_only_t<F>, void> : std::false_type {};
+template <typename Callback>
+struct takes_field<Callback, decltype(std::declval<Callback&>()(size_t{}, size_t{}), void())> : std::false_type {};
+
+template <typename Bridge, typename Callback>
+void fire(Bridge& bridge, Callback& callback, size_t step, size_t steps, std::true_type) {
+    bridge.invoke(callback, step, steps);
+}
+template <typename Bridge, typename F>
+void fire(Bridge& bridge, progress_only_t<F>& callback, size_t step, size_t steps, std::false_type) {
+    bridge.invoke(callback.f, step, steps);  // same arguments, batched: the field is not the step's
+}
+template <typename Bridge, typename Callback>
+void fire(Bridge&, Callback& callback, size_t step, size_t steps, std::false_type) {
+    callback(step, steps);
+}
+
+/// canonical.h:29-88.  `callback(queue, buffer, step, ideal_steps)` fires once per completed step, in
+/// order, after the directional receiver has taken its sample -- exactly the reference's lambda at
+/// :66-69 -- with `buffer` the step's (pre-update) pressure field.
+template <typename Context, typename Mesh, typename Vec3, typename Environment, typename Callback>
+std::experimental::optional<band> canonical_impl(const Context& cc, const Mesh& mesh, double simulation_time,
+                                                 const Vec3& source, const Vec3& receiver,
+                                                 const Environment& environment, const std::atomic_bool& keep_going,
+                                                 Callback&& callback) {
     const auto sample_rate = compute_sample_rate(mesh.get_descriptor(), environment.speed_of_sound);
-    const auto compute_mesh_index = [&](const vec3& pt) {
+    const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
+    const auto compute_mesh_index = [&](const Vec3& pt) {
         const auto ret = compute_index(mesh.get_descriptor(), pt);
-        if (ret >= mesh.get_structure().get_condensed_nodes().size() || !waveguide::is_inside(mesh, ret))
+        if (ret >= num_nodes || !(mesh.get_structure().get_condensed_nodes()[ret].boundary_type & WV_ID_INSIDE))
             throw std::runtime_error{"Source/receiver node position appears to be outside mesh."};
         return ret;
     };
@@ -630,39 +689,58 @@ std::experimental::optional<band> canonical_impl(const Context& cc, const mesh& 
         input.front() = (float)rectilinear_calibration_factor(mesh.get_descriptor().spacing,
                                                               environment.acoustic_impedance);
     const size_t receiver_index = compute_mesh_index(receiver);
-    postprocessor::directional_receiver dr{mesh.get_descriptor(), sample_rate, get_ambient_density(environment),
-                                           receiver_index};
+    postprocessor::directional_receiver dr{mesh.get_descriptor(), sample_rate,
+                                           environment.acoustic_impedance / environment.speed_of_sound, receiver_index};
     std::vector<uint64_t> nodes{receiver_index};
     for (auto n : dr.get_surrounding_nodes()) nodes.push_back(n);
 
+    using callback_t = typename std::decay<Callback>::type;
+    constexpr bool sees_field = takes_field<callback_t>::value;
     band ret{{}, sample_rate};
     ret.directional.reserve(ideal_steps);
+    // one bridge per run, made on the first batch (it needs the engine run_device creates)
+    using bridge_t = typename callback_bridge_for<Context>::type;
+    std::unique_ptr<bridge_t> bridge;
     const size_t steps = run_device(
             cc, mesh, source_kind::hard, compute_mesh_index(source), input.begin(), input.end(), nodes,
-            [&](size_t first, size_t n, const std::vector<double>& s) {
+            [&](size_t first, size_t n, const std::vector<double>& s, wv_engine* e) {
+                if (!bridge) bridge.reset(callback_bridge_for<Context>::make(cc, e, num_nodes));
                 for (size_t i = 0; i < n; ++i) {
                     float nb[6];
                     for (int k = 0; k < 6; ++k) nb[k] = (float)s[i * 7 + 1 + k];
                     ret.directional.emplace_back(dr.accumulate((float)s[i * 7], nb));
-                    callback(first + i, ideal_steps);
+                    fire(*bridge, callback, first + i, ideal_steps, std::integral_constant<bool, sees_field>{});
                 }
             },
-            keep_going);
+            keep_going, sees_field ? 1 : 256);
     if (steps != ideal_steps) return std::experimental::nullopt;
     return ret;
 }
 }  // namespace detail
 
-/// canonical.h:100-127 for an already-built mesh (the reference passes voxels_and_mesh and uses
-/// only its .mesh member here).
-template <typename Context, typename PressureCallback>
+/// canonical.h:100-127 for an already-built mesh.
+template <typename Context, typename Vec3, typename Environment, typename PressureCallback>
 std::experimental::optional<std::vector<bandpass_band>> canonical(
-        const Context& cc, const mesh& mesh, const vec3& source, const vec3& receiver,
-        const core::environment& environment, const single_band_parameters& sim_params, double simulation_time,
-        const std::atomic_bool& keep_going, PressureCallback&& pressure_callback) {
+        const Context& cc, const mesh& mesh, const Vec3& source, const Vec3& receiver, const Environment& environment,
+        const single_band_parameters& sim_params, double simulation_time, const std::atomic_bool& keep_going,
+        PressureCallback&& pressure_callback) {
     if (auto ret = detail::canonical_impl(cc, mesh, simulation_time, source, receiver, environment, keep_going,
                                           pressure_callback)) {
-        return std::vector<bandpass_band>{bandpass_band{std::move(*ret), 0.0, sim_params.cutoff}};
+        return std::vector<bandpass_band>{bandpass_band{std::move(*ret), util::make_range(0.0, sim_params.cutoff)}};
+    }
+    return std::experimental::nullopt;
+}
+
+/// canonical.h:100-127 as the reference declares it: `voxelised` is a voxels_and_mesh -- setup.h's, the
+/// reference's own (mesh.h:52-58), anything with a `.mesh` member.
+template <typename Context, typename VoxelsAndMesh, typename Vec3, typename Environment, typename PressureCallback>
+auto canonical(const Context& cc, VoxelsAndMesh voxelised, const Vec3& source, const Vec3& receiver,
+               const Environment& environment, const single_band_parameters& sim_params, double simulation_time,
+               const std::atomic_bool& keep_going, PressureCallback&& pressure_callback)
+        -> decltype((void)voxelised.mesh, std::experimental::optional<std::vector<bandpass_band>>{}) {
+    if (auto ret = detail::canonical_impl(cc, voxelised.mesh, simulation_time, source, receiver, environment, keep_going,
+                                          pressure_callback)) {
+        return std::vector<bandpass_band>{bandpass_band{std::move(*ret), util::make_range(0.0, sim_params.cutoff)}};
     }
     return std::experimental::nullopt;
 }

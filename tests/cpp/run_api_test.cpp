@@ -149,6 +149,34 @@ static void canonical_matches_generic() {
         [&](auto& q, const auto& b, auto step) { acc(q, b, step); }, true);
     REQUIRE(acc.get_output().size() == fast.size());
     REQUIRE(std::memcmp(acc.get_output().data(), fast.data(), fast.size() * sizeof(fast[0])) == 0);
+    // the reference's 4-argument pressure callback (canonical.h:66-69, 77-81): it sees the step's field
+    std::vector<float> seen_at_receiver, seen_max;
+    size_t calls4 = 0;
+    const auto receiver_index = compute_index(m.get_descriptor(), receiver);
+    const auto res4 = canonical(cc, m, source, receiver, env, single_band_parameters{1000.0, 0.5}, sim_time, true,
+                                [&](auto& queue, const auto& buffer, auto step, auto steps) {
+                                    REQUIRE(step == calls4 && steps == 151);
+                                    ++calls4;
+                                    seen_at_receiver.push_back(read_value<float>(queue, buffer, receiver_index));
+                                    if (step % 50 == 0) {  // engine.cpp:158-169: the visualiser's full read
+                                        const auto pressures = read_from_buffer<float>(queue, buffer);
+                                        REQUIRE(pressures.size() == compute_num_nodes(m.get_descriptor()));
+                                        REQUIRE(pressures[receiver_index] == seen_at_receiver.back());
+                                        float mx = 0;
+                                        for (float v : pressures) mx = std::max(mx, std::fabs(v));
+                                        seen_max.push_back(mx);
+                                    }
+                                });
+    REQUIRE(bool(res4) && calls4 == 151 && seen_max.size() == 4 && seen_max[0] > 0);
+    REQUIRE(std::memcmp(res4->front().band.directional.data(), fast.data(), fast.size() * sizeof(fast[0])) == 0);
+    for (size_t i = 0; i < 151; ++i) REQUIRE(seen_at_receiver[i] == fast[i].pressure);  // the step's field, not a later one
+    // the same callback marked as not reading the field: batched on the device, same results
+    size_t calls_p = 0;
+    const auto res_p = canonical(cc, m, source, receiver, env, single_band_parameters{1000.0, 0.5}, sim_time, true,
+                                 progress_only([&](auto&, const auto&, auto step, auto) { REQUIRE(step == calls_p++); }));
+    REQUIRE(bool(res_p) && calls_p == 151);
+    REQUIRE(std::memcmp(res_p->front().band.directional.data(), fast.data(), fast.size() * sizeof(fast[0])) == 0);
+    REQUIRE(res_p->front().valid_hz.get_min() == 0.0 && res_p->front().valid_hz.get_max() == 1000.0);
     // early cancel -> nullopt (canonical.h:83-85)
     std::atomic_bool stop{false};
     const auto cancelled = canonical(cc, m, source, receiver, env, single_band_parameters{1000.0, 0.5}, 5000.0 / sr,
@@ -210,7 +238,12 @@ static void scene_to_audio() {
     }
     REQUIRE(floor_seen && wall_seen);
 
-    const auto bands = canonical(cc, vm.mesh, source, receiver, env, params, 0.25, true, [](size_t, size_t) {});
+    // canonical.h:100-110 takes the voxels_and_mesh (by value); the mesh overload gives the same band
+    const auto bands = canonical(cc, vm, source, receiver, env, params, 0.25, true, [](size_t, size_t) {});
+    const auto bands_m = canonical(cc, vm.mesh, source, receiver, env, params, 0.25, true, [](size_t, size_t) {});
+    REQUIRE(bool(bands_m) && bands_m->front().band.directional.size() == bands->front().band.directional.size());
+    REQUIRE(std::memcmp(bands_m->front().band.directional.data(), bands->front().band.directional.data(),
+                        bands->front().band.directional.size() * sizeof(bands->front().band.directional[0])) == 0);
     REQUIRE(bool(bands) && bands->size() == 1);
     const double fs = bands->front().band.sample_rate;
     const size_t steps = bands->front().band.directional.size();
@@ -239,7 +272,7 @@ static void scene_to_audio() {
     const auto two = canonical(cc, vm, source, receiver, env, multiple_band_constant_spacing_parameters{2, 150.0, 0.6},
                                0.05, true, [](size_t, size_t) {});
     REQUIRE(bool(two) && two->size() == 2);
-    REQUIRE(std::fabs((*two)[0].valid_hz_min - 20.0) < 1e-9 && std::fabs((*two)[1].valid_hz_min - (*two)[0].valid_hz_max) < 1e-9);
+    REQUIRE(std::fabs((*two)[0].valid_hz.get_min() - 20.0) < 1e-9 && std::fabs((*two)[1].valid_hz.get_min() - (*two)[0].valid_hz.get_max()) < 1e-9);
     REQUIRE((*two)[0].band.directional.size() == (*two)[1].band.directional.size());
     const auto mixed = postprocess(*two, attenuator::null{}, env.acoustic_impedance, 44100.0);
     REQUIRE(!mixed.empty());

@@ -14,6 +14,7 @@ def _build(built_library):
     if os.path.exists(EXE) and os.path.getmtime(EXE) > max(
             os.path.getmtime(SRC), os.path.getmtime(built_library),
             os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "waveguide.h")),
+            os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "compat_core.h")),
             os.path.getmtime(os.path.join(ROOT, "include", "wayverb_amd", "setup.h"))):
         return
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
@@ -37,6 +38,44 @@ def test_reference_style_cpp_tests_pass(built_library):
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "ALL OK" in p.stdout
+
+
+SHAPE_SRC = os.path.join(ROOT, "tests", "cpp", "combined_shape_test.cpp")
+SHAPE_EXE = os.path.join(ROOT, "tests", "cpp", "combined_shape_test")
+OPENCL_INCLUDE = "/opt/rocm/include"     # CL/cl.hpp, the bindings the reference uses (core/cl/include.h)
+
+
+def _build_shape_test(built_library):
+    """A translation unit laid out like src/combined's: OpenCL bindings + its own `wayverb::core`
+    first, then the mirror with WAYVERB_AMD_HAVE_REFERENCE_CORE (no redefinitions), cl.hpp types in
+    the pressure callback."""
+    if not os.path.exists(os.path.join(OPENCL_INCLUDE, "CL", "cl.hpp")):
+        pytest.skip("no OpenCL C++ bindings in this image")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-DCL_TARGET_OPENCL_VERSION=120",
+                           "-isystem", OPENCL_INCLUDE, "-I", os.path.join(ROOT, "include"), SHAPE_SRC, "-o", SHAPE_EXE,
+                           "-L", os.path.join(ROOT, "wayverb_amd"), "-lwayverb_amd", "-lOpenCL",
+                           "-Wl,-rpath," + os.path.join(ROOT, "wayverb_amd")])
+
+
+def test_combined_call_shape_compiles_against_the_mirror(built_library):
+    _build_shape_test(built_library)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([SHAPE_EXE], capture_output=True, text=True)
+    assert p.returncode in (2, 3), p.stdout + p.stderr       # no OpenCL / HIP device here: said so, not crashed
+
+
+@pytest.mark.gpu
+def test_combined_call_shape_runs_with_real_opencl_types(built_library):
+    """waveguide_base.cpp:22-43 + engine.cpp:150-173 as written (cl::CommandQueue& / const cl::Buffer&
+    callback, read_from_buffer<float> on the cl::Buffer) get the step's field through the cl mirror."""
+    _build_shape_test(built_library)
+    p = subprocess.run([SHAPE_EXE], capture_output=True, text=True, timeout=600)
+    if p.returncode == 3:
+        pytest.skip("no OpenCL GPU device on this box: " + p.stdout.strip())
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "COMBINED SHAPE OK" in p.stdout
 
 
 C_SRC = os.path.join(ROOT, "examples", "box_run.c")
