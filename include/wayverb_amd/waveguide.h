@@ -89,15 +89,18 @@ private:
 /// What a step callback sees instead of cl::Buffer: one of the engine's two pressure fields.
 class buffer final {
 public:
-    buffer(wv_engine* e, int which, size_t items) : e_{e}, which_{which}, items_{items} {}
+    buffer(wv_engine* e, int which, size_t items, int precision = WV_PRECISION_F64)
+            : e_{e}, which_{which}, items_{items}, precision_{precision} {}
     wv_engine* engine() const { return e_; }
     int which() const { return which_; }
     size_t items() const { return items_; }
+    int precision() const { return precision_; }  // WV_PRECISION_*: how the engine stores pressures
 
 private:
     wv_engine* e_;
     int which_;
     size_t items_;
+    int precision_;
 };
 
 }  // namespace waveguide
@@ -379,7 +382,7 @@ size_t run(const Context& cc, const Mesh& mesh, step_preprocessor&& pre, step_po
     auto engine = detail::make_engine(cc, mesh, default_precision());
     const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
     queue q{engine.get()};
-    buffer current{engine.get(), WV_BUF_CURRENT, num_nodes};  // the handle follows the swaps
+    buffer current{engine.get(), WV_BUF_CURRENT, num_nodes, default_precision()};  // the handle follows the swaps
     size_t step = 0;
     for (; pre(q, current, step) && keep_going; ++step) {
         int32_t flag = 0;
@@ -424,8 +427,16 @@ public:
     template <typename Q, typename B>
     bool operator()(Q& q, B& b, size_t) {
         if (begin_ == end_) return false;
-        const auto current_pressure = core::read_value<float>(q, b, node_);
-        core::write_value(q, b, node_, current_pressure + *begin_++);
+        // the sum is taken in the field's own precision: float like the reference (soft_source.h:21-24)
+        // on a float field, double on the fp64 engine (where rounding the field to float first would
+        // throw away what the engine carries)
+        if (b.precision() == WV_PRECISION_F32) {
+            const auto current_pressure = core::read_value<float>(q, b, node_);
+            core::write_value(q, b, node_, current_pressure + static_cast<float>(*begin_++));
+        } else {
+            const auto current_pressure = core::read_value<double>(q, b, node_);
+            core::write_value(q, b, node_, current_pressure + static_cast<double>(*begin_++));
+        }
         return true;
     }
     size_t get_node() const { return node_; }

@@ -282,11 +282,16 @@ static void scene_to_audio() {
 int main() {
     try {
         filters_are_stable();
-        run_waveguide();
-        determinism();
-        nan_in_waveguide();
-        canonical_matches_generic();
-        scene_to_audio();
+        // the fp64 engine (default) and the reference's own float storage
+        for (int precision : {WV_PRECISION_F64, WV_PRECISION_F32}) {
+            default_precision() = precision;
+            std::printf("-- pressures stored as %s\n", precision == WV_PRECISION_F64 ? "double" : "float");
+            run_waveguide();
+            determinism();
+            nan_in_waveguide();
+            canonical_matches_generic();
+            scene_to_audio();
+        }
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 2;
