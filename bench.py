@@ -14,9 +14,14 @@ in HBM before the timed region.
           (configs[3] at N = 8), ghost planes exchanged each step over RCCL inside the engine.
 
 Prints ONE JSON line on rank 0 (see the README of the driver contract); `roofline` is for the
-dominant kernel (the streaming pressure update), timed with HIP events on the engine's stream;
-`cpu_baseline` is the CPU restatement (oracle/, kind "port") on all host cores, N=1 only.
+dominant kernel, timed with HIP events on the engine's stream: at N = 1 the two-step pass
+(pair_march_kernel: one launch advances every node by TWO time steps, so its algorithmic bytes are
+2 x 24 B per node), at N > 1 the single-step plane sweep of a slab's interior planes.
+`cpu_baseline` is the reference's own kernel compiled for the host (oracle/_ref, kind "reference";
+the C restatement, kind "port", when that is absent) on the host's cores, N = 1 only, on the SAME
+mesh for a few steps.
 """
+import hashlib
 import argparse
 import json
 import os
@@ -46,14 +51,25 @@ def parse_args():
     return p.parse_args()
 
 
+def kernel_sources_hash():
+    """Fingerprint of the device code: PMC traffic figures under profiles/ are only quoted for the
+    kernels they were measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "wayverb_amd", "csrc")
+    for name in ("device_common.hip.h", "stream_kernels.hip.h", "pair_kernels.hip.h", "boundary_kernels.hip.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, elem):
-    """The CPU restatement on all host cores, on a bounded sample of the same workload:
-    a 1024 x 1024 x 32 slice of the box (same node mix per plane), timed for ~cpu_seconds."""
-    from oracle.oracle import Oracle
+    """the CPU path on the same mesh, threaded over the host's cores, for a handful of
+    steps (1024^3 is ~2 s per step on 128-256 threads; `--cpu-seconds` bounds the timed part)."""
+    from oracle.oracle import Oracle, Reference, reference_available
     from wayverb_amd import mesh as M
     from wayverb_amd.engine import make_box_nodes
     cores = os.cpu_count() or 1
-    nx, ny, nz = args.nx, args.ny, 32
+    nx, ny, nz = args.nx, args.ny, args.nz
     nodes, counts = make_box_nodes(nx, ny, nz)
     coeffs = M.bench_materials()
     mesh = M.Mesh((nx, ny, nz), nodes, coeffs,
@@ -66,7 +82,6 @@ def cpu_baseline(args, elem):
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
     # prefer the reference's own kernel (oracle/_ref: its OpenCL C text compiled for the host,
     # pressure type promoted to double for the fp64 bench) over the repo's C restatement
-    from oracle.oracle import Reference, reference_available
     if reference_available():
         impl = Reference("f32" if args.precision == "f32" else "f64")
         kind = "reference"
@@ -76,11 +91,11 @@ def cpu_baseline(args, elem):
         impl = Oracle()
         kind = "port"
         what = "C restatement (oracle/), OpenMP over x-rows"
-    impl.step(prev, cur, mesh, bd, threads=cores)  # first touch
+    impl.step(prev, cur, mesh, bd, threads=cores)  # first touch of every page
     prev, cur = cur, prev
-    # pick the thread count that is actually fastest on this host (SMT / NUMA make "all" a guess)
+    # SMT / NUMA make "all logical cores" a guess: one step each at all / half of them, keep the faster
     best = None
-    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+    for t in sorted({cores, max(1, cores // 2)}, reverse=True):
         t0 = time.perf_counter()
         impl.step(prev, cur, mesh, bd, threads=t)
         prev, cur = cur, prev
@@ -95,11 +110,12 @@ def cpu_baseline(args, elem):
         prev, cur = cur, prev
         steps += 1
         dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds and steps >= 2:
+        if (dt >= args.cpu_seconds and steps >= 2) or steps >= 10:
             break
     rate = mesh.num_nodes * steps / dt / 1e9
     return {"value": round(rate, 5), "unit": "Gnode-updates/s", "cores": threads, "kind": kind,
-            "sample": "%dx%dx%d %s box slice, %d steps in %.1f s, %d threads (host has %d logical cores); %s"
+            "per_core_mnode_per_s": round(rate * 1e3 / threads, 2),
+            "sample": "the same %dx%dx%d %s box mesh, %d steps in %.1f s on %d threads (host has %d logical cores); %s"
                       % (nx, ny, nz, args.precision, steps, dt, threads, cores, what)}
 
 
@@ -182,27 +198,43 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms, launches = eng.kernel_time_ms()
+    kernel_ms, launches, timed_steps = eng.kernel_time_detail()
     eng.enable_kernel_timing(False)
 
     owned_nodes = nx * ny * (layout.z1 - layout.z0)
     total_nodes = nx * ny * nz_global
     value = total_nodes * args.steps / elapsed / 1e9
 
-    # nodes covered by the timed launch: all owned planes at N=1, the interior planes (faces are
-    # updated by two small launches before the halo exchange) at N>1
+    # nodes covered by a timed launch: all owned planes at N=1, the interior planes (faces are
+    # updated by two small launches before the halo exchange) at N>1; time steps per launch: 2 when
+    # the engine took two-step passes (N=1 on a mesh this size), else 1
+    steps_per_launch = (timed_steps / launches) if launches else 1.0
+    two_step = steps_per_launch > 1.5
     timed_planes = (layout.z1 - layout.z0) - (int(layout.ghost_lo) + int(layout.ghost_hi))
-    alg_bytes = 3 * elem * nx * ny * timed_planes
+    # algorithmic bytes: 3 fields of `elem` bytes per node-update x node-updates per launch
+    alg_bytes = int(3 * elem * nx * ny * timed_planes * steps_per_launch)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    kernel_name = "pair_march_kernel" if two_step else "stream_sweep_kernel"
+    # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
+    # when it was measured on this very device code, this kernel and this workload
     traffic = None
+    traffic_note = "no PMC measurement on file for this kernel / workload / device code"
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(prof):
         try:
             rec = json.load(open(prof))
-            if rec.get("workload") == "%dx%dx%d %s" % (nx, ny, args.nz, args.precision):
+            if (rec.get("workload") == "%dx%dx%d %s" % (nx, ny, args.nz, args.precision)
+                    and rec.get("kernel") == kernel_name and rec.get("kernel_sources") == kernel_sources_hash()):
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 --pmc passes of %s (profiles/%s)" % (rec.get("measured", "?"), rec.get("files", "traffic.json"))
         except Exception:
             traffic = None
+    triad = None
+    if world == 1:
+        try:
+            triad = round(E.measure_triad(local_rank), 1)
+        except Exception:
+            triad = None
 
     out = {
         "metric": "Gnode-updates/s, fp64 box mesh" if args.precision == "f64" else "Gnode-updates/s, fp32 box mesh",
@@ -216,9 +248,14 @@ def main():
                    "halo": "RCCL send/recv, 1 plane per neighbour per step" if world > 1 else "none",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "stream_sweep_kernel", "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                     "time_steps_per_launch": round(steps_per_launch, 3),
                      "alg_bytes_per_launch": alg_bytes,
+                     "alg_bytes_definition": "24 B (fp64) per node-update x node-updates per launch; a two-step pass "
+                                             "needs only 4 fields of HBM traffic per node for its 2 updates",
+                     "min_traffic_per_launch": int((4 if two_step else 3) * elem * nx * ny * timed_planes),
+                     "triad_gbs": triad,
                      "whole_step_frac": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
     eng.close()

@@ -189,6 +189,10 @@ int wv_step_count(wv_engine* e, uint64_t* steps);
  * last call, measured with HIP events on the engine's own stream; 0 launches -> 0. */
 int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches);
 int wv_enable_kernel_timing(wv_engine* e, int enable);
+/* The same plus the number of time steps the timed launches covered: on meshes big enough to be bound
+ * by HBM bytes the engine advances TWO steps per pass over the fields (pair_kernels.hip.h; results are
+ * bit-identical to single steps), so a launch of the dominant kernel may stand for two steps. */
+int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uint64_t* steps);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);
 /* Tuning hook for the streaming kernel.  variant 2 = plane sweep, 0 = register z-march, 1 = naive.
@@ -215,6 +219,10 @@ int wv_comm_destroy(wv_engine* e);
  * *steps_done and *flag are those of the chain; receivers are fetched per engine as usual). */
 int wv_comm_init_local(wv_engine* const* engines, int32_t n);
 int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_t* steps_done, int32_t* flag);
+
+/* Measured device triad a[i] = b[i] + s*c[i] over n_doubles doubles per array (2 reads + 1 write, the
+ * stencil's byte mix), mean of `iters` launches: the bandwidth yardstick of SURVEY.md 8(d). */
+int wv_measure_triad(int32_t device, uint64_t n_doubles, int32_t iters, double* gb_per_s);
 
 /* ---- unit kernel of the boundary IIR step ------------------------------------------------------- */
 /* The reference's `filter_test_2` test kernel (src/waveguide/src/cl/filters.cpp:66-75, launched by

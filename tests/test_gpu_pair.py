@@ -1,0 +1,186 @@
+"""Two time steps per pass over the fields (csrc/pair_kernels.hip.h, engine.hip::enqueue_pair): forced
+on with WV_PAIR=1 on meshes of every shape, it must reproduce exactly what single steps produce --
+golden vectors of the reference kernel, the oracle, fields AND wall filter memories AND receiver
+traces AND the step at which an error flag stops the run.  (By default the engine takes the pair
+path only on meshes big enough to be bound by HBM bytes; tests/test_gpu_parity.py's full-size
+1024^3 test runs through it that way.)"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import golden
+from helpers import run_engine, run_oracle
+from test_gpu_parity import RAGGED, _random_case, _set_env, assert_same_run
+from wayverb_amd import engine as E
+from wayverb_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _pair_on(built_library):
+    _set_env(WV_PAIR=1)
+    yield
+    _set_env()
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_pair_path_matches_golden(name, tag):
+    r = run_engine(cases.CASES[name](), tag)
+    assert r["steps"] == cases.CASES[name]()["steps"]
+    assert_same_run(r, golden(name), tag, name)
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_pair_path_z_chunks_match_golden(chunks, tag):
+    """Several workgroups along z: each recomputes the two t+1 planes below its first plane."""
+    _set_env(WV_PAIR=1, WV_PAIR_CHUNKS=chunks)
+    r = run_engine(cases.CASES["random"](), tag)
+    assert_same_run(r, golden("random"), tag, "random")
+
+
+@pytest.mark.parametrize("dims", RAGGED + [(1024, 9, 7), (640, 13, 11)], ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_pair_path_ragged_meshes_match_oracle(oracle, dims, tag):
+    """Odd row lengths (pad columns), 1 to 8 waves per row, ny not a multiple of the strip height, the
+    minimum box; written fields first go through two single full sweeps, then pairs, then (odd
+    step count) one more single step."""
+    dtype = np.float32 if tag == "f32" else np.float64
+    case = _random_case(dims, seed=sum(dims), steps=13, reentrant=min(dims) > 5)
+    want = run_oracle(oracle, case, dtype, threads=4)
+    got = run_engine(case, tag)
+    assert want["flag"] == 0 and got["steps"] == want["steps"]
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    for a, b in zip(got["bd"], want["bd"]):
+        assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("room", ["L", "sphere", "blob"])
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_pair_path_non_box_rooms(oracle, room, tag, dtype):
+    """Curved walls, re-entrant nodes, all 26 boundary types, inside nodes next to every kind of
+    neighbour (visiting every tile: rooms with work lists keep single steps)."""
+    dims = (40, 36, 30)
+    mask = M.room_mask((dims[2], dims[1], dims[0]), room, seed=3)
+    nodes, counts = E.classify_nodes(mask)
+    rng = np.random.default_rng(17)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 3),
+                             np.array([M.flat_coefficients(0.3)], dtype=M.coefficients_dtype)])
+    mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=[0, 1, 2, 3, 0, 1])
+    inside = np.nonzero(mesh.nodes["boundary_type"] & M.ID_INSIDE)[0]
+    steps = 41
+    sig = rng.uniform(-0.1, 0.1, steps)
+    src = int(inside[len(inside) // 2])
+    # receivers: next to the source, on a wall, far away
+    wall = int(np.nonzero((mesh.nodes["boundary_type"] != 0) & ((mesh.nodes["boundary_type"] & (M.ID_INSIDE | M.ID_REENTRANT)) == 0))[0][5])
+    recv = [src + 1, wall, int(inside[3]), int(inside[-4])]
+    for kind in (E.SOURCE_HARD, E.SOURCE_SOFT):
+        case = dict(mesh=mesh, steps=steps, source_kind=kind, source_node=src, signal=sig, recv=recv, init=None)
+        want = run_oracle(oracle, case, dtype, threads=4)
+        got = run_engine(case, tag, all_tiles=True)
+        assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
+        assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+        assert got["current"].tobytes() == want["current"].tobytes()
+        assert got["previous"].tobytes() == want["previous"].tobytes()
+        for a, b in zip(got["bd"], want["bd"]):
+            assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("where", ["wall", "corner_inside", "next_to_wall"])
+def test_pair_path_source_on_and_near_walls(oracle, where):
+    mesh = M.box_mesh(20, 18, 16, coefficients=M.passive_peak_filter_coefficients(np.random.default_rng(2), 2),
+                      surface_of_face=[0, 1, 0, 1, 0, 1])
+    ci = mesh.compute_index
+    src = {"wall": ci(1, 8, 8), "corner_inside": ci(2, 2, 2), "next_to_wall": ci(2, 9, 7)}[where]
+    steps = 30
+    sig = np.random.default_rng(9).uniform(-0.2, 0.2, steps)
+    recv = [src, ci(3, 8, 8), ci(10, 9, 8), ci(1, 1, 1)]
+    for kind in (E.SOURCE_HARD, E.SOURCE_SOFT):
+        case = dict(mesh=mesh, steps=steps, source_kind=kind, source_node=src, signal=sig, recv=recv, init=None)
+        want = run_oracle(oracle, case, np.float64, threads=2)
+        got = run_engine(case, "f64")
+        assert np.array_equal(got["trace"], want["trace"])
+        assert got["current"].tobytes() == want["current"].tobytes()
+        for a, b in zip(got["bd"], want["bd"]):
+            assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("bad_step", [16, 17, 18, 0, 1])
+def test_pair_path_stops_at_the_failing_step(bad_step):
+    """The flag of each of the two steps of a pass is its own: the run stops at the exact step."""
+    mesh = M.box_mesh(12, 12, 12)
+    sig = np.zeros(40)
+    sig[0] = 1.0
+    sig[bad_step] = np.inf
+    for pair in (1, 0):
+        _set_env(WV_PAIR=pair)
+        eng = E.Engine(mesh, precision="f32")
+        eng.set_source(E.SOURCE_HARD, mesh.compute_index(6, 6, 6), sig)
+        eng.set_receivers([mesh.compute_index(7, 6, 6)])
+        done, flag = eng.run_steps(40)
+        assert done == bad_step and flag & M.ERR_INF
+        assert eng.fetch_receivers(0, bad_step).shape == (bad_step, 1)
+        eng.close()
+
+
+def test_pair_path_is_what_runs_and_changing_the_source_rebuilds_the_map(oracle):
+    """kernel_time_detail reports two steps per timed launch; moving the source between runs moves
+    the nodes whose t+2 waits for the source sample."""
+    mesh = M.box_mesh(24, 20, 18)
+    eng = E.Engine(mesh, precision="f64")
+    eng.enable_kernel_timing(True)
+    ci = mesh.compute_index
+    o_prev = np.zeros(mesh.num_nodes)
+    o_cur = np.zeros(mesh.num_nodes)
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    rng = np.random.default_rng(1)
+    for src in (ci(12, 10, 9), ci(5, 5, 5), ci(12, 10, 9)):
+        sig = rng.uniform(-0.3, 0.3, 10)
+        eng.set_source(E.SOURCE_SOFT, src, sig)
+        assert eng.run_steps(10) == (10, 0)
+        ms, launches, steps = eng.kernel_time_detail()
+        assert launches == 5 and steps == 10
+        for s in range(10):
+            o_cur[src] += sig[s]
+            assert oracle.step(o_prev, o_cur, mesh, bd) == 0
+            o_prev, o_cur = o_cur, o_prev
+        assert eng.read_field(E.BUF_CURRENT).tobytes() == o_cur.tobytes()
+        assert eng.read_field(E.BUF_PREVIOUS).tobytes() == o_prev.tobytes()
+    eng.close()
+
+
+def test_generic_steps_and_pair_passes_interleave(oracle):
+    """wv_step / wv_swap (the per-step callback path) between device-resident runs: the four field
+    buffers keep their roles straight."""
+    mesh = M.box_mesh(16, 16, 16)
+    eng = E.Engine(mesh, precision="f64")
+    o_prev = np.zeros(mesh.num_nodes)
+    o_cur = np.zeros(mesh.num_nodes)
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    node = mesh.compute_index(8, 8, 8)
+    eng.write_value(node, 1.0)
+    o_cur[node] = 1.0
+
+    def o_steps(n):
+        nonlocal o_prev, o_cur
+        for _ in range(n):
+            assert oracle.step(o_prev, o_cur, mesh, bd) == 0
+            o_prev, o_cur = o_cur, o_prev
+
+    for n_fast, n_generic in ((6, 1), (3, 2), (4, 3)):
+        assert eng.run_steps(n_fast) == (n_fast, 0)
+        o_steps(n_fast)
+        for _ in range(n_generic):
+            assert eng.step() == 0
+            eng.swap()
+        o_steps(n_generic)
+        assert eng.read_field(E.BUF_CURRENT).tobytes() == o_cur.tobytes()
+        assert eng.read_field(E.BUF_PREVIOUS).tobytes() == o_prev.tobytes()
+        assert eng.read_value(node) == o_cur[node]
+    eng.close()

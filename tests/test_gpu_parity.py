@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _set_env(**kw):
     for k in ("WV_STREAM_RY", "WV_STREAM_NWX", "WV_STREAM_NWY", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS", "WV_GRAPH",
-              "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS"):
+              "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS", "WV_PAIR", "WV_PAIR_CHUNKS"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -221,7 +221,7 @@ def test_config2_1024cubed_full_size(oracle, built_library):
          per step, so S steps leave everything S planes away from a cut exact."""
     from wayverb_amd import engine as E
     from wayverb_amd.slab import box_slab_mesh
-    n, S = 1024, 4
+    n, S = 1024, 6            # written fields: two single full sweeps first, then two two-step passes
     dims = (n, n, n)
     rng = np.random.default_rng(5)
     coeffs = M.passive_peak_filter_coefficients(rng, 1)

@@ -147,7 +147,7 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         for (int j = 0; j < 6; ++j) a.fmem[(size_t)j * a.n_slots + slot[i]] = m[i][j];
     }
     bad |= bad_bits(next);
-    a.prev[idx] = next;
+    a.next[idx] = next;
 }
 
 // entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
@@ -170,7 +170,7 @@ constexpr uint32_t kMaxLdsCoefficientSets = 256;  // 28 KiB
 template <typename Real>
 __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32_t t, uint32_t width);  // below
 
-// `next`: when next.flag is non-null the last workgroup also does the NEXT step's source injection /
+// `next`: when next.fused is set the last workgroup also does the NEXT step's source injection /
 // receiver gather (on `prev`, which is that step's `current`).  Only legal when none of those nodes
 // is a boundary node -- then they were final when the sweep before this launch ended (engine.hip).
 template <typename Real, bool LDSC>
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
         boundary_entry<Real>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
-    if (next.flag && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
+    if (next.fused && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
 }
 
 // ---- source injection + receiver gather: the pre/post callbacks, device resident -------------
@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
 // every thread of the workgroup calls this; `width` threads share the receivers
 template <typename Real>
 __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32_t t, uint32_t width) {
-    if (t == 0) *a.flag = a.flag_init;  // waveguide.h:82 (write_value(error_flag, id_success)) + static bits
+    if (t == 0 && a.flag) *a.flag = a.flag_init;  // waveguide.h:82 (write_value(error_flag, id_success)) + static bits
+    if (t == 0 && a.flag2) *a.flag2 = a.flag_init;
     Real injected = 0;
     const bool has_source = a.source_kind != 0;
     if (has_source) {

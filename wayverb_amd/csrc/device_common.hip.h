@@ -77,6 +77,10 @@ __device__ __forceinline__ double read_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// neither inf nor nan: one v_cmp_class
+__device__ __forceinline__ bool is_finite(float v) { return __builtin_amdgcn_classf(v, 0x1F8); }
+__device__ __forceinline__ bool is_finite(double v) { return __builtin_amdgcn_class(v, 0x1F8); }
+
 template <typename Real>
 __device__ __forceinline__ int bad_bits(Real v) {
     return (isinf(v) ? FLAG_INF : 0) | (isnan(v) ? FLAG_NAN : 0);
@@ -85,7 +89,8 @@ __device__ __forceinline__ int bad_bits(Real v) {
 // ---- kernel argument blocks -----------------------------------------------------------------
 template <typename Real>
 struct BoundaryArgs {
-    Real* prev;
+    const Real* prev;        // field at t-1: this node's own old value
+    Real* next;              // where the node's new value goes (= prev when the update is in place)
     const Real* cur;
     int* flag;
     const uint32_t* bnode;   // [n_entries] local node index, INVALID_NODE = unused slot
@@ -136,8 +141,10 @@ struct PrePostArgs {
     const uint64_t* recv;    // [n_recv]
     Real* recv_out;          // row of this step: [n_recv]
     uint32_t n_recv;
-    int* flag;               // this step's error_code word, reset here ...
+    int* flag;               // this step's error_code word, reset here (null: leave it alone) ...
+    int* flag2;              // (two-step pass) the next step's word, reset with it; null otherwise
     int flag_init;           // ... to the mesh-static bits (0 for a well-formed mesh)
+    int fused;               // non-zero: boundary_kernel's last workgroup does this work
 };
 
 }  // namespace wv

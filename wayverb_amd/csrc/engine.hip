@@ -21,6 +21,7 @@
 
 #include "boundary_kernels.hip.h"
 #include "comm.h"
+#include "pair_kernels.hip.h"
 #include "stream_kernels.hip.h"
 
 namespace {
@@ -108,7 +109,7 @@ struct wv_engine {
     virtual int set_receivers(const uint64_t* nodes, uint32_t n) = 0;
     virtual int run(uint64_t n_steps, uint64_t* done, int32_t* flag) = 0;
     virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
-    virtual int kernel_time(double* mean_ms, uint64_t* launches) = 0;
+    virtual int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) = 0;
     virtual int synchronize() = 0;
     virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
@@ -168,7 +169,8 @@ public:
             WV_HIP(hipMalloc((void**)&field_[i], field_bytes_ + 256));
             WV_HIP(hipMemsetAsync(field_[i], 0, field_bytes_ + 256, stream_));
         }
-        cur_ = 1;  // field_[0] = previous, field_[1] = current
+        prv_ = 0;  // field_[0] = previous, field_[1] = current; [2], [3]: outputs of a two-step pass (ensure_pair)
+        cur_ = 1;
 
         // ---- class map + compact boundary lists ------------------------------------------------
         cls_pitch_ = pitch_ / 4;
@@ -634,6 +636,7 @@ public:
         if (timed) {
             WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
             ev_used_ += 2;
+            timed_steps_ += 1;
         }
         return WV_OK;
     }
@@ -641,6 +644,7 @@ public:
     wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const {
         wv::BoundaryArgs<Real> b{};
         b.prev = prev;
+        b.next = prev;  // one step at a time: the next field replaces `previous` in place
         b.cur = cur;
         b.flag = flag;
         b.bnode = bnode_;
@@ -666,12 +670,17 @@ public:
 
     // Boundary nodes of planes [z0, z1).  MUST be enqueued after the streaming launch that covers
     // those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
+    // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
     int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1,
-                        const wv::PrePostArgs<Real>* next = nullptr) {
+                        const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr) {
         if (!n_entries_ || z0 >= z1) return WV_OK;
         wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
-        wv::PrePostArgs<Real> nx{};  // flag == nullptr: nothing fused
-        if (next) nx = *next;
+        if (out) b.next = out;
+        wv::PrePostArgs<Real> nx{};  // fused == 0: nothing rides in this launch
+        if (next) {
+            nx = *next;
+            nx.fused = 1;
+        }
         uint32_t n = n_entries_;
         if (z0 > z_begin_ || z1 < z_end_) {
             const int rc = build_plane_order();
@@ -712,7 +721,7 @@ public:
     // this step's boundary launch instead of a launch of its own -- one launch less per step,
     // which is what small meshes are bound by.
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, bool fuse_next = false) {
-        Real* prev = field_[cur_ ^ 1];
+        Real* prev = field_[prv_];
         Real* cur = field_[cur_];
         int* flag = flags_ + slot;
         int rc;
@@ -734,7 +743,7 @@ public:
             if ((rc = launch_boundary(prev, cur, flag, z_begin_, zi0))) return rc;
             if ((rc = launch_boundary(prev, cur, flag, zi1, z_end_))) return rc;
             WV_HIP(hipGetLastError());
-            if (!comm_->exchange_faces(stream_, cur_ ^ 1, &cerr)) return fail(WV_E_COMM, cerr);
+            if (!comm_->exchange_faces(stream_, prv_, &cerr)) return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
             if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
         } else {
@@ -752,6 +761,203 @@ public:
         if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
         if (outside_dirty_ > 0 && outside_dirty_ < (1 << 30)) --outside_dirty_;
+        return WV_OK;
+    }
+
+    // ---- two steps per pass (pair_kernels.hip.h) ----------------------------------------------------
+    // May this engine take two-step passes right now?  Needs: the product sweep on a whole, unsliced
+    // mesh whose rows fit one workgroup, outside nodes known to hold zeros, and (unless forced) a
+    // mesh big enough to be bound by HBM bytes rather than by launches or the Infinity Cache --
+    // two more fields are allocated the first time (288 GB of HBM: 4 x 8.6 GB at 1024^3).
+    bool pair_eligible() {
+        constexpr int WX = 64 * (16 / (int)sizeof(Real));
+        if (pair_mode_ == 0 || pair_failed_ || comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
+        if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ != 0) return false;
+        if (pair_mode_ < 0) {
+            if (stored_nodes_ < pair_min_nodes_) return false;
+            // rooms that leave much of the mesh outside keep their work lists (the march visits every strip)
+            if (build_tile_lists(z_begin_, z_end_) != WV_OK || tile_list_) return false;
+        }
+        return true;
+    }
+
+    // spare fields, the pair map and the fix-up list for the current source node
+    int ensure_pair() {
+        const uint64_t src = source_kind_ != WV_SOURCE_NONE ? source_node_ : ~0ull;
+        if (pair_map_ && pair_source_ == src) return WV_OK;
+        for (int i = 0; i < 2; ++i) {
+            Real*& f = field_[spare_[i]];
+            if (!f) {
+                if (hipMalloc((void**)&f, field_bytes_ + 256) != hipSuccess) {
+                    (void)hipGetLastError();
+                    f = nullptr;
+                    pair_failed_ = true;  // not enough memory for four fields: stay with single steps
+                    return WV_OK;
+                }
+                WV_HIP(hipMemsetAsync(f, 0, field_bytes_ + 256, stream_));
+            }
+        }
+        const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
+        if (!pair_map_) {
+            WV_HIP(hipMalloc((void**)&pair_map_, cls_bytes + 16));
+            WV_HIP(hipMemsetAsync(pair_map_, 0, cls_bytes + 16, stream_));
+        }
+        if (!pair_counter_) WV_HIP(hipMalloc((void**)&pair_counter_, sizeof(uint32_t)));
+        wv::PairMapArgs m{};
+        m.cls = cls_;
+        m.pair_map = pair_map_;
+        m.counter = pair_counter_;
+        m.source_node = src;
+        m.nx = nx_;
+        m.ny = ny_;
+        m.nz = nz_;
+        m.pitch = pitch_;
+        m.cls_pitch = cls_pitch_;
+        m.z_begin = z_begin_;
+        m.z_end = z_end_;
+        const int64_t n_bytes = (int64_t)cls_pitch_ * ny_ * nz_;
+        const unsigned grid = (unsigned)((n_bytes + 255) / 256);
+        uint32_t count = 0;
+        WV_HIP(hipMemsetAsync(pair_counter_, 0, sizeof(uint32_t), stream_));
+        hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // count
+        WV_HIP(hipMemcpyAsync(&count, pair_counter_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        if (pair_list_) {
+            (void)hipFree(pair_list_);
+            pair_list_ = nullptr;
+        }
+        pair_list_n_ = count;
+        if (count) {
+            WV_HIP(hipMalloc((void**)&pair_list_, (size_t)count * sizeof(uint32_t)));
+            m.list = pair_list_;
+            WV_HIP(hipMemsetAsync(pair_counter_, 0, sizeof(uint32_t), stream_));
+            hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // fill
+            WV_HIP(hipGetLastError());
+            // processing order: 64 x 8 x 8 bricks like the boundary entries (init), so that a wave's
+            // neighbour reads share cache lines; the values do not depend on the order
+            std::vector<uint32_t> list(count);
+            WV_HIP(hipMemcpyAsync(list.data(), pair_list_, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
+            std::vector<uint64_t> keyed(count);
+            for (uint32_t i = 0; i < count; ++i) {
+                const uint64_t idx = list[i];
+                const uint64_t x = idx % (uint32_t)pitch_, q = idx / (uint32_t)pitch_;
+                const uint64_t y = q % (uint32_t)ny_, z = q / (uint32_t)ny_;
+                const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
+                keyed[i] = (((brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63)) << 32) | idx;  // brick < 2^20
+            }
+            parallel_sort(keyed);
+            for (uint32_t i = 0; i < count; ++i) list[i] = (uint32_t)keyed[i];
+            WV_HIP(hipMemcpy(pair_list_, list.data(), (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        pair_source_ = src;
+        // march geometry: strips of 4 rows, all planes unless there are too few strips to fill the chip
+        constexpr int WX = 64 * (16 / (int)sizeof(Real));
+        pair_nw_ = pitch_ / WX;
+        pair_strips_ = (ny_ + wv::kPairRows - 1) / wv::kPairRows;
+        const int owned = z_end_ - z_begin_;
+        const int64_t resident = 256ll * std::max(1, wv::kPairMaxWaves / pair_nw_);  // workgroups the chip holds at 2 waves / SIMD
+        int chunks = env_int("WV_PAIR_CHUNKS", 0);
+        if (chunks <= 0) chunks = (int)std::max<int64_t>(1, (resident + pair_strips_ - 1) / pair_strips_);
+        chunks = std::max(1, std::min(chunks, std::max(1, owned / 8)));
+        pair_zc_ = (owned + chunks - 1) / chunks;
+        pair_chunks_ = (owned + pair_zc_ - 1) / pair_zc_;
+        return WV_OK;
+    }
+
+    static void parallel_sort(std::vector<uint64_t>& v) {
+        const size_t n = v.size();
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (n < (1u << 16) || hw < 2) {
+            std::sort(v.begin(), v.end());
+            return;
+        }
+        std::vector<size_t> cut(hw + 1);
+        for (unsigned t = 0; t <= hw; ++t) cut[t] = n * t / hw;
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < hw; ++t) workers.emplace_back([&, t] { std::sort(v.begin() + cut[t], v.begin() + cut[t + 1]); });
+        for (auto& w : workers) w.join();
+        for (unsigned width = 1; width < hw; width *= 2)
+            for (unsigned t = 0; t + width < hw; t += 2 * width)
+                std::inplace_merge(v.begin() + cut[t], v.begin() + cut[t + width], v.begin() + cut[std::min(hw, t + 2 * width)]);
+    }
+
+    // Steps `slot` and `slot + 1` of a batch in one pass: fields (prv_, cur_) = (t-1, t) in, the spare
+    // fields receive t+1 and t+2 and become (previous, current).
+    int enqueue_pair(int slot, uint64_t signal_pos, bool source_live) {
+        Real* A = field_[prv_];
+        Real* B = field_[cur_];
+        Real* O1 = field_[spare_[0]];
+        Real* O2 = field_[spare_[1]];
+        int* flag1 = flags_ + slot;
+        int* flag2 = flags_ + slot + 1;
+        int rc;
+        {   // step t: flag words of both steps, source sample into t, receivers from t
+            wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
+            pp.flag2 = flag2;
+            hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
+        wv::PairArgs<Real> a{};
+        a.prev = A;
+        a.cur = B;
+        a.out1 = O1;
+        a.out2 = O2;
+        a.pair_map = pair_map_;
+        a.flag1 = flag1;
+        a.flag2 = flag2;
+        a.ny = ny_;
+        a.nz = nz_;
+        a.pitch = pitch_;
+        a.cls_pitch = cls_pitch_;
+        a.z_begin = z_begin_;
+        a.z_end = z_end_;
+        a.nw = pair_nw_;
+        a.zc = pair_zc_;
+        a.chunks = pair_chunks_;
+        a.strips = pair_strips_;
+        a.strips_per_xcd = (pair_strips_ + 7) / 8;
+        const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)pair_chunks_;
+        const bool timed = timing && ev_used_ + 2 <= (int)events_.size();
+        if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+        if (pair_nw_ == 8)  // rows of 1024 doubles / 2048 floats: the row length folds into the code
+            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 8>), dim3(grid), dim3(512), 0, stream_, a);
+        else
+            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        if (timed) {
+            WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
+            ev_used_ += 2;
+            timed_steps_ += 2;
+        }
+        // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
+        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1))) return rc;
+        if (n_recv_ || source_live) {  // step t+1: source sample into t+1, receivers from it
+            wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
+            pp.flag = nullptr;  // reset above, and already written to by the march
+            hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
+        if (pair_list_n_) {  // t+2 of the nodes next to a boundary node / the source, from the complete t+1
+            wv::PairFixupArgs<Real> f{};
+            f.nodes = pair_list_;
+            f.n = pair_list_n_;
+            f.t1 = O1;
+            f.cur = B;
+            f.out2 = O2;
+            f.flag2 = flag2;
+            f.nx = nx_;
+            f.ny = ny_;
+            f.nz = nz_;
+            f.pitch = pitch_;
+            hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((pair_list_n_ + 255) / 256), dim3(256), 0, stream_, f);
+        }
+        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2))) return rc;
+        WV_HIP(hipGetLastError());
+        // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
+        const int a_idx = prv_, b_idx = cur_;
+        prv_ = spare_[0];
+        cur_ = spare_[1];
+        spare_[0] = a_idx;
+        spare_[1] = b_idx;
         return WV_OK;
     }
 
@@ -779,7 +985,7 @@ public:
     }
 
     int swap() override {
-        cur_ ^= 1;
+        std::swap(cur_, prv_);
         ++steps_done;
         return WV_OK;
     }
@@ -800,18 +1006,19 @@ public:
                 if (rc) return rc;
             }
             (void)io_nodes_plain();
-            const int cur_before = cur_;
+            const int cur_before = cur_, prv_before = prv_;
             hipGraph_t graph = nullptr;
             WV_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             graph_capturing_ = true;
             int rc = WV_OK;
             for (uint64_t i = 0; i < batch && rc == WV_OK; ++i) {
                 rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch);
-                cur_ ^= 1;
+                std::swap(cur_, prv_);
             }
             graph_capturing_ = false;
             const hipError_t end = hipStreamEndCapture(stream_, &graph);
             cur_ = cur_before;
+            prv_ = prv_before;
             if (rc != WV_OK) {
                 if (graph) (void)hipGraphDestroy(graph);
                 return rc;
@@ -848,7 +1055,7 @@ public:
         DeviceGuard guard(device_);
         const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_, batch_can_fuse_ && i + 1 < batch);
         if (rc) return rc;
-        cur_ ^= 1;
+        std::swap(cur_, prv_);
         return WV_OK;
     }
 
@@ -887,7 +1094,7 @@ public:
         signal_pos_ += good;
         // fields have advanced past a failing step: like the reference after its throw, the state is
         // no longer meaningful; keep the buffer roles consistent with `good` swaps
-        if (flag && good < batch && ((batch - good) & 1)) cur_ ^= 1;
+        if (flag && good < batch && ((batch - good) & 1)) std::swap(cur_, prv_);
         *good_out = good;
         *flag_out = flag;
         return WV_OK;
@@ -912,9 +1119,23 @@ public:
                 int rc = replay_batch(batch, batch_source_live_, batch_can_fuse_);
                 if (rc) return rc;
             } else {
-                for (uint64_t i = 0; i < batch; ++i) {
-                    int rc = enqueue_batch_step(i, batch);
+                // big meshes: two steps per pass over the fields wherever a batch has two left
+                bool pairs = pair_eligible();
+                if (pairs) {
+                    int rc = ensure_pair();
                     if (rc) return rc;
+                    pairs = !pair_failed_;
+                }
+                for (uint64_t i = 0; i < batch;) {
+                    if (pairs && i + 2 <= batch) {
+                        int rc = enqueue_pair((int)i, signal_pos_ + i, batch_source_live_);
+                        if (rc) return rc;
+                        i += 2;
+                    } else {
+                        int rc = enqueue_batch_step(i, batch);
+                        if (rc) return rc;
+                        i += 1;
+                    }
                 }
             }
             int rc = collect_batch(batch);
@@ -1020,7 +1241,7 @@ public:
     }
 
     // -------------------------------------------------------------------------------------------
-    Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[cur_ ^ 1]; }
+    Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[prv_]; }
     // class (CLS_*) of the node at (x, row) of the stored layout, read back from the class map
     hipError_t class_of(uint64_t x, uint64_t row, uint32_t* cls) {
         uint8_t byte = 0;
@@ -1166,12 +1387,14 @@ public:
         return WV_OK;
     }
 
-    int kernel_time(double* mean_ms, uint64_t* launches) override {
+    int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) override {
         DeviceGuard guard(device_);
         if (mean_ms) *mean_ms = time_n_ ? time_ms_ / (double)time_n_ : 0.0;
         if (launches) *launches = time_n_;
+        if (steps) *steps = timed_steps_;
         time_ms_ = 0;
         time_n_ = 0;
+        timed_steps_ = 0;
         return WV_OK;
     }
 
@@ -1201,8 +1424,9 @@ public:
         return adopt_comm(std::move(c));
     }
     int adopt_comm(std::unique_ptr<wv::SlabComm> c) {
-        void* fields[2] = {field_[0], field_[1]};
-        c->set_fields(fields, 2, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
+        // (a slab never takes two-step passes, so the roles stay within the buffers that exist now)
+        void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
+        c->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
         comm_ = std::move(c);
         return WV_OK;
     }
@@ -1221,10 +1445,10 @@ private:
         if (stream_) (void)hipStreamSynchronize(stream_);
         for (auto& e : events_) (void)hipEventDestroy(e);
         events_.clear();
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-        void* ptrs[] = {signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+        void* ptrs[] = {pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                         status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -1237,8 +1461,8 @@ private:
     int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = -1;
     uint64_t n_nodes_ = 0, stored_nodes_ = 0, field_bytes_ = 0;
     int pitch_ = 0;
-    Real* field_[2] = {nullptr, nullptr};
-    int cur_ = 1;
+    Real* field_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cur_ = 1, prv_ = 0, spare_[2] = {2, 3};  // which field_ holds which role
     uint8_t* cls_ = nullptr;
     int cls_pitch_ = 0;
     uint32_t n1_ = 0, n2_ = 0, n3_ = 0, n_entries_ = 0, n_slots_ = 0, n_coeffs_ = 0;
@@ -1270,6 +1494,17 @@ private:
     int graph_mode_ = env_int("WV_GRAPH", 0);
     uint64_t graph_max_nodes_ = 64ull << 20;
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
+    // two-step passes
+    int pair_mode_ = env_int("WV_PAIR", -1);   // 1 always (where eligible), 0 never, -1 from pair_min_nodes_ up
+    uint64_t pair_min_nodes_ = 96ull << 20;     // four fields of this size no longer fit the 256 MB Infinity Cache anyway
+    bool pair_failed_ = false;
+    uint8_t* pair_map_ = nullptr;
+    uint32_t* pair_list_ = nullptr;
+    uint32_t* pair_counter_ = nullptr;
+    uint32_t pair_list_n_ = 0;
+    uint64_t pair_source_ = 0;
+    int pair_nw_ = 1, pair_strips_ = 0, pair_zc_ = 0, pair_chunks_ = 1;
+    uint64_t timed_steps_ = 0;
     bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
@@ -1424,7 +1659,11 @@ int wv_step_count(wv_engine* e, uint64_t* steps) {
 }
 int wv_kernel_time_ms(wv_engine* e, double* mean_ms, uint64_t* launches) {
     WV_NEED(e);
-    return e->kernel_time(mean_ms, launches);
+    return e->kernel_time(mean_ms, launches, nullptr);
+}
+int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uint64_t* steps) {
+    WV_NEED(e);
+    return e->kernel_time(mean_ms, launches, steps);
 }
 int wv_enable_kernel_timing(wv_engine* e, int enable) {
     WV_NEED(e);
@@ -1507,6 +1746,50 @@ int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_
 int wv_field_pitch(wv_engine* e, uint64_t* pitch_elements) {
     WV_NEED(e);
     *pitch_elements = e->field_pitch();
+    return WV_OK;
+}
+
+// a[i] = b[i] + s * c[i] over `n` doubles, `iters` timed launches after one warm-up: the classic device
+// triad, as the yardstick bench.py prints next to the stencil's own bandwidth
+__global__ void __launch_bounds__(256) triad_kernel(double* a, const double* b, const double* c, double s, int64_t n) {
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    const int64_t n2 = n / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const V2 x = reinterpret_cast<const V2*>(b)[i], y = reinterpret_cast<const V2*>(c)[i];
+        reinterpret_cast<V2*>(a)[i] = x + s * y;
+    }
+}
+
+int wv_measure_triad(int32_t device, uint64_t n_doubles, int32_t iters, double* gb_per_s) {
+    if (!gb_per_s || n_doubles < 2 || iters < 1) return fail(WV_E_INVALID_ARGUMENT, "bad triad arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    DeviceGuard guard(device);
+    ScopedDevice a, b, c;
+    const size_t bytes = (size_t)n_doubles * sizeof(double);
+    WV_HIP(hipMalloc(&a.p, bytes));
+    WV_HIP(hipMalloc(&b.p, bytes));
+    WV_HIP(hipMalloc(&c.p, bytes));
+    WV_HIP(hipMemset(b.p, 0, bytes));
+    WV_HIP(hipMemset(c.p, 0, bytes));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    WV_HIP(hipEventCreate(&e0));
+    WV_HIP(hipEventCreate(&e1));
+    const unsigned grid = 256u * 32u;
+    for (int it = 0; it < iters + 1; ++it) {
+        if (it == 1) WV_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(triad_kernel, dim3(grid), dim3(256), 0, 0, static_cast<double*>(a.p), static_cast<const double*>(b.p),
+                           static_cast<const double*>(c.p), 0.5, (int64_t)n_doubles);
+    }
+    WV_HIP(hipEventRecord(e1, 0));
+    WV_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    WV_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    WV_HIP(hipGetLastError());
+    *gb_per_s = 3.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
     return WV_OK;
 }
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "wv_read_field", "wv_write_field", "wv_read_planes", "wv_write_planes", "wv_read_boundary_data", "wv_write_boundary_data",
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
-    "wv_enable_kernel_timing", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
+    "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
     "wv_comm_destroy", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
@@ -105,6 +105,7 @@ def load_library():
     lib.wv_step_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.wv_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.wv_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.wv_kernel_time_detail.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.wv_synchronize.argtypes = [C.c_void_p]
     lib.wv_set_stream_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.wv_filter_test_2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -226,6 +227,15 @@ def boundary_index_data(dims, min_corner, spacing, nodes, triangles, vertices):
                                       out[1].ctypes.data_as(C.c_void_p), cap[1],
                                       out[2].ctypes.data_as(C.c_void_p), cap[2], counts))
     return [out[d][:int(counts[d])].copy() for d in range(3)]
+
+
+def measure_triad(device=-1, n_doubles=1 << 28, iters=10):
+    """wv_measure_triad: GB/s of the device triad (2 reads + 1 write per element)."""
+    lib = load_library()
+    lib.wv_measure_triad.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]
+    out = C.c_double()
+    _check(lib.wv_measure_triad(device, n_doubles, iters, C.byref(out)))
+    return out.value
 
 
 def filter_test_2(inputs, memory, coeffs):
@@ -400,6 +410,14 @@ class Engine:
         n = C.c_uint64()
         _check(self.lib.wv_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_time_detail(self):
+        """(mean ms per launch of the dominant kernel, launches, time steps those launches covered)"""
+        ms = C.c_double()
+        n = C.c_uint64()
+        steps = C.c_uint64()
+        _check(self.lib.wv_kernel_time_detail(self.h, C.byref(ms), C.byref(n), C.byref(steps)))
+        return ms.value, n.value, steps.value
 
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
