@@ -211,9 +211,16 @@ def main():
     steps_per_launch = (timed_steps / launches) if launches else 1.0
     two_step = steps_per_launch > 1.5
     timed_planes = (layout.z1 - layout.z0) - (int(layout.ghost_lo) + int(layout.ghost_hi))
-    # algorithmic bytes: 3 fields of `elem` bytes per node-update x node-updates per launch
-    alg_bytes = int(3 * elem * nx * ny * timed_planes * steps_per_launch)
+    # Algorithmic bytes of one launch = what the kernel has to move if every value crosses the HBM
+    # interface once: the single-step sweep reads 2 fields and writes 1 per node
+    # (3 x elem = 24 B per node-update in fp64); the two-step pass reads 2 and writes 2 for TWO updates
+    # per node (4 x elem = 32 B per node and pass, 16 B per node-update).
+    fields_per_launch = 4 if two_step else 3
+    alg_bytes = int(fields_per_launch * elem * nx * ny * timed_planes)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # the same launch priced at the single-step figure (24 B per node-update): what a one-step-per-pass
+    # kernel would have to sustain to keep up -- above the HBM peak is the point of the two-step pass
+    per_update_equiv = 3 * elem * nx * ny * timed_planes * steps_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     kernel_name = "pair_march_kernel" if two_step else "stream_sweep_kernel"
     # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
     # when it was measured on this very device code, this kernel and this workload
@@ -252,11 +259,13 @@ def main():
                      "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                      "time_steps_per_launch": round(steps_per_launch, 3),
                      "alg_bytes_per_launch": alg_bytes,
-                     "alg_bytes_definition": "24 B (fp64) per node-update x node-updates per launch; a two-step pass "
-                                             "needs only 4 fields of HBM traffic per node for its 2 updates",
-                     "min_traffic_per_launch": int((4 if two_step else 3) * elem * nx * ny * timed_planes),
+                     "alg_bytes_definition": ("two-step pass: read fields t-1, t, write t+1, t+2 = 4 x %d B per node and launch "
+                                              "(16 B per node-update in fp64)" % elem) if two_step else
+                                             ("single-step sweep: read 2 fields, write 1 = 3 x %d B per node-update" % elem),
+                     "single_step_equivalent": {"bytes_per_node_update": 3 * elem, "achieved": round(per_update_equiv, 1),
+                                                "frac": round(per_update_equiv / HBM_PEAK_GBS, 4)},
                      "triad_gbs": triad,
-                     "whole_step_frac": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "whole_step_frac_at_24B_per_update": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
     eng.close()
 
