@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
                     o2[k] = live ? o2[k] : Real(0);
                     // one class test per value; exact flags are worked out after the march, and only
                     // if anything non-finite was seen at all (never, in a healthy run)
-                    if (!(X & PX_NO_FLAGS)) nonfinite = nonfinite || !is_finite(o1[k]) || !is_finite(o2[k]);
+                    if (!(X & PX_NO_FLAGS)) nonfinite |= (bool)((int)!is_finite(o1[k]) | (int)!is_finite(o2[k]));  // no short circuit: no branch
                 }
                 if (X & PX_STORE_CACHED) {
                     t.store_cached(a.out1, y0 + r, z, o1);
