@@ -87,11 +87,13 @@ def test_concert_hall_impulse_response(hall, oracle, precision, dtype):
     assert spec[freqs > 260].max() < 5e-2 * spec.max()                             # band-limited at the 200 Hz cutoff
 
 
+@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
 @pytest.mark.parametrize("world", [2, 8])
-def test_concert_hall_in_z_slabs(hall, world):
+def test_concert_hall_in_z_slabs(hall, world, pair, monkeypatch):
     """The hall cut into z-slabs and stepped as a chain == the single-domain run (fields, wall filter
     memories, receiver traces), source and receiver wherever they fall."""
     from test_gpu_slabs import assert_same, single_domain, slab_chain
+    monkeypatch.setenv("WV_PAIR", str(pair))
     vm = hall["vm"]
     mesh = vm.mesh
     steps = 90

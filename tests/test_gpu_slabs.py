@@ -14,6 +14,25 @@ from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes"])
+def _step_mode(request):
+    """Every test of this file runs twice: with the engine's default choice (single steps on meshes this
+    small) and with two-step passes forced on (WV_PAIR=1), where a slab exchanges its face planes
+    twice per pass -- t+1, then t+2 (engine.hip::enqueue_pair_a / _b).  Slabs with fewer than four
+    planes cannot take two-step passes, and then the whole chain falls back together."""
+    import os
+    old = os.environ.get("WV_PAIR")
+    if request.param == "two-step-passes":
+        os.environ["WV_PAIR"] = "1"
+    else:
+        os.environ.pop("WV_PAIR", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("WV_PAIR", None)
+    else:
+        os.environ["WV_PAIR"] = old
+
+
 def materials(rng):
     return np.concatenate([M.passive_peak_filter_coefficients(rng, 4),
                            np.array([M.rigid_coefficients(), M.flat_coefficients(0.2)], dtype=M.coefficients_dtype)])
@@ -63,7 +82,11 @@ def slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, recei
         layouts.append(L)
         recv_maps.append(mine)
     group = E.LocalSlabGroup(engines)
+    for e in engines:
+        e.enable_kernel_timing(True)
     done, flag = group.run_steps(steps)
+    # which path ran: time steps per timed launch of the dominant kernel (2 = two-step passes)
+    detail = [e.kernel_time_detail() for e in engines]
     trace = np.full((done, len(receivers)), np.nan)
     ghost_trace = {}
     cur, prev, bd = [], [], [[], [], []]
@@ -81,7 +104,7 @@ def slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, recei
         for d in range(3):
             bd[d].append(e.read_boundary_data(d + 1))
     group.close()
-    return dict(done=done, flag=flag, trace=trace, ghost_trace=ghost_trace, cur=np.concatenate(cur),
+    return dict(done=done, flag=flag, trace=trace, ghost_trace=ghost_trace, cur=np.concatenate(cur), detail=detail,
                 prev=np.concatenate(prev), bd=[np.concatenate(b) for b in bd])
 
 
@@ -112,7 +135,7 @@ def assert_same(got, want, gmesh):
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 @pytest.mark.parametrize("world,room,dims", [(2, "box", (16, 14, 24)), (3, "box", (40, 36, 25)), (8, "box", (16, 14, 24)),
                                              (2, "L", (20, 18, 24)), (3, "blob", (24, 22, 26)), (8, "L", (36, 20, 48))])
-def test_slab_chain_equals_single_domain(built_library, world, room, dims, precision):
+def test_slab_chain_equals_single_domain(built_library, world, room, dims, precision, _step_mode):
     rng = np.random.default_rng(2024 + world)
     gmesh = global_mesh(dims, room, rng)
     dtype = np.float32 if precision == "f32" else np.float64
@@ -144,6 +167,10 @@ def test_slab_chain_equals_single_domain(built_library, world, room, dims, preci
         assert want["done"] == steps and want["flag"] == 0
         assert_same(got, want, gmesh)
         assert len(got["ghost_trace"]) >= 1          # at least the -z neighbour was read from a ghost plane
+        planes = dims[2] // world
+        if _step_mode == "two-step-passes" and planes >= 4:
+            # written fields -> two single full sweeps first, then passes of two steps
+            assert all(steps_ > launches for _, launches, steps_ in got["detail"] if launches), got["detail"]
 
 
 def test_a_flag_on_one_slab_stops_the_whole_chain(built_library):

@@ -111,7 +111,9 @@ struct BoundaryArgs {
 
 template <typename Real>
 struct StreamArgs {
-    Real* prev;          // previous field, overwritten in place with the next field
+    const Real* prev;    // previous field
+    Real* next;          // where the next field goes: = prev (in place) except for the face planes of a
+                         // slab's two-step pass, which go to another field
     const Real* cur;     // current field (read only)
     const uint8_t* cls;  // class map (see cls_word_index), cls_pitch = pitch/4 words per row group
     int* flag;           // error_code word of this step

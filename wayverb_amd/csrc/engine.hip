@@ -118,7 +118,9 @@ struct wv_engine {
     virtual int comm_destroy() = 0;
     // a batch of steps in parts, so that a group of slabs can be driven in lockstep (wv_run_group)
     virtual uint64_t plan_batch(uint64_t remaining) = 0;
-    virtual int enqueue_batch_step(uint64_t i, uint64_t batch) = 0;
+    virtual int enqueue_batch_step(uint64_t i, uint64_t batch, bool next_is_single) = 0;
+    virtual int enqueue_batch_pair(uint64_t i, int part) = 0;
+    virtual int batch_pairs_ready(int* singles_first) = 0;
     virtual int collect_batch(uint64_t batch) = 0;
     virtual const int* batch_flags() const = 0;
     virtual int commit_batch(uint64_t batch, const int* flags, uint64_t* good, int32_t* flag) = 0;
@@ -335,7 +337,7 @@ public:
                              hipMemcpyHostToDevice));
 
         // ---- per-step rings ---------------------------------------------------------------------
-        WV_HIP(hipMalloc((void**)&flags_, kRing * sizeof(int)));
+        WV_HIP(hipMalloc((void**)&flags_, (kRing + 1) * sizeof(int)));  // + one word for collective decisions
         WV_HIP(hipHostMalloc((void**)&flags_host_, kRing * sizeof(int), hipHostMallocDefault));
         WV_HIP(hipMalloc((void**)&scratch_, 64));
 
@@ -583,10 +585,12 @@ public:
         return WV_OK;
     }
 
-    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed) {
+    // `out`: where the new field goes (null: in place, over `prev`)
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr) {
         if (z0 >= z1) return WV_OK;
         wv::StreamArgs<Real> a{};
         a.prev = prev;
+        a.next = out ? out : prev;
         a.cur = cur;
         a.cls = cls_;
         a.flag = flag;
@@ -771,8 +775,11 @@ public:
     // two more fields are allocated the first time (288 GB of HBM: 4 x 8.6 GB at 1024^3).
     bool pair_eligible() {
         constexpr int WX = 64 * (16 / (int)sizeof(Real));
-        if (pair_mode_ == 0 || pair_failed_ || comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
-        if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ != 0) return false;
+        if (pair_mode_ == 0 || pair_failed_) return false;
+        if (comm_ && comm_->nranks() == 1 && (opt_.ghost_lo || opt_.ghost_hi)) return false;  // single-rank loopback: single steps
+        if ((opt_.ghost_lo || opt_.ghost_hi) && (!comm_ || z_end_ - z_begin_ < 4)) return false;
+        // (outside nodes a caller wrote to are zeroed by two single full sweeps first: batch_pairs_ready)
+        if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
         if (pair_mode_ < 0) {
             if (stored_nodes_ < pair_min_nodes_) return false;
             // rooms that leave much of the mesh outside keep their work lists (the march visits every strip)
@@ -797,12 +804,16 @@ public:
                 WV_HIP(hipMemsetAsync(f, 0, field_bytes_ + 256, stream_));
             }
         }
+        if (comm_) {  // the exchange has to know the two new fields
+            void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
+            comm_->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
+        }
         const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
         if (!pair_map_) {
             WV_HIP(hipMalloc((void**)&pair_map_, cls_bytes + 16));
             WV_HIP(hipMemsetAsync(pair_map_, 0, cls_bytes + 16, stream_));
         }
-        if (!pair_counter_) WV_HIP(hipMalloc((void**)&pair_counter_, sizeof(uint32_t)));
+        if (!pair_counter_) WV_HIP(hipMalloc((void**)&pair_counter_, 2 * sizeof(uint32_t)));
         wv::PairMapArgs m{};
         m.cls = cls_;
         m.pair_map = pair_map_;
@@ -815,48 +826,60 @@ public:
         m.cls_pitch = cls_pitch_;
         m.z_begin = z_begin_;
         m.z_end = z_end_;
+        // a slab's face planes are not marched: their t+2 needs the neighbour's t+1 face (enqueue_pair)
+        pair_z0_ = z_begin_ + (opt_.ghost_lo ? 1 : 0);
+        pair_z1_ = z_end_ - (opt_.ghost_hi ? 1 : 0);
+        m.march_begin = pair_z0_;
+        m.march_end = pair_z1_;
         const int64_t n_bytes = (int64_t)cls_pitch_ * ny_ * nz_;
         const unsigned grid = (unsigned)((n_bytes + 255) / 256);
-        uint32_t count = 0;
-        WV_HIP(hipMemsetAsync(pair_counter_, 0, sizeof(uint32_t), stream_));
+        uint32_t count[2] = {0, 0};
+        WV_HIP(hipMemsetAsync(pair_counter_, 0, 2 * sizeof(uint32_t), stream_));
         hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // count
-        WV_HIP(hipMemcpyAsync(&count, pair_counter_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipMemcpyAsync(count, pair_counter_, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
         if (pair_list_) {
             (void)hipFree(pair_list_);
             pair_list_ = nullptr;
         }
-        pair_list_n_ = count;
-        if (count) {
-            WV_HIP(hipMalloc((void**)&pair_list_, (size_t)count * sizeof(uint32_t)));
+        pair_list_n_ = count[0];
+        pair_face_n_ = count[1];
+        const uint32_t total = count[0] + count[1];
+        if (total) {
+            // one allocation: [marched planes' nodes][face planes' nodes]
+            WV_HIP(hipMalloc((void**)&pair_list_, (size_t)total * sizeof(uint32_t)));
             m.list = pair_list_;
-            WV_HIP(hipMemsetAsync(pair_counter_, 0, sizeof(uint32_t), stream_));
+            m.list_face = pair_list_ + count[0];
+            WV_HIP(hipMemsetAsync(pair_counter_, 0, 2 * sizeof(uint32_t), stream_));
             hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // fill
             WV_HIP(hipGetLastError());
             // processing order: 64 x 8 x 8 bricks like the boundary entries (init), so that a wave's
             // neighbour reads share cache lines; the values do not depend on the order
-            std::vector<uint32_t> list(count);
-            WV_HIP(hipMemcpyAsync(list.data(), pair_list_, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            std::vector<uint32_t> list(total);
+            WV_HIP(hipMemcpyAsync(list.data(), pair_list_, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
             WV_HIP(hipStreamSynchronize(stream_));
             const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
-            std::vector<uint64_t> keyed(count);
-            for (uint32_t i = 0; i < count; ++i) {
-                const uint64_t idx = list[i];
-                const uint64_t x = idx % (uint32_t)pitch_, q = idx / (uint32_t)pitch_;
-                const uint64_t y = q % (uint32_t)ny_, z = q / (uint32_t)ny_;
-                const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
-                keyed[i] = (((brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63)) << 32) | idx;  // brick < 2^20
+            for (int part = 0; part < 2; ++part) {
+                const uint32_t first = part ? count[0] : 0u, n = count[part];
+                std::vector<uint64_t> keyed(n);
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint64_t idx = list[first + i];
+                    const uint64_t x = idx % (uint32_t)pitch_, q = idx / (uint32_t)pitch_;
+                    const uint64_t y = q % (uint32_t)ny_, z = q / (uint32_t)ny_;
+                    const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
+                    keyed[i] = (((brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63)) << 32) | idx;  // brick < 2^20
+                }
+                parallel_sort(keyed);
+                for (uint32_t i = 0; i < n; ++i) list[first + i] = (uint32_t)keyed[i];
             }
-            parallel_sort(keyed);
-            for (uint32_t i = 0; i < count; ++i) list[i] = (uint32_t)keyed[i];
-            WV_HIP(hipMemcpy(pair_list_, list.data(), (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice));
+            WV_HIP(hipMemcpy(pair_list_, list.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
         pair_source_ = src;
         // march geometry: strips of 4 rows, all planes unless there are too few strips to fill the chip
         constexpr int WX = 64 * (16 / (int)sizeof(Real));
         pair_nw_ = pitch_ / WX;
         pair_strips_ = (ny_ + wv::kPairRows - 1) / wv::kPairRows;
-        const int owned = z_end_ - z_begin_;
+        const int owned = pair_z1_ - pair_z0_;
         const int64_t resident = 256ll * std::max(1, wv::kPairMaxWaves / pair_nw_);  // workgroups the chip holds at 2 waves / SIMD
         int chunks = env_int("WV_PAIR_CHUNKS", 0);
         if (chunks <= 0) chunks = (int)std::max<int64_t>(1, (resident + pair_strips_ - 1) / pair_strips_);
@@ -885,7 +908,16 @@ public:
 
     // Steps `slot` and `slot + 1` of a batch in one pass: fields (prv_, cur_) = (t-1, t) in, the spare
     // fields receive t+1 and t+2 and become (previous, current).
-    int enqueue_pair(int slot, uint64_t signal_pos, bool source_live) {
+    //
+    // On a slab the two time levels each need the neighbours' face planes, so a pass has two exchanges:
+    //   part A  face planes to t+1 (sweep + boundary nodes, out of place) -> exchange #1 of the t+1 field
+    //           -> march over the planes in between (t+1 and t+2) + their boundary nodes to t+1,
+    //           overlapping the exchange
+    //   part B  ghosts of t+1 landed -> source / receivers on t+1 -> face planes to t+2 (fix-up list of all
+    //           their nodes + boundary nodes) -> exchange #2 of the t+2 field -> the other fix-up nodes and
+    //           boundary nodes to t+2, overlapping it.
+    // A chain inside one process (wv_run_group) enqueues part A of every slab before part B of any.
+    int enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live) {
         Real* A = field_[prv_];
         Real* B = field_[cur_];
         Real* O1 = field_[spare_[0]];
@@ -893,10 +925,21 @@ public:
         int* flag1 = flags_ + slot;
         int* flag2 = flags_ + slot + 1;
         int rc;
+        std::string cerr;
+        if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+        if (pre_post_done_) return fail(WV_E_STATE, "a two-step pass cannot follow a step that served its source / receivers early");
         {   // step t: flag words of both steps, source sample into t, receivers from t
             wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
             pp.flag2 = flag2;
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
+        if (comm_) {
+            if ((rc = launch_stream(A, B, flag1, z_begin_, pair_z0_, false, O1))) return rc;
+            if ((rc = launch_stream(A, B, flag1, pair_z1_, z_end_, false, O1))) return rc;
+            if ((rc = launch_boundary(A, B, flag1, z_begin_, pair_z0_, nullptr, O1))) return rc;
+            if ((rc = launch_boundary(A, B, flag1, pair_z1_, z_end_, nullptr, O1))) return rc;
+            WV_HIP(hipGetLastError());
+            if (!comm_->exchange_faces(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
         }
         wv::PairArgs<Real> a{};
         a.prev = A;
@@ -910,8 +953,8 @@ public:
         a.nz = nz_;
         a.pitch = pitch_;
         a.cls_pitch = cls_pitch_;
-        a.z_begin = z_begin_;
-        a.z_end = z_end_;
+        a.z_begin = pair_z0_;
+        a.z_end = pair_z1_;
         a.nw = pair_nw_;
         a.zc = pair_zc_;
         a.chunks = pair_chunks_;
@@ -930,34 +973,80 @@ public:
             timed_steps_ += 2;
         }
         // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
-        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1))) return rc;
+        if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, nullptr, O1))) return rc;
+        WV_HIP(hipGetLastError());
+        return WV_OK;
+    }
+
+    int launch_fixup(uint32_t first, uint32_t n, const Real* t1, const Real* cur, Real* out2, int* flag2) {
+        if (!n) return WV_OK;
+        wv::PairFixupArgs<Real> f{};
+        f.nodes = pair_list_ + first;
+        f.n = n;
+        f.t1 = t1;
+        f.cur = cur;
+        f.out2 = out2;
+        f.flag2 = flag2;
+        f.nx = nx_;
+        f.ny = ny_;
+        f.nz = nz_;
+        f.pitch = pitch_;
+        hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((n + 255) / 256), dim3(256), 0, stream_, f);
+        return WV_OK;
+    }
+
+    int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live) {
+        Real* B = field_[cur_];
+        Real* O1 = field_[spare_[0]];
+        Real* O2 = field_[spare_[1]];
+        int* flag2 = flags_ + slot + 1;
+        int rc;
+        std::string cerr;
+        if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
         if (n_recv_ || source_live) {  // step t+1: source sample into t+1, receivers from it
             wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
-            pp.flag = nullptr;  // reset above, and already written to by the march
+            pp.flag = nullptr;  // reset in part A, and already written to by the march
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
-        if (pair_list_n_) {  // t+2 of the nodes next to a boundary node / the source, from the complete t+1
-            wv::PairFixupArgs<Real> f{};
-            f.nodes = pair_list_;
-            f.n = pair_list_n_;
-            f.t1 = O1;
-            f.cur = B;
-            f.out2 = O2;
-            f.flag2 = flag2;
-            f.nx = nx_;
-            f.ny = ny_;
-            f.nz = nz_;
-            f.pitch = pitch_;
-            hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((pair_list_n_ + 255) / 256), dim3(256), 0, stream_, f);
+        if (comm_) {
+            if ((rc = launch_fixup(pair_list_n_, pair_face_n_, O1, B, O2, flag2))) return rc;
+            if ((rc = launch_boundary(B, O1, flag2, z_begin_, pair_z0_, nullptr, O2))) return rc;
+            if ((rc = launch_boundary(B, O1, flag2, pair_z1_, z_end_, nullptr, O2))) return rc;
+            WV_HIP(hipGetLastError());
+            if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
         }
-        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2))) return rc;
+        // t+2 of the nodes next to a boundary node / the source, from the complete t+1; then the boundary nodes
+        if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2))) return rc;
         WV_HIP(hipGetLastError());
+        if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
         const int a_idx = prv_, b_idx = cur_;
         prv_ = spare_[0];
         cur_ = spare_[1];
         spare_[0] = a_idx;
         spare_[1] = b_idx;
+        return WV_OK;
+    }
+
+    // part 0 / 1 of the two-step pass that covers steps i and i + 1 of the batch
+    int enqueue_batch_pair(uint64_t i, int part) override {
+        DeviceGuard guard(device_);
+        return part == 0 ? enqueue_pair_a((int)i, signal_pos_ + i, batch_source_live_)
+                         : enqueue_pair_b((int)i, signal_pos_ + i, batch_source_live_);
+    }
+
+    // Would this engine take two-step passes in the batch being planned?  *singles_first = -1: no;
+    // otherwise the number of single steps (full sweeps) that must come first because a caller wrote
+    // into outside nodes (0, 1 or 2).  Decided per batch, and by all slabs of a chain together: they
+    // must agree, or their exchanges would not pair up.
+    int batch_pairs_ready(int* singles_first) override {
+        DeviceGuard guard(device_);
+        *singles_first = -1;
+        if (!pair_eligible()) return WV_OK;
+        const int rc = ensure_pair();
+        if (rc) return rc;
+        if (!pair_failed_) *singles_first = outside_dirty_;
         return WV_OK;
     }
 
@@ -1051,9 +1140,12 @@ public:
         return batch;
     }
 
-    int enqueue_batch_step(uint64_t i, uint64_t batch) override {
+    // `next_is_single`: step i + 1 of the batch is a single step too (its source / receiver work may
+    // then ride in this step's boundary launch; a two-step pass does its own)
+    int enqueue_batch_step(uint64_t i, uint64_t batch, bool next_is_single) override {
         DeviceGuard guard(device_);
-        const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_, batch_can_fuse_ && i + 1 < batch);
+        const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_,
+                                    batch_can_fuse_ && next_is_single && i + 1 < batch);
         if (rc) return rc;
         std::swap(cur_, prv_);
         return WV_OK;
@@ -1120,20 +1212,30 @@ public:
                 if (rc) return rc;
             } else {
                 // big meshes: two steps per pass over the fields wherever a batch has two left
-                bool pairs = pair_eligible();
-                if (pairs) {
-                    int rc = ensure_pair();
-                    if (rc) return rc;
-                    pairs = !pair_failed_;
+                int singles_first = -1;
+                int rc = batch_pairs_ready(&singles_first);
+                if (rc) return rc;
+                if (comm_ && comm_->nranks() > 1) {
+                    // every rank of the chain has to take the same path: one flag word, OR-ed over the
+                    // ranks -- bit 3 "some rank cannot", bits 0-1 the largest number of single steps any
+                    // rank needs first (thermometer code: OR = max)
+                    int word = singles_first < 0 ? 8 : (singles_first >= 2 ? 3 : singles_first);
+                    std::string cerr;
+                    WV_HIP(hipMemcpyAsync(flags_ + kRing, &word, sizeof(int), hipMemcpyHostToDevice, stream_));
+                    if (!comm_->or_flags(stream_, flags_ + kRing, 1, &cerr)) return fail(WV_E_COMM, cerr);
+                    WV_HIP(hipMemcpyAsync(&word, flags_ + kRing, sizeof(int), hipMemcpyDeviceToHost, stream_));
+                    WV_HIP(hipStreamSynchronize(stream_));
+                    singles_first = (word & 8) ? -1 : ((word & 2) ? 2 : (word & 1));
                 }
+                const bool pairs = singles_first >= 0;
+                auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
                 for (uint64_t i = 0; i < batch;) {
-                    if (pairs && i + 2 <= batch) {
-                        int rc = enqueue_pair((int)i, signal_pos_ + i, batch_source_live_);
-                        if (rc) return rc;
+                    if (pair_at(i)) {
+                        if ((rc = enqueue_batch_pair(i, 0))) return rc;
+                        if ((rc = enqueue_batch_pair(i, 1))) return rc;
                         i += 2;
                     } else {
-                        int rc = enqueue_batch_step(i, batch);
-                        if (rc) return rc;
+                        if ((rc = enqueue_batch_step(i, batch, !pair_at(i + 1)))) return rc;
                         i += 1;
                     }
                 }
@@ -1424,7 +1526,6 @@ public:
         return adopt_comm(std::move(c));
     }
     int adopt_comm(std::unique_ptr<wv::SlabComm> c) {
-        // (a slab never takes two-step passes, so the roles stay within the buffers that exist now)
         void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
         c->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
         comm_ = std::move(c);
@@ -1501,7 +1602,8 @@ private:
     uint8_t* pair_map_ = nullptr;
     uint32_t* pair_list_ = nullptr;
     uint32_t* pair_counter_ = nullptr;
-    uint32_t pair_list_n_ = 0;
+    uint32_t pair_list_n_ = 0, pair_face_n_ = 0;  // fix-up nodes of the marched planes / of a slab's face planes
+    int pair_z0_ = 0, pair_z1_ = 0;                // planes the march produces
     uint64_t pair_source_ = 0;
     int pair_nw_ = 1, pair_strips_ = 0, pair_zc_ = 0, pair_chunks_ = 1;
     uint64_t timed_steps_ = 0;
@@ -1718,12 +1820,34 @@ int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_
         uint64_t batch = n_steps - completed;
         for (int k = 0; k < n; ++k) batch = std::min(batch, engines[k]->plan_batch(n_steps - completed));
         if (batch == 0) break;
-        // lockstep: step i of every slab is enqueued before step i + 1 of any (comm.h, local transport)
-        for (uint64_t i = 0; i < batch; ++i)
-            for (int k = 0; k < n; ++k) {
-                const int rc = engines[k]->enqueue_batch_step(i, batch);
-                if (rc) return rc;
+        // two-step passes only if every slab can take them, after the single steps any of them needs first
+        int singles_first = 0;
+        for (int k = 0; k < n && singles_first >= 0; ++k) {
+            int mine = -1;
+            const int rc = engines[k]->batch_pairs_ready(&mine);
+            if (rc) return rc;
+            singles_first = mine < 0 ? -1 : std::max(singles_first, mine);
+        }
+        const bool pairs = singles_first >= 0;
+        // lockstep: step i of every slab is enqueued before step i + 1 of any, and the two parts of a
+        // two-step pass likewise (comm.h, local transport)
+        auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+        for (uint64_t i = 0; i < batch;) {
+            if (pair_at(i)) {
+                for (int part = 0; part < 2; ++part)
+                    for (int k = 0; k < n; ++k) {
+                        const int rc = engines[k]->enqueue_batch_pair(i, part);
+                        if (rc) return rc;
+                    }
+                i += 2;
+            } else {
+                for (int k = 0; k < n; ++k) {
+                    const int rc = engines[k]->enqueue_batch_step(i, batch, !pair_at(i + 1));
+                    if (rc) return rc;
+                }
+                i += 1;
             }
+        }
         ored.assign((size_t)batch, 0);
         for (int k = 0; k < n; ++k) {
             const int rc = engines[k]->collect_batch(batch);

@@ -348,11 +348,13 @@ __global__ void __launch_bounds__(256) pair_fixup_kernel(const PairFixupArgs<Rea
 struct PairMapArgs {
     const uint8_t* cls;
     uint8_t* pair_map;
-    uint32_t* list;        // null: count only
-    uint32_t* counter;     // number of code-3 nodes (count pass), write cursor (fill pass)
+    uint32_t* list;        // null: count only.  Nodes of the marched planes first ...
+    uint32_t* list_face;   // ... nodes of a slab's face planes here (the march does not produce those planes)
+    uint32_t* counter;     // [2]: code-3 nodes of the marched planes / of the face planes (count pass), write cursors (fill pass)
     uint64_t source_node;  // stored index of the source node, ~0 = none
     int nx, ny, nz, pitch, cls_pitch;
-    int z_begin, z_end;    // planes the pair pass produces
+    int z_begin, z_end;          // planes this engine owns
+    int march_begin, march_end;  // planes the march produces: all owned planes but a slab's face planes
 };
 
 // one thread per class byte (4 nodes of one row)
@@ -385,10 +387,14 @@ __global__ void __launch_bounds__(256) pair_map_kernel(const PairMapArgs a) {
             }
             // (a neighbour off the stored grid contributes the same 0 to the march as to the reference's
             // update; a pad column, x in [nx, pitch), is class "none" and sends its neighbour to the list)
+            // a slab's face planes wait for the neighbour's t+1 face: the fix-up list takes all of their nodes
+            const bool marched = z >= a.march_begin && z < a.march_end;
+            plain = plain && marched;
             code = plain ? 1u : 3u;
             if (!plain && z >= a.z_begin && z < a.z_end) {
-                const uint32_t at = atomicAdd(a.counter, 1u);
-                if (a.list) a.list[at] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + x);
+                const uint32_t at = atomicAdd(a.counter + (marched ? 0 : 1), 1u);
+                uint32_t* dst = marched ? a.list : a.list_face;
+                if (dst) dst[at] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + x);
             }
         }
         out |= code << (2 * k);

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
             out = s;
             bad |= bad_bits(out);
         }
-        a.prev[idx] = out;
+        a.next[idx] = out;
     }
     if (bad) atomicOr(a.flag, bad);
 }
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_march_kernel(const Stre
                 bool skip = false;
                 const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r + 1], pv[r], mid_e, r,
                                                   cl[r], bad, skip);
-                store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
+                store_row<Real, X>(a.next + io.at(y0 + r, z), out, cl[r], skip);
             }
         }
         // ---- rotate the register planes
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_nolds_kernel(cons
             bool skip = false;
             const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r],
                                               bad, skip);
-            store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
+            store_row<Real, X>(a.next + io.at(y0 + r, z), out, cl[r], skip);
         }
     }
     if (__any(bad != 0)) {
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
             bool skip = false;
             const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r], bad,
                                               skip);
-            store_row<Real, X>(a.prev + io.at(y0 + r, z), out, cl[r], skip);
+            store_row<Real, X>(a.next + io.at(y0 + r, z), out, cl[r], skip);
         }
     }
     if (__any(bad != 0)) {
