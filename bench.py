@@ -48,6 +48,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-small", action="store_true", help="skip the 256^3 side measurement")
+    p.add_argument("--no-reference-on-gpu", action="store_true",
+                   help="skip running the reference's OpenCL kernel on this GPU (oracle/_ref/libwvref_cl.so)")
     return p.parse_args()
 
 
@@ -287,6 +289,18 @@ def main():
         out["config"]["also_256cubed_gnode_per_s"] = round(256 ** 3 * 2000 / dt / 1e9, 2)
         e2.close()
 
+    if world == 1 and rank == 0 and not args.no_reference_on_gpu:
+        # the reference's own OpenCL program, JIT-compiled by this box's OpenCL runtime and run on this
+        # very GPU (worker process; bounded: 512^3, a few dozen steps) -- context for `value`, not part of it
+        try:
+            from oracle.oracle import ReferenceOnDevice
+            if ReferenceOnDevice.built():
+                ref = ReferenceOnDevice()
+                if ref.device_name():
+                    out["reference_on_gpu"] = {"as_written_f32": ref.bench(512, 30, "f32"),
+                                               "pressures_promoted_to_f64": ref.bench(512, 30, "f64")}
+        except Exception as e:  # a baseline must never sink the bench line
+            out["reference_on_gpu"] = {"error": str(e)[:300]}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, elem)
     elif rank == 0:

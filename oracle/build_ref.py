@@ -17,7 +17,10 @@ What this does (recipe from SURVEY.md section 8(c) / Appendix F):
      *language builtins* the kernel calls (get_global_id, popcount, isnan, ...; OpenCL
      1.2 spec semantics) and a serial driver loop;
   4. leaves only oracle/_ref/libwvref_f32.so and oracle/_ref/libwvref_f64.so behind
-     (git-ignored; they travel to the GPU box like any built .so).
+     (git-ignored; they travel to the GPU box like any built .so);
+  5. also builds oracle/_ref/libwvref_cl.so: the same two program texts as DATA next to an OpenCL
+     host driver (oracle/ref_cl_driver.cpp) that gives them to the OpenCL runtime at run time, as
+     the reference's own library does -- on the GPU box that is ROCm's OpenCL on the MI355X.
 
 If /root/reference is absent (GPU box) this script is a no-op: the prebuilt .so files are used.
 """
@@ -228,6 +231,29 @@ def build_bcf(tmp, verbose):
         print("[build_ref] built", so)
 
 
+def build_cl(tmp, verbose):
+    """oracle/_ref/libwvref_cl.so: the program text (as written, and pressure-promoted) as data next to
+    oracle/ref_cl_driver.cpp, which hands it to the OpenCL runtime of the machine it runs on -- on the
+    GPU box the reference's kernel then runs on the MI355X itself.  Skipped when the image has no
+    OpenCL headers / loader."""
+    if not os.path.exists("/opt/rocm/include/CL/cl.h"):
+        if verbose:
+            print("[build_ref] no OpenCL headers: libwvref_cl.so not built")
+        return
+    gen = os.path.join(tmp, "program_text.c")
+    with open(gen, "w") as f:
+        for tag, promote in (("f32", False), ("f64", True)):
+            data = assemble(promote).encode("utf-8") + b"\0"
+            f.write("const char wvref_program_text_%s[] = {%s};\n" % (tag, ",".join(str(b) for b in data)))
+    so = os.path.join(OUT, "libwvref_cl.so")
+    obj = os.path.join(tmp, "program_text.o")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", gen, "-o", obj])
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++14", "-isystem", "/opt/rocm/include",
+                           os.path.join(HERE, "ref_cl_driver.cpp"), obj, "-o", so, "-lOpenCL"])
+    if verbose:
+        print("[build_ref] built", so)
+
+
 def build(verbose=True):
     if not os.path.isdir(WG):
         if verbose:
@@ -238,6 +264,7 @@ def build(verbose=True):
     with tempfile.TemporaryDirectory(prefix="wvref_") as tmp:
         build_setup(tmp, verbose)
         build_bcf(tmp, verbose)
+        build_cl(tmp, verbose)
         for tag, promote in (("f32", False), ("f64", True)):
             cl = os.path.join(tmp, "program_%s.cl" % tag)
             with open(cl, "w") as f:

@@ -281,3 +281,61 @@ class Reference:
         out = np.zeros_like(inp)
         self._ft(_ptr(inp), _ptr(out), _ptr(memory), _ptr(coeffs), len(inp))
         return out
+
+
+class ReferenceOnDevice:
+    """The reference's OpenCL program run by the machine's own OpenCL runtime (oracle/ref_cl_driver.cpp
+    + the program text inside oracle/_ref/libwvref_cl.so): on the GPU box, the reference's kernel on
+    the MI355X through ROCm's OpenCL.  TEST / BENCH-BASELINE INFRASTRUCTURE ONLY.
+
+    Runs in a worker process (oracle/ref_cl_worker.py): ROCm's OpenCL runtime and the HIP runtime
+    bundled with torch bring one HSA runtime each, and a process that initialises both loses its GPU."""
+
+    PATH = os.path.join(HERE, "_ref", "libwvref_cl.so")
+    WORKER = os.path.join(HERE, "ref_cl_worker.py")
+
+    @classmethod
+    def built(cls):
+        return os.path.exists(cls.PATH)
+
+    def _worker(self, *args, timeout=3600):
+        import subprocess
+        import sys
+        env = dict(os.environ)
+        p = subprocess.run([sys.executable, self.WORKER] + [str(a) for a in args], capture_output=True, text=True,
+                           timeout=timeout, env=env)
+        if p.returncode != 0:
+            raise RuntimeError("reference on the OpenCL device: " + (p.stderr.strip() or p.stdout.strip())[-2000:])
+        return p.stdout
+
+    def device_name(self):
+        """Name of the OpenCL GPU device, or None when there is none."""
+        try:
+            out = self._worker("name").strip()
+        except RuntimeError:
+            return None
+        return out or None
+
+    def run(self, previous, current, mesh, bd, source_kind, source_node, signal, n_steps, recv, contract_off=False):
+        """waveguide::run on the OpenCL device.  previous / current / bd are updated in place (roles as
+        after the last swap).  Returns (steps, flag, traces[steps, len(recv)], seconds of the step loop)."""
+        import tempfile
+        assert previous.dtype in (np.float32, np.float64) and current.dtype == previous.dtype
+        with tempfile.TemporaryDirectory(prefix="wvrefcl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            fin, fout = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
+            np.savez(fin, dims=np.array(mesh.dims), nodes=mesh.nodes, coefficients=mesh.coefficients, bd1=bd[0], bd2=bd[1],
+                     bd3=bd[2], previous=previous, current=current, source_kind=source_kind, source_node=source_node,
+                     signal=np.asarray(signal, dtype=np.float64), n_steps=n_steps, recv=np.asarray(recv, dtype=np.uint64),
+                     contract_off=bool(contract_off))
+            self._worker("run", fin, fout)
+            out = np.load(fout)
+            previous[...] = out["previous"]
+            current[...] = out["current"]
+            for dst, key in zip(bd, ("bd1", "bd2", "bd3")):
+                dst[...] = out[key]
+            return int(out["steps"]), int(out["flag"]), out["trace"], float(out["seconds"])
+
+    def bench(self, n, steps, tag):
+        """Gnode-updates/s of the reference's kernel on an n^3 box (built inside the worker): a dict."""
+        import json
+        return json.loads(self._worker("bench", n, steps, tag).strip().splitlines()[-1])

@@ -880,9 +880,24 @@ public:
         pair_nw_ = pitch_ / WX;
         pair_strips_ = (ny_ + wv::kPairRows - 1) / wv::kPairRows;
         const int owned = pair_z1_ - pair_z0_;
-        const int64_t resident = 256ll * std::max(1, wv::kPairMaxWaves / pair_nw_);  // workgroups the chip holds at 2 waves / SIMD
+        // Workgroups the chip holds at once: 256 CUs x (8 wave slots at 2 waves / SIMD) / waves per
+        // workgroup.  Chunks along z are chosen so that the workgroups fill whole rounds of that, weighed
+        // against the three planes every chunk recomputes or loads before its first output plane.
+        const int64_t slots = 256ll * std::max(1, wv::kPairMaxWaves / pair_nw_);
         int chunks = env_int("WV_PAIR_CHUNKS", 0);
-        if (chunks <= 0) chunks = (int)std::max<int64_t>(1, (resident + pair_strips_ - 1) / pair_strips_);
+        if (chunks <= 0) {
+            double best = 0;
+            for (int c = 1; c <= std::max(1, owned / 8) && c <= 256; ++c) {
+                const int64_t wgs = (int64_t)pair_strips_ * c;
+                const int64_t rounds = (wgs + slots - 1) / slots;
+                const double zc = (double)((owned + c - 1) / c);
+                const double cost = (double)(rounds * slots) / (double)wgs * (zc + 3.0) / zc;
+                if (chunks <= 0 || cost < best - 1e-9) {
+                    best = cost;
+                    chunks = c;
+                }
+            }
+        }
         chunks = std::max(1, std::min(chunks, std::max(1, owned / 8)));
         pair_zc_ = (owned + chunks - 1) / chunks;
         pair_chunks_ = (owned + pair_zc_ - 1) / pair_zc_;
