@@ -354,7 +354,8 @@ typedef struct wv_waveguide_band {
     double valid_hz_min, valid_hz_max;
 } wv_waveguide_band;
 enum { WV_ATTENUATOR_NULL = 0,       /* core::attenuator::null: the pressure itself */
-       WV_ATTENUATOR_MICROPHONE = 1  /* core::attenuator::microphone (pointing, shape) */ };
+       WV_ATTENUATOR_MICROPHONE = 1  /* core::attenuator::microphone (pointing, shape) */
+       /* core::attenuator::hrtf: 8 bands per sample, see the wv_*_hrtf entry points below */ };
 enum { WV_FILTER_LOPASS = 0, WV_FILTER_HIPASS = 1, WV_FILTER_BANDPASS = 2 };
 
 /* attenuate / make_attenuate_mapper (src/waveguide/include/waveguide/attenuator.h:13-49;
@@ -378,6 +379,35 @@ int wv_frequency_domain_filter(float* signal, uint64_t n, int32_t kind, double e
 int wv_postprocess_waveguide(const wv_waveguide_band* bands, uint32_t n_bands, int32_t method, const float pointing[3],
                              float shape, float acoustic_impedance, double output_sample_rate, float* out,
                              uint64_t capacity, uint64_t* n_out);
+
+/* ---- HRTF receiver capsules (core::attenuator::hrtf, src/core/include/core/attenuator/hrtf.h) ---------
+ * The reference looks the 8 band energies of a direction up in a table it generates AT BUILD TIME from
+ * measured head-related impulse responses (src/hrtf/cmd/main.cpp writes hrtf_entries.h; neither that file
+ * nor the measurements are in the reference tree), so the table is the caller's to supply:
+ *   energy[az][el][channel][band], az in [0, az_num): azimuth az * 360 / az_num degrees,
+ *   el in [0, el_num): elevation (el + 1) * 180 / (el_num + 1) - 90 degrees (el_num odd), channel 0 = left,
+ *   nearest-entry lookup exactly as vector_look_up_table.h:50-110 (azimuth = atan2(x, -z) negated, elevation =
+ *   asin(y), in the head's frame: pointing = -z, up = +y; orientation.cpp:21-43). */
+typedef struct wv_hrtf_table {
+    const double* energy;
+    uint32_t az_num, el_num;
+} wv_hrtf_table;
+/* attenuation(hrtf, incident) (src/core/src/attenuator/hrtf.cpp:121-133) */
+int wv_hrtf_attenuation(const wv_hrtf_table* table, const float pointing[3], const float up[3], int32_t channel,
+                        const float incident[3], float bands[8]);
+/* get_ear_position (hrtf.cpp:135-141); fails with "Hrtf radius outside reasonable range." unless 0 <= radius <= 1 */
+int wv_hrtf_ear_position(const float pointing[3], const float up[3], int32_t channel, float radius,
+                         const float base_position[3], float ear[3]);
+/* attenuate / make_attenuate_mapper with an hrtf method (attenuator.h:13-49): out[n][8] */
+int wv_attenuate_hrtf(const wv_hrtf_table* table, const float pointing[3], const float up[3], int32_t channel,
+                      float acoustic_impedance, const wv_directional_output* in, uint64_t n, float* out);
+/* core::multiband_filter_and_mixdown (src/core/include/core/mixdown.h:17-26; hrtf_data::multiband_filter,
+ * src/hrtf/lib/include/hrtf/multiband.h:38-44): bands[n][8] is filtered in place, out[n] = sum of the 8 bands */
+int wv_multiband_filter_and_mixdown(float* bands, uint64_t n, double sample_rate, float* out);
+/* waveguide::postprocess with an hrtf method (postprocess.h:57-126).  Size-query protocol as above. */
+int wv_postprocess_waveguide_hrtf(const wv_waveguide_band* bands, uint32_t n_bands, const wv_hrtf_table* table,
+                                  const float pointing[3], const float up[3], int32_t channel, float acoustic_impedance,
+                                  double output_sample_rate, float* out, uint64_t capacity, uint64_t* n_out);
 
 #ifdef __cplusplus
 }

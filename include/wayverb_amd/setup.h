@@ -19,7 +19,8 @@
 //     triangles, 8-band absorption per surface) instead of core::generic_scene_data /
 //     voxelised_scene_data templates; `voxels_and_mesh::voxels` is the flattened voxel array the
 //     device kernels walk (what scene_buffers uploads), not the octree object.
-//   - microphone / null attenuators only (the HRTF tables are not part of this engine).
+//   - the hrtf attenuator takes its direction table from `core::attenuator::hrtf_look_up_table()`, which the
+//     caller fills (the reference generates its table at build time from data outside its tree).
 //   - `voxels_and_mesh` here is what the single- and multi-band `canonical` overloads take by value, as in
 //     the reference (canonical.h:100-110,138-148).
 #pragma once
@@ -53,6 +54,24 @@ struct microphone final {  // src/core/include/core/attenuator/microphone.h
     waveguide::vec3 pointing{0, 0, 1};
     float shape{0};
 };
+struct hrtf final {  // src/core/include/core/attenuator/hrtf.h:12-37 (orientation: pointing + up, orientation.h:16-34)
+    enum class channel { left, right };
+    waveguide::vec3 pointing{0, 0, -1};
+    waveguide::vec3 up{0, 1, 0};
+    channel ear{channel::left};
+    float radius{0.1f};
+};
+/// The direction -> 8 band energies table.  The reference bakes it in at build time (hrtf_entries.h, written
+/// by src/hrtf/cmd from measured responses that are not part of its source tree); here it is set once per
+/// process: energy[az][el][ear][band], az_num x el_num (odd) directions.
+struct hrtf_table final {
+    std::vector<double> energy;
+    uint32_t az_num{0}, el_num{0};
+};
+inline hrtf_table& hrtf_look_up_table() {
+    static hrtf_table t;
+    return t;
+}
 }  // namespace attenuator
 }  // namespace core
 
@@ -279,6 +298,44 @@ inline std::vector<float> postprocess(const std::vector<bandpass_band>& results,
     const float p[3] = {mic.pointing.x, mic.pointing.y, mic.pointing.z};
     return detail::postprocess_impl(results, WV_ATTENUATOR_MICROPHONE, p, mic.shape, acoustic_impedance,
                                     output_sample_rate);
+}
+
+/// postprocess.h:74-126 for an HRTF capsule: 8 bands per sample, band-filtered and mixed down (mixdown.h:17-26)
+inline std::vector<float> postprocess(const std::vector<bandpass_band>& results, const core::attenuator::hrtf& h,
+                                      double acoustic_impedance, double output_sample_rate) {
+    const auto& t = core::attenuator::hrtf_look_up_table();
+    if (t.energy.size() != (size_t)t.az_num * t.el_num * 16 || t.energy.empty())
+        throw std::runtime_error{"hrtf_look_up_table() has not been filled"};
+    const wv_hrtf_table table{t.energy.data(), t.az_num, t.el_num};
+    std::vector<std::vector<wv_directional_output>> keep;
+    std::vector<wv_waveguide_band> bands;
+    for (const auto& r : results) {
+        keep.push_back(detail::to_abi(r.band));
+        bands.push_back(wv_waveguide_band{keep.back().data(), keep.back().size(), r.band.sample_rate,
+                                          r.valid_hz.get_min(), r.valid_hz.get_max()});
+    }
+    const float p[3] = {h.pointing.x, h.pointing.y, h.pointing.z}, u[3] = {h.up.x, h.up.y, h.up.z};
+    const int ear = h.ear == core::attenuator::hrtf::channel::left ? 0 : 1;
+    uint64_t n = 0;
+    auto call = [&](float* out, uint64_t cap) {
+        if (wv_postprocess_waveguide_hrtf(bands.data(), (uint32_t)bands.size(), &table, p, u, ear, (float)acoustic_impedance,
+                                          output_sample_rate, out, cap, &n) != WV_OK)
+            throw std::runtime_error{wv_last_error()};
+    };
+    call(nullptr, 0);
+    std::vector<float> out(n);
+    call(out.data(), n);
+    return out;
+}
+
+/// get_ear_position (hrtf.cpp:135-141)
+inline vec3 get_ear_position(const core::attenuator::hrtf& h, const vec3& base_position) {
+    const float p[3] = {h.pointing.x, h.pointing.y, h.pointing.z}, u[3] = {h.up.x, h.up.y, h.up.z};
+    const float b[3] = {base_position.x, base_position.y, base_position.z};
+    float e[3];
+    if (wv_hrtf_ear_position(p, u, h.ear == core::attenuator::hrtf::channel::left ? 0 : 1, h.radius, b, e) != WV_OK)
+        throw std::runtime_error{wv_last_error()};
+    return vec3{e[0], e[1], e[2]};
 }
 
 /// config.cpp:29-56

@@ -261,6 +261,30 @@ static void scene_to_audio() {
     REQUIRE(peak > 0);
     const auto omni = postprocess(*bands, attenuator::null{}, env.acoustic_impedance, 44100.0);
     REQUIRE(omni.size() == audio.size());
+    // HRTF capsules (core::attenuator::hrtf): a table whose right ear hears twice the energy of the left
+    {
+        auto& table = attenuator::hrtf_look_up_table();
+        table.az_num = 24;
+        table.el_num = 11;
+        table.energy.assign((size_t)table.az_num * table.el_num * 16, 0.0);
+        for (size_t cell = 0; cell < (size_t)table.az_num * table.el_num; ++cell)
+            for (int ear = 0; ear < 2; ++ear)
+                for (int b = 0; b < 8; ++b) table.energy[(cell * 2 + ear) * 8 + b] = ear ? 1.0 : 0.5;
+        attenuator::hrtf left, right;
+        right.ear = attenuator::hrtf::channel::right;
+        const auto l = postprocess(*bands, left, env.acoustic_impedance, 44100.0);
+        const auto r = postprocess(*bands, right, env.acoustic_impedance, 44100.0);
+        REQUIRE(l.size() == audio.size() && r.size() == audio.size());
+        float pl = 0, pr = 0;
+        for (size_t i = 0; i < l.size(); ++i) {
+            REQUIRE(std::isfinite(l[i]) && std::isfinite(r[i]));
+            pl = std::max(pl, std::fabs(l[i]));
+            pr = std::max(pr, std::fabs(r[i]));
+        }
+        REQUIRE(pl > 0 && std::fabs(pr / pl - 2.0f) < 1e-3f);  // sqrt(|I| att^2 Z): linear in the table entry
+        const vec3 ear_l = get_ear_position(left, receiver), ear_r = get_ear_position(right, receiver);
+        REQUIRE(std::fabs(ear_r.x - ear_l.x - 0.2f) < 1e-6f && ear_l.y == receiver.y);
+    }
     bool threw = false;
     try {
         postprocess(*bands, mic, 250.0, 44100.0);

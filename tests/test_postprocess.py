@@ -106,3 +106,100 @@ def test_postprocess_chain(built_library, method):
     want = O.postprocess(bands, P.adjust_sampling_rate, method, pointing, 0.5, 400.0, 16000.0)
     assert got.shape == want.shape == (3200,)     # the longer of 700 * 4 and 400 * 8
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+# ---- HRTF receiver capsules (core::attenuator::hrtf).  PARITY UNPINNED for the table's numbers: the reference
+# generates them at build time from measured data outside its tree; the look-up, the per-band attenuation and the
+# 8-band filter + mixdown are restated in oracle/postprocess_oracle.py and checked here on synthetic tables.
+def _table(az_num=72, el_num=17, seed=0):
+    """energy[az, el, ear, band] that names its own indices, plus a little seeded noise"""
+    rng = np.random.default_rng(seed)
+    e = np.zeros((az_num, el_num, 2, 8))
+    a, l, c, b = np.meshgrid(np.arange(az_num), np.arange(el_num), np.arange(2), np.arange(8), indexing="ij")
+    e[...] = 0.2 + 0.01 * a + 0.001 * l + 0.3 * c + 0.05 * b + rng.uniform(0, 1e-4, e.shape)
+    return e
+
+
+def test_hrtf_lookup_matches_restatement(built_library):
+    energy = _table()
+    table = P.HrtfTable(energy)
+    rng = np.random.default_rng(8)
+    pointing, up = (0.3, 0.1, -0.9), (0.05, 1.0, 0.1)
+    dirs = list(rng.normal(size=(400, 3))) + [np.array(v, dtype=float) for v in
+                                              ((0, 1, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (1, 0, 0), (-1, 0, 0), (0, 0, 0))]
+    seen = set()
+    for d in dirs:
+        for ch in (0, 1):
+            got = P.hrtf_attenuation(table, d, pointing, up, ch)
+            want = O.hrtf_attenuation(energy, pointing, up, ch, np.asarray(d, dtype=np.float32))
+            assert np.array_equal(got, want), (d, ch)
+            seen.add(round(float(got[0] - (0.3 if ch else 0.0)), 2))
+    assert len(seen) > 30                                  # many different table cells were reached
+    # the head turned together with the source hears the same thing
+    front = P.hrtf_attenuation(table, (0, 0, -1))
+    assert np.array_equal(P.hrtf_attenuation(table, (1, 0, 0), pointing=(1, 0, 0)), front)
+    # a source to the left (-x for a head looking down -z) is azimuth -90 degrees -> index 3/4 of the way round
+    left = P.hrtf_attenuation(table, (-1, 0, 0))
+    assert abs(float(left[0]) - (0.2 + 0.01 * 18 + 0.001 * 8)) < 2e-4
+    with pytest.raises(AssertionError):
+        P.HrtfTable(np.zeros((72, 16, 2, 8)))              # elevation divisions must be odd (vector_look_up_table.h:27)
+
+
+def test_hrtf_ear_positions(built_library):
+    base = np.array([1.0, 2.0, 3.0], dtype=np.float32)
+    l = P.hrtf_ear_position(base, channel=0, radius=0.1)
+    r = P.hrtf_ear_position(base, channel=1, radius=0.1)
+    assert np.allclose(l, [0.9, 2.0, 3.0]) and np.allclose(r, [1.1, 2.0, 3.0])   # looking down -z: +x is the right ear
+    turned = P.hrtf_ear_position(base, pointing=(1, 0, 0), channel=1, radius=0.1)  # looking down +x: right ear towards +z
+    assert np.allclose(turned, [1.0, 2.0, 3.1], atol=1e-6)
+    with pytest.raises(WaveguideError, match="Hrtf radius outside reasonable range."):
+        P.hrtf_ear_position(base, radius=1.5)
+
+
+def test_hrtf_attenuator_and_mixdown_match_restatement(built_library):
+    energy = _table(seed=2)
+    table = P.HrtfTable(energy)
+    rng = np.random.default_rng(6)
+    d = _directional(rng, 1500)
+    pointing, up = (0.0, 0.2, -1.0), (0.0, 1.0, 0.0)
+    got = P.attenuate_hrtf(d, table, pointing, up, 1, 410.0)
+    want = O.attenuate_hrtf(d, energy, pointing, up, 1, 410.0)
+    assert np.array_equal(got, want)
+    assert np.all(got[::17] == 0)                                                  # zero intensity -> zero in every band
+    with pytest.raises(WaveguideError, match="Acoustic impedance outside expected range."):
+        P.attenuate_hrtf(d, table, pointing, up, 1, 250.0)
+    fb, mix = P.multiband_filter_and_mixdown(got, 16000.0)
+    ob, omix = O.multiband_filter_and_mixdown(got, 16000.0)
+    scale = np.abs(ob).max()
+    assert np.abs(fb - ob).max() <= 2e-6 * scale and np.abs(mix - omix).max() <= 1e-5 * scale
+
+
+def test_the_eight_bands_add_up_to_the_audible_range(built_library):
+    """Crossovers are sin^2 / cos^2 pairs: the band gains sum to 1 between 20 Hz and 20 kHz, so a signal that
+    lives there, copied into all 8 bands, comes back from the mixdown."""
+    sr = 44100.0
+    n = 4096
+    t = np.arange(n) / sr
+    x = (np.sin(2 * np.pi * 330.0 * t) + 0.5 * np.sin(2 * np.pi * 2500.0 * t + 1.0)) * np.hanning(n)
+    bands = np.repeat(x.astype(np.float32)[:, None], 8, axis=1)
+    _, mix = P.multiband_filter_and_mixdown(bands, sr)
+    assert np.abs(mix - x).max() < 2e-3 * np.abs(x).max()
+
+
+def test_hrtf_postprocess_with_a_flat_table_is_the_omni_microphone(built_library):
+    """All energies 1: the capsule hears every direction alike, and (the bands adding up to 1 inside 20 Hz ..
+    20 kHz) the chain equals the omnidirectional microphone's wherever the 20 Hz band edge has no say."""
+    rng = np.random.default_rng(12)
+    n, sr = 6000, 8000.0
+    d = np.zeros(n, dtype=P.directional_output_dtype)
+    t = np.arange(n) / sr
+    d["pressure"] = (np.sin(2 * np.pi * 400 * t) * np.exp(-t * 3)).astype(np.float32)
+    d["intensity"] = (rng.normal(size=(n, 3)) * 1e-3 * np.abs(d["pressure"])[:, None]).astype(np.float32)
+    bands = [(d, sr, (0.0, 2000.0))]
+    table = P.HrtfTable(np.ones((36, 9, 2, 8)))
+    hrtf = P.postprocess_hrtf(bands, table, output_sample_rate=16000.0)
+    mic = P.postprocess(bands, P.ATTENUATOR_MICROPHONE, (0, 0, -1), 0.0, 400.0, 16000.0)
+    assert hrtf.shape == mic.shape and np.abs(mic).max() > 0
+    assert np.abs(hrtf - mic).max() < 0.02 * np.abs(mic).max()
+    # and an ear that hears nothing from anywhere gives silence
+    assert np.abs(P.postprocess_hrtf(bands, P.HrtfTable(np.zeros((36, 9, 2, 8))), output_sample_rate=16000.0)).max() == 0

@@ -29,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include "../../include/wayverb_amd.h"
@@ -187,6 +188,137 @@ float attenuate(int method, const float pointing[3], float shape, float Z, const
     return std::copysign(std::sqrt(intensity * Z), s.pressure);
 }
 
+// ---- HRTF attenuator (src/core/src/attenuator/hrtf.cpp, vector_look_up_table.h, az_el.cpp, orientation.cpp)
+struct Orientation {  // orientation.cpp:10-33: right-handed, +y up, -z forwards
+    float m[3][3];    // columns x_axis, y_axis, z_axis of get_matrix()
+};
+
+void normalize3(float v[3]) {
+    const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int k = 0; k < 3; ++k) v[k] /= l;
+}
+void cross3(const float a[3], const float b[3], float out[3]) {
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+Orientation make_orientation(const float pointing_in[3], const float up_in[3]) {
+    float pointing[3] = {pointing_in[0], pointing_in[1], pointing_in[2]}, up[3] = {up_in[0], up_in[1], up_in[2]};
+    normalize3(pointing);
+    normalize3(up);
+    Orientation o;
+    float z_axis[3] = {-pointing[0], -pointing[1], -pointing[2]}, x_axis[3], y_axis[3];
+    cross3(up, z_axis, x_axis);
+    normalize3(x_axis);
+    cross3(z_axis, x_axis, y_axis);
+    normalize3(y_axis);
+    for (int k = 0; k < 3; ++k) {
+        o.m[k][0] = x_axis[k];
+        o.m[k][1] = y_axis[k];
+        o.m[k][2] = z_axis[k];
+    }
+    return o;
+}
+
+// transform (orientation.cpp:41-43): inverse(get_matrix()) * vec, general 3x3 inverse by cofactors
+void to_object_space(const Orientation& o, const float v[3], float out[3]) {
+    const float(*a)[3] = o.m;
+    const float c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
+                c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    const float det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+    const float inv[3][3] = {
+            {c00 / det, (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det, (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det},
+            {c01 / det, (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det, (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det},
+            {c02 / det, (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det, (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det}};
+    for (int r = 0; r < 3; ++r) out[r] = inv[r][0] * v[0] + inv[r][1] * v[1] + inv[r][2] * v[2];
+}
+
+// almost_equal(a, b, ulps) of src/core/include/core/almost_equal.h, for the poles of az_el.cpp:64-71
+bool almost_equal_ulps(float x, float y, int ulp) {
+    return std::abs(x - y) < std::numeric_limits<float>::epsilon() * std::abs(x + y) * (float)ulp ||
+           std::abs(x - y) < std::numeric_limits<float>::min();
+}
+
+struct TableIndex {
+    size_t azimuth, elevation;
+};
+
+// vector_look_up_table<T, az_num, el_num>::index (vector_look_up_table.h:50-110)
+TableIndex table_index(const float dir[3], uint32_t az_num, uint32_t el_num) {
+    float azimuth = std::atan2(dir[0], -dir[2]);  // az_el.cpp:56-62
+    const float elevation = std::asin(dir[1]);
+    if (almost_equal_ulps(elevation, (float)(-kPi / 2), 10) || almost_equal_ulps(elevation, (float)(kPi / 2), 10)) azimuth = 0;
+    const auto degrees = [](float radians) { return (float)(radians * 180 / kPi); };
+    const double az_angle = 360.0 / az_num, el_angle = 180.0 / (el_num + 1);
+    double az = (double)degrees(-azimuth) + az_angle / 2;
+    while (az < 0) az += 360;
+    double el = (double)degrees(elevation) + 90 + el_angle / 2;
+    while (el < 0) el += 360;
+    const size_t adjusted = (size_t)(el / el_angle) % (2 * ((size_t)el_num + 1));
+    if ((size_t)el_num + 1 < adjusted) throw std::runtime_error("Elevation out of range.");
+    return TableIndex{(size_t)(az / az_angle) % az_num, std::max<size_t>(1, std::min<size_t>(el_num, adjusted)) - 1};
+}
+
+// attenuation(hrtf, incident) (hrtf.cpp:121-133): the table's 8 band energies for the direction `incident`
+// comes from, seen from the oriented head; zeros for a zero vector
+void hrtf_attenuation(const wv_hrtf_table& t, const Orientation& o, int channel, const float incident[3], float bands[8]) {
+    const float l = std::sqrt(incident[0] * incident[0] + incident[1] * incident[1] + incident[2] * incident[2]);
+    for (int b = 0; b < 8; ++b) bands[b] = 0;
+    if (!l) return;
+    const float unit[3] = {incident[0] / l, incident[1] / l, incident[2] / l};
+    float local[3];
+    to_object_space(o, unit, local);
+    const TableIndex i = table_index(local, t.az_num, t.el_num);
+    const double* e = t.energy + (((size_t)i.azimuth * t.el_num + i.elevation) * 2 + (channel ? 1 : 0)) * 8;
+    for (int b = 0; b < 8; ++b) bands[b] = (float)e[b];
+}
+
+// attenuate (attenuator.h:13-23) with a bands_type attenuation: 8 values per sample
+void attenuate_hrtf(const wv_hrtf_table& t, const Orientation& o, int channel, float Z, const wv_directional_output& s,
+                    float out[8]) {
+    const float minus[3] = {-s.intensity[0], -s.intensity[1], -s.intensity[2]};
+    float att[8];
+    hrtf_attenuation(t, o, channel, minus, att);
+    const float l = std::sqrt(s.intensity[0] * s.intensity[0] + s.intensity[1] * s.intensity[1] + s.intensity[2] * s.intensity[2]);
+    for (int b = 0; b < 8; ++b) {
+        const float intensity = l * std::pow(att[b], 2.0f);
+        out[b] = std::copysign(std::sqrt(intensity * Z), s.pressure);
+    }
+}
+
+// hrtf_data::hrtf_band_params (multiband.h:26-36): 9 edges of the 8 bands over 20 Hz .. 20 kHz, relative to the
+// sample rate, and the crossover width factor for overlap 1 (envelope.cpp:5-16)
+void hrtf_band_params(double sample_rate, double edges[9], double* width_factor) {
+    for (int i = 0; i < 9; ++i) edges[i] = 20.0 * std::pow(20000.0 / 20.0, i / 8.0) / sample_rate;
+    const double base = std::pow(20000.0 / 20.0, 1.0 / 8);
+    *width_factor = (base - 1) / (base + 1);
+}
+
+// multiband_filter_and_mixdown (mixdown.h:17-26, multiband_filter.h:47-90): band i of every sample is band-passed
+// to band i's range, then the 8 bands of a sample are summed
+std::vector<float> multiband_filter_and_mixdown(std::vector<float>& bands, size_t n, double sample_rate) {
+    double edges[9], wf;
+    hrtf_band_params(sample_rate, edges, &wf);
+    std::vector<float> column(n);
+    for (int b = 0; b < 8; ++b) {
+        for (size_t i = 0; i < n; ++i) column[i] = bands[i * 8 + b];
+        frequency_domain_filter(column.data(), n, [&](double f) {
+            return lopass_magnitude(f, edges[b + 1], wf, 0) * hipass_magnitude(f, edges[b], wf, 0);
+        });
+        for (size_t i = 0; i < n; ++i) bands[i * 8 + b] = column[i];
+    }
+    std::vector<float> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        float s = 0;
+        for (int b = 0; b < 8; ++b) s += bands[i * 8 + b];
+        out[i] = s;
+    }
+    return out;
+}
+
+bool table_ok(const wv_hrtf_table* t) { return t && t->energy && t->az_num >= 1 && t->el_num >= 1 && (t->el_num % 2) == 1; }
+
 }  // namespace
 
 extern "C" int wv_attenuate(int32_t method, const float pointing[3], float shape, float acoustic_impedance,
@@ -262,6 +394,89 @@ extern "C" int wv_postprocess_waveguide(const wv_waveguide_band* bands, uint32_t
             for (size_t i = 0; i < processed.size(); ++i) ret[i] += processed[i];
         }
         // DC block at 10 Hz (postprocess.h:108-122)
+        const double dc_block = 10.0 / output_sample_rate;
+        frequency_domain_filter(ret.data(), ret.size(), [&](double f) { return hipass_magnitude(f, dc_block, 0.9, 0); });
+        *n_out = ret.size();
+        if (out && capacity >= ret.size()) std::copy(ret.begin(), ret.end(), out);
+    } catch (const std::exception& e) {
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, e.what());
+    }
+    return WV_OK;
+}
+
+// ---- HRTF receiver (core::attenuator::hrtf) -----------------------------------------------------------
+extern "C" int wv_hrtf_attenuation(const wv_hrtf_table* table, const float pointing[3], const float up[3], int32_t channel,
+                                   const float incident[3], float bands[8]) {
+    if (!table_ok(table) || !pointing || !up || !incident || !bands)
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument (elevation divisions must be odd)");
+    try {
+        hrtf_attenuation(*table, make_orientation(pointing, up), channel, incident, bands);
+    } catch (const std::exception& e) {
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, e.what());
+    }
+    return WV_OK;
+}
+
+extern "C" int wv_hrtf_ear_position(const float pointing[3], const float up[3], int32_t channel, float radius,
+                                    const float base_position[3], float ear[3]) {
+    if (!pointing || !up || !base_position || !ear) return wv::fail_with(WV_E_INVALID_ARGUMENT, "null argument");
+    if (radius < 0 || 1 < radius) return wv::fail_with(WV_E_INVALID_ARGUMENT, "Hrtf radius outside reasonable range.");
+    const Orientation o = make_orientation(pointing, up);
+    const float x = channel ? radius : -radius;  // hrtf.cpp:135-141: left ear at -radius along the head's x axis
+    for (int k = 0; k < 3; ++k) ear[k] = base_position[k] + o.m[k][0] * x;
+    return WV_OK;
+}
+
+extern "C" int wv_attenuate_hrtf(const wv_hrtf_table* table, const float pointing[3], const float up[3], int32_t channel,
+                                 float acoustic_impedance, const wv_directional_output* in, uint64_t n, float* out) {
+    if (!table_ok(table) || !pointing || !up || (n && (!in || !out)))
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument (elevation divisions must be odd)");
+    if (acoustic_impedance < 300 || 500 <= acoustic_impedance)
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, "Acoustic impedance outside expected range.");
+    try {
+        const Orientation o = make_orientation(pointing, up);
+        for (uint64_t i = 0; i < n; ++i) attenuate_hrtf(*table, o, channel, acoustic_impedance, in[i], out + i * 8);
+    } catch (const std::exception& e) {
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, e.what());
+    }
+    return WV_OK;
+}
+
+extern "C" int wv_multiband_filter_and_mixdown(float* bands, uint64_t n, double sample_rate, float* out) {
+    if ((n && (!bands || !out)) || !(sample_rate > 0)) return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument");
+    std::vector<float> work(bands, bands + n * 8);
+    const std::vector<float> mixed = multiband_filter_and_mixdown(work, n, sample_rate);
+    std::copy(work.begin(), work.end(), bands);
+    std::copy(mixed.begin(), mixed.end(), out);
+    return WV_OK;
+}
+
+extern "C" int wv_postprocess_waveguide_hrtf(const wv_waveguide_band* bands, uint32_t n_bands, const wv_hrtf_table* table,
+                                             const float pointing[3], const float up[3], int32_t channel,
+                                             float acoustic_impedance, double output_sample_rate, float* out,
+                                             uint64_t capacity, uint64_t* n_out) {
+    if ((n_bands && !bands) || !n_out || !table_ok(table) || !pointing || !up)
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, "bad argument (elevation divisions must be odd)");
+    if (acoustic_impedance < 300 || 500 <= acoustic_impedance)
+        return wv::fail_with(WV_E_INVALID_ARGUMENT, "Acoustic impedance outside expected range.");
+    try {
+        const Orientation o = make_orientation(pointing, up);
+        std::vector<float> ret;
+        for (uint32_t bi = 0; bi < n_bands; ++bi) {
+            const wv_waveguide_band& band = bands[bi];
+            // postprocess(band, method, ...) (postprocess.h:57-72) with the bands_type overload (:37-46)
+            std::vector<float> per_band((size_t)band.n * 8);
+            for (uint64_t i = 0; i < band.n; ++i)
+                attenuate_hrtf(*table, o, channel, acoustic_impedance, band.directional[i], per_band.data() + i * 8);
+            const std::vector<float> mixed = multiband_filter_and_mixdown(per_band, band.n, band.sample_rate);
+            std::vector<float> processed = adjust_sampling_rate(mixed.data(), mixed.size(), band.sample_rate, output_sample_rate);
+            const double lo = band.valid_hz_min / output_sample_rate, hi = band.valid_hz_max / output_sample_rate;
+            frequency_domain_filter(processed.data(), processed.size(), [&](double f) {
+                return lopass_magnitude(f, hi, 0.1, 0) * hipass_magnitude(f, lo, 0.1, 0);
+            });
+            ret.resize(std::max(ret.size(), processed.size()), 0.0f);
+            for (size_t i = 0; i < processed.size(); ++i) ret[i] += processed[i];
+        }
         const double dc_block = 10.0 / output_sample_rate;
         frequency_domain_filter(ret.data(), ret.size(), [&](double f) { return hipass_magnitude(f, dc_block, 0.9, 0); });
         *n_out = ret.size();

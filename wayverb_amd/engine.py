@@ -31,7 +31,8 @@ EXPORTS = [
     "wv_comm_destroy", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
-    "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
+    "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_hrtf_attenuation", "wv_hrtf_ear_position",
+    "wv_attenuate_hrtf", "wv_multiband_filter_and_mixdown", "wv_postprocess_waveguide_hrtf", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
     "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy",
 ]
 
