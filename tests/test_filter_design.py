@@ -117,3 +117,35 @@ def test_surface_coefficients_run_clean_in_the_oracle(built_library, oracle):
     assert out["flag"] == 0
     tr = np.abs(out["trace"][:, 0])
     assert tr[:100].max() > 0 and tr[-50:].max() < 0.5 * tr[:100].max()
+
+
+def test_fixed_numeric_vectors(built_library):
+    """tests/golden/filter_design.npz (generator: make_golden_filters.py): frozen outputs of this repository's
+    own Yule-Walker restatement -- NOT of the reference (itpp is not in its tree) -- so that a regression in
+    either implementation shows.  Envelopes incl. the reference test's, the concert-hall demo's two
+    materials and three spectral shapes at three sample rates."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filter_design.npz"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_filters", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                    "golden", "make_golden_filters.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+
+    def close(x, y, tol):
+        scale = max(1.0, float(np.abs(y).max()))
+        return float(np.abs(np.asarray(x) - np.asarray(y)).max()) <= tol * scale
+
+    for name, env in gen.ENVELOPES.items():
+        b, a = F.arbitrary_magnitude_filter(env)
+        ob, oa = O.arbitrary_magnitude_filter(env)
+        for got_b, got_a, tol in ((b, a, TOL), (ob, oa, 1e-12)):
+            assert close(got_b, g["envelope_%s_b" % name], tol) and close(got_a, g["envelope_%s_a" % name], tol), name
+    for name, absorption in gen.ABSORPTIONS.items():
+        for sr in gen.SAMPLE_RATES:
+            key = "%s_%d" % (name, int(sr))
+            c = F.reflectance_filter(absorption, sr)
+            assert close(c["b"], g["reflectance_%s_b" % key], TOL) and close(c["a"], g["reflectance_%s_a" % key], TOL), key
+            imp = F.impedance_coefficients(c)
+            assert close(imp["b"], g["impedance_%s_b" % key], 10 * TOL) and close(imp["a"], g["impedance_%s_a" % key], 10 * TOL), key
+            assert F.is_stable(c["a"])
