@@ -125,7 +125,8 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         slot[i] = slot_base + (uint32_t)i * n_d + k;
         cf[i] = coeffs + (size_t)a.cidx[slot[i]] * 14;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = a.fmem[(size_t)j * a.n_slots + slot[i]];
+        // filter memories are read once and written once per step: keep them from displacing field lines in L2
+        for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
 
     Real facc = 0, cacc = 0;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         const double diff = (a0 * (double)(Real)(prev - next)) / (b0 * (double)a.courant) + (m[i][0] / b0);
         filter_step_6(-diff, m[i], cf[i], cf[i] + 7);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) a.fmem[(size_t)j * a.n_slots + slot[i]] = m[i][j];
+        for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(m[i][j], a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
     bad |= bad_bits(next);
     a.next[idx] = next;
