@@ -781,7 +781,12 @@ public:
         // (outside nodes a caller wrote to are zeroed by two single full sweeps first: batch_pairs_ready)
         if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
         if (pair_mode_ < 0) {
-            if (stored_nodes_ < pair_min_nodes_) return false;
+            // Measured (profiles/r02): in fp64 the two-step pass wins from 384^3 up (222 vs 203 Gnode-updates/s;
+            // 512^3 248 vs 221, 768^3 261 vs 180, 1024^3 320-330 vs 243) and loses at 256^3 (171 vs 178: four
+            // fields no longer fit the Infinity Cache where two almost do).  In fp32 a node is half the
+            // bytes for the same arithmetic and the march is bound by its instruction stream instead:
+            // 383 vs 444 at 1024^3, so float fields keep single steps.
+            if (sizeof(Real) != 8 || stored_nodes_ < pair_min_nodes_) return false;
             // rooms that leave much of the mesh outside keep their work lists (the march visits every strip)
             if (build_tile_lists(z_begin_, z_end_) != WV_OK || tile_list_) return false;
         }
@@ -1612,7 +1617,7 @@ private:
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
     // two-step passes
     int pair_mode_ = env_int("WV_PAIR", -1);   // 1 always (where eligible), 0 never, -1 from pair_min_nodes_ up
-    uint64_t pair_min_nodes_ = 96ull << 20;     // four fields of this size no longer fit the 256 MB Infinity Cache anyway
+    uint64_t pair_min_nodes_ = 40ull << 20;     // between 256^3 (single steps win) and 384^3 (passes win)
     bool pair_failed_ = false;
     uint8_t* pair_map_ = nullptr;
     uint32_t* pair_list_ = nullptr;
