@@ -776,7 +776,6 @@ public:
     bool pair_eligible() {
         constexpr int WX = 64 * (16 / (int)sizeof(Real));
         if (pair_mode_ == 0 || pair_failed_) return false;
-        if (comm_ && comm_->nranks() == 1 && (opt_.ghost_lo || opt_.ghost_hi)) return false;  // single-rank loopback: single steps
         if ((opt_.ghost_lo || opt_.ghost_hi) && (!comm_ || z_end_ - z_begin_ < 4)) return false;
         // (outside nodes a caller wrote to are zeroed by two single full sweeps first: batch_pairs_ready)
         if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
@@ -1235,7 +1234,7 @@ public:
                 int singles_first = -1;
                 int rc = batch_pairs_ready(&singles_first);
                 if (rc) return rc;
-                if (comm_ && comm_->nranks() > 1) {
+                if (comm_ && !comm_->is_local()) {
                     // every rank of the chain has to take the same path: one flag word, OR-ed over the
                     // ranks -- bit 3 "some rank cannot", bits 0-1 the largest number of single steps any
                     // rank needs first (thermometer code: OR = max)
