@@ -201,7 +201,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches, timed_steps = eng.kernel_time_detail()
-    timed_kernel = eng.timed_kernel_name()
     eng.enable_kernel_timing(False)
 
     owned_nodes = nx * ny * (layout.z1 - layout.z0)
@@ -224,7 +223,7 @@ def main():
     # the same launch priced at the single-step figure (24 B per node-update): what a one-step-per-pass
     # kernel would have to sustain to keep up -- above the HBM peak is the point of the two-step pass
     per_update_equiv = 3 * elem * nx * ny * timed_planes * steps_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    kernel_name = timed_kernel or ("pair_march_kernel" if two_step else "stream_sweep_kernel")
+    kernel_name = "pair_march_kernel" if two_step else "stream_sweep_kernel"
     # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
     # when it was measured on this very device code, this kernel and this workload
     traffic = None

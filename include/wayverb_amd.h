@@ -193,9 +193,6 @@ int wv_enable_kernel_timing(wv_engine* e, int enable);
  * by HBM bytes the engine advances TWO steps per pass over the fields (pair_kernels.hip.h; results are
  * bit-identical to single steps), so a launch of the dominant kernel may stand for two steps. */
 int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uint64_t* steps);
-/* Which kernel those launches were: "pair_march_kernel" (two steps per pass), "stream_fused_kernel" (one launch per
- * step: sweep + each tile's boundary nodes + source / receivers) or "stream_sweep_kernel" (sweep alone; slabs). */
-const char* wv_timed_kernel_name(wv_engine* e);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);
 /* Tuning hook for the streaming kernel.  variant 2 = plane sweep, 0 = register z-march, 1 = naive.

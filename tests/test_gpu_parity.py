@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _set_env(**kw):
     for k in ("WV_STREAM_RY", "WV_STREAM_NWX", "WV_STREAM_NWY", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS", "WV_GRAPH",
-              "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS", "WV_PAIR", "WV_PAIR_CHUNKS", "WV_FUSED"):
+              "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS", "WV_PAIR", "WV_PAIR_CHUNKS"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -66,16 +66,13 @@ def test_every_stream_variant_matches_golden(env, tag):
 
 
 @pytest.mark.parametrize("env", [dict(WV_GRAPH=1), dict(WV_FUSE_PRE_POST=0), dict(WV_BOUNDARY_LDS=0),
-                                 dict(WV_BOUNDARY_ORDER=0), dict(WV_GRAPH=1, WV_FUSE_PRE_POST=0), dict(WV_FUSED=0),
-                                 dict(WV_FUSED=0, WV_FUSE_PRE_POST=0), dict(WV_FUSED=0, WV_GRAPH=1),
-                                 dict(WV_FUSED=1, WV_BOUNDARY_ORDER=0)],
+                                 dict(WV_BOUNDARY_ORDER=0), dict(WV_GRAPH=1, WV_FUSE_PRE_POST=0)],
                          ids=lambda e: "-".join("%s%s" % (k[3:], v) for k, v in e.items()))
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 def test_engine_switches_do_not_change_results(env, tag):
     """Replaying a captured batch of steps as a hipGraph, the pre/post work riding in the boundary
-    launch, LDS-staged coefficients, brick-ordered boundary entries, the one-launch step (sweep + each
-    tile's boundary nodes + source / receivers, the default wherever the mesh is not sliced) against
-    separate launches: each switched the other way still reproduces the golden run bit for bit."""
+    launch, LDS-staged coefficients, brick-ordered boundary entries: each switched the other way
+    still reproduces the golden run bit for bit."""
     _set_env(**env)
     for name in ("random", "impulse_flat"):
         r = run_engine(cases.CASES[name](), tag)

@@ -200,10 +200,7 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
 // every thread of the workgroup calls this; `width` threads share the receivers
 template <typename Real>
 __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32_t t, uint32_t width) {
-    // waveguide.h:82 (write_value(error_flag, id_success)) + static bits; `flag_count` words when later steps of the
-    // batch have no launch of their own to do it (fused_kernels.hip.h)
-    if (a.flag)
-        for (uint32_t i = t; i < (a.flag_count ? a.flag_count : 1u); i += width) a.flag[i] = a.flag_init;
+    if (t == 0 && a.flag) *a.flag = a.flag_init;  // waveguide.h:82 (write_value(error_flag, id_success)) + static bits
     if (t == 0 && a.flag2) *a.flag2 = a.flag_init;
     Real injected = 0;
     const bool has_source = a.source_kind != 0;
@@ -354,7 +351,6 @@ struct TileActivityArgs {
     uint8_t* active;  // [nz][tiles_y][tiles_x]
     int ny, nz, pitch, cls_pitch;
     int tile_rows, tile_cols, tiles_x, tiles_y;
-    uint32_t class_bits;  // 0x55: tiles with a node the sweep updates; 0xFF: also tiles that only hold boundary nodes
 };
 
 __global__ void __launch_bounds__(256) tile_activity_kernel(const TileActivityArgs a) {
@@ -367,7 +363,7 @@ __global__ void __launch_bounds__(256) tile_activity_kernel(const TileActivityAr
     uint32_t any = 0;
     for (int y = ty * a.tile_rows; y < min((ty + 1) * a.tile_rows, a.ny); ++y)
         for (int x = tx * a.tile_cols; x < min((tx + 1) * a.tile_cols, a.pitch); x += 4)
-            any |= a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)] & a.class_bits;  // bit 0 of a class: inside / re-entrant
+            any |= a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)] & 0x55u;  // bit 0 of a class: inside / re-entrant
     a.active[t] = any ? 1 : 0;
 }
 

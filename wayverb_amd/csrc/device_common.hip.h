@@ -147,7 +147,6 @@ struct PrePostArgs {
     int* flag2;              // (two-step pass) the next step's word, reset with it; null otherwise
     int flag_init;           // ... to the mesh-static bits (0 for a well-formed mesh)
     int fused;               // non-zero: boundary_kernel's last workgroup does this work
-    uint32_t flag_count;     // flag words to reset from `flag` on (0 = 1)
 };
 
 }  // namespace wv

@@ -21,7 +21,6 @@
 
 #include "boundary_kernels.hip.h"
 #include "comm.h"
-#include "fused_kernels.hip.h"
 #include "pair_kernels.hip.h"
 #include "stream_kernels.hip.h"
 
@@ -111,7 +110,6 @@ struct wv_engine {
     virtual int run(uint64_t n_steps, uint64_t* done, int32_t* flag) = 0;
     virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
     virtual int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) = 0;
-    virtual const char* timed_kernel() const = 0;
     virtual int synchronize() = 0;
     virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
@@ -390,7 +388,6 @@ public:
     // variant 2 (default): plane sweep, L2-resident z reuse; 0: register z-march; 1: naive
     void plan_stream() {
         lists_built_ = false;  // tile shapes may change
-        tb_built_ = false;
         StreamPlan& p = plan_;
         constexpr int VX = 16 / (int)sizeof(Real);
         constexpr int WX = 64 * VX;
@@ -514,7 +511,6 @@ public:
         t.tile_cols = wave_cols;
         t.tiles_x = wtiles_x;
         t.tiles_y = wtiles_y;
-        t.class_bits = fused_mode_ != 0 ? 0xFFu : 0x55u;  // a fused step also visits tiles that only hold boundary nodes
         hipLaunchKernelGGL(wv::tile_activity_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream_, t);
         WV_HIP(hipGetLastError());
         std::vector<uint8_t> active((size_t)n_tiles);
@@ -589,55 +585,8 @@ public:
         return WV_OK;
     }
 
-    // ---- one launch per step (fused_kernels.hip.h) -------------------------------------------------
-    // boundary entries per sweep tile of the current plan: tile = (z * tiles_y_all + ty) * tiles_x + tx
-    int build_tile_boundary_lists() {
-        if (tb_built_) return WV_OK;
-        tb_built_ = true;
-        for (void** p : {(void**)&tb_start_, (void**)&tb_entries_})
-            if (*p) {
-                (void)hipFree(*p);
-                *p = nullptr;
-            }
-        constexpr int WX = 64 * (16 / (int)sizeof(Real));
-        const int tile_cols = WX * plan_.nwx, tile_rows = plan_.ry * plan_.nwy;
-        tb_tiles_y_ = (ny_ + tile_rows - 1) / tile_rows;
-        const uint64_t n_tiles = (uint64_t)nz_ * tb_tiles_y_ * plan_.tiles_x;
-        if (n_tiles >= 0xFFFFFFFFull) return WV_OK;  // (never: 2^32 stored nodes at most)
-        std::vector<uint32_t> bnode(std::max<uint32_t>(n_entries_, 1));
-        if (n_entries_) WV_HIP(hipMemcpy(bnode.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> start(n_tiles + 1, 0), tile_of(n_entries_);
-        for (uint32_t e = 0; e < n_entries_; ++e) {
-            if (bnode[e] == wv::INVALID_NODE) {
-                tile_of[e] = 0xFFFFFFFFu;
-                continue;
-            }
-            const uint32_t x = bnode[e] % (uint32_t)pitch_, q = bnode[e] / (uint32_t)pitch_;
-            const uint32_t y = q % (uint32_t)ny_, z = q / (uint32_t)ny_;
-            tile_of[e] = (z * (uint32_t)tb_tiles_y_ + y / (uint32_t)tile_rows) * (uint32_t)plan_.tiles_x + x / (uint32_t)tile_cols;
-            ++start[tile_of[e] + 1];
-        }
-        for (uint64_t t = 0; t < n_tiles; ++t) start[t + 1] += start[t];
-        std::vector<uint32_t> entries(std::max<uint32_t>(start[n_tiles], 1)), cursor(start.begin(), start.end() - 1);
-        for (uint32_t e = 0; e < n_entries_; ++e)  // processing order inside a tile = the engine's entry order
-            if (tile_of[e] != 0xFFFFFFFFu) entries[cursor[tile_of[e]]++] = e;
-        WV_HIP(hipMalloc((void**)&tb_start_, start.size() * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(tb_start_, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        WV_HIP(hipMalloc((void**)&tb_entries_, entries.size() * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(tb_entries_, entries.data(), entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        return WV_OK;
-    }
-
-    // The whole step of an unsliced mesh in one launch?  (Default tile shape of the product sweep only.)
-    bool fused_eligible() const {
-        return fused_mode_ != 0 && !comm_ && !opt_.ghost_lo && !opt_.ghost_hi && plan_.variant == 2 && plan_.ry == 4 &&
-               plan_.nwx == 1 && plan_.nwy == 4;
-    }
-
     // `out`: where the new field goes (null: in place, over `prev`)
-    // `io` non-null: the fused kernel (this step's boundary nodes, receivers and the next step's source sample ride along)
-    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr,
-                      const wv::StepIO<Real>* io = nullptr) {
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr) {
         if (z0 >= z1) return WV_OK;
         wv::StreamArgs<Real> a{};
         a.prev = prev;
@@ -681,18 +630,7 @@ public:
         }
         timed = timed && timing && ev_used_ + 2 <= (int)events_.size();
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
-        if (timed) timed_kernel_ = io ? "stream_fused_kernel" : "stream_sweep_kernel";
-        if (io) {
-            wv::FusedArgs<Real> f{};
-            f.s = a;
-            f.b = boundary_args(prev, cur, flag);
-            f.b.next = a.next;
-            f.io = *io;
-            f.tb_start = tb_start_;
-            f.tb_entries = tb_entries_;
-            f.tiles_y_all = tb_tiles_y_;
-            hipLaunchKernelGGL((wv::stream_fused_kernel<Real, 4, 1, 4>), dim3(grid), dim3(256), 0, stream_, f);
-        } else if (plan_.variant == 1) {
+        if (plan_.variant == 1) {
             hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
         } else if (plan_.ry == 2) {
             launch_ry<2>(a, grid);
@@ -794,10 +732,8 @@ public:
         std::string cerr;
         // ghost planes of `cur` come from the exchange issued at the end of the previous step
         if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-        const bool served_early = pre_post_done_;  // this step's source sample is in place, its flag word reset
         if (!pre_post_done_) {
-            wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);
-            pp.flag_count = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(flags_to_reset_, (uint64_t)(kRing - slot)));
+            const wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
         pre_post_done_ = false;
@@ -814,22 +750,6 @@ public:
             if (!comm_->exchange_faces(stream_, prv_, &cerr)) return fail(WV_E_COMM, cerr);
             if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
             if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
-        } else if (fused_eligible()) {
-            // one launch: sweep + each tile's boundary nodes; it also gathers this step's receivers when the
-            // previous step already put this step's source sample in place, and puts the next one in place
-            if ((rc = build_tile_boundary_lists())) return rc;
-            const bool io_live = with_pre_post && (n_recv_ || source_live);
-            wv::StepIO<Real> io{};
-            io.signal = signal_;
-            io.next_pos = signal_pos + 1;
-            io.signal_base = graph_capturing_ ? signal_base_dev_ : nullptr;
-            io.source_node = source_node_;
-            io.source_kind = fuse_next && io_live && source_live ? source_kind_ : 0;
-            io.recv = recv_nodes_;
-            io.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
-            io.n_recv = served_early && io_live ? n_recv_ : 0;
-            if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true, nullptr, &io))) return rc;
-            pre_post_done_ = fuse_next;
         } else {
             if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
             if (fuse_next && n_entries_) {
@@ -1070,7 +990,6 @@ public:
             WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
             ev_used_ += 2;
             timed_steps_ += 2;
-            timed_kernel_ = "pair_march_kernel";
         }
         // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
         if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, nullptr, O1))) return rc;
@@ -1164,7 +1083,6 @@ public:
     // -------------------------------------------------------------------------------------------
     int step(int32_t* flag) override {
         DeviceGuard guard(device_);
-        flags_to_reset_ = 1;
         int rc = enqueue_step(0, false, 0, false);
         if (rc) return rc;
         WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -1196,17 +1114,12 @@ public:
                 if (rc) return rc;
             }
             (void)io_nodes_plain();
-            if (fused_eligible()) {
-                const int rc = build_tile_boundary_lists();
-                if (rc) return rc;
-            }
             const int cur_before = cur_, prv_before = prv_;
             hipGraph_t graph = nullptr;
             WV_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             graph_capturing_ = true;
             int rc = WV_OK;
             for (uint64_t i = 0; i < batch && rc == WV_OK; ++i) {
-                flags_to_reset_ = batch - i;
                 rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch);
                 std::swap(cur_, prv_);
             }
@@ -1241,8 +1154,7 @@ public:
             const uint64_t left = signal_len_ - std::min(signal_len_, signal_pos_);
             batch = std::min(batch, left);
         }
-        // (the fused step serves any source / receiver node; the boundary launch only nodes it does not update itself)
-        batch_can_fuse_ = !comm_ && env_int("WV_FUSE_PRE_POST", 1) != 0 && (fused_eligible() || io_nodes_plain());
+        batch_can_fuse_ = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
         batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
         return batch;
     }
@@ -1251,7 +1163,6 @@ public:
     // then ride in this step's boundary launch; a two-step pass does its own)
     int enqueue_batch_step(uint64_t i, uint64_t batch, bool next_is_single) override {
         DeviceGuard guard(device_);
-        flags_to_reset_ = batch - i;  // a step that resets flag words does it for the rest of the batch
         const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_,
                                     batch_can_fuse_ && next_is_single && i + 1 < batch);
         if (rc) return rc;
@@ -1608,8 +1519,6 @@ public:
         return WV_OK;
     }
 
-    const char* timed_kernel() const override { return timed_kernel_; }
-
     int synchronize() override {
         DeviceGuard guard(device_);
         WV_HIP(hipStreamSynchronize(stream_));
@@ -1659,7 +1568,7 @@ private:
         for (int i = 0; i < 4; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-        void* ptrs[] = {tb_start_, tb_entries_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+        void* ptrs[] = {pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                         status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -1704,12 +1613,6 @@ private:
     bool graph_capturing_ = false;
     int graph_mode_ = env_int("WV_GRAPH", 0);
     uint64_t graph_max_nodes_ = 64ull << 20;
-    int fused_mode_ = env_int("WV_FUSED", 1);  // 1: a single step = one launch where the mesh is not sliced
-    bool tb_built_ = false;
-    uint32_t* tb_start_ = nullptr;
-    uint32_t* tb_entries_ = nullptr;
-    int tb_tiles_y_ = 0;
-    uint64_t flags_to_reset_ = 1;
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
     // two-step passes
     int pair_mode_ = env_int("WV_PAIR", -1);   // 1 always (where eligible), 0 never, -1 from pair_min_nodes_ up
@@ -1723,7 +1626,6 @@ private:
     uint64_t pair_source_ = 0;
     int pair_nw_ = 1, pair_strips_ = 0, pair_zc_ = 0, pair_chunks_ = 1;
     uint64_t timed_steps_ = 0;
-    const char* timed_kernel_ = "";           // which kernel the timed launches ran
     bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
@@ -1884,7 +1786,6 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
     WV_NEED(e);
     return e->kernel_time(mean_ms, launches, steps);
 }
-const char* wv_timed_kernel_name(wv_engine* e) { return e ? e->timed_kernel() : ""; }
 int wv_enable_kernel_timing(wv_engine* e, int enable) {
     WV_NEED(e);
     e->timing = enable != 0;

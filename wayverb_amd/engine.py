@@ -27,7 +27,7 @@ EXPORTS = [
     "wv_read_field", "wv_write_field", "wv_read_planes", "wv_write_planes", "wv_read_boundary_data", "wv_write_boundary_data",
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
-    "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_timed_kernel_name", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
+    "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
     "wv_comm_destroy", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
@@ -419,11 +419,6 @@ class Engine:
         steps = C.c_uint64()
         _check(self.lib.wv_kernel_time_detail(self.h, C.byref(ms), C.byref(n), C.byref(steps)))
         return ms.value, n.value, steps.value
-
-    def timed_kernel_name(self):
-        self.lib.wv_timed_kernel_name.restype = C.c_char_p
-        self.lib.wv_timed_kernel_name.argtypes = [C.c_void_p]
-        return self.lib.wv_timed_kernel_name(self.h).decode()
 
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
