@@ -786,8 +786,6 @@ public:
             // bytes for the same arithmetic and the march is bound by its instruction stream instead:
             // 383 vs 444 at 1024^3, so float fields keep single steps.
             if (sizeof(Real) != 8 || stored_nodes_ < pair_min_nodes_) return false;
-            // rooms that leave much of the mesh outside keep their work lists (the march visits every strip)
-            if (build_tile_lists(z_begin_, z_end_) != WV_OK || tile_list_) return false;
         }
         return true;
     }
@@ -905,6 +903,78 @@ public:
         chunks = std::max(1, std::min(chunks, std::max(1, owned / 8)));
         pair_zc_ = (owned + chunks - 1) / chunks;
         pair_chunks_ = (owned + pair_zc_ - 1) / pair_zc_;
+        return build_pair_units(owned);
+    }
+
+    // Rooms that leave much of the mesh outside: a unit of the march (a strip of 4 rows through one chunk
+    // of planes) without a single node to update produces nothing but the zeros its outputs already hold,
+    // so only the other units are launched -- each XCD a run of neighbouring strips with about the same
+    // number of units.  (A mesh that is nearly all room keeps the arithmetic mapping.)
+    int build_pair_units(int owned) {
+        if (pair_units_) {
+            (void)hipFree(pair_units_);
+            pair_units_ = nullptr;
+        }
+        if (env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0 || pair_strips_ >= (1 << 16)) return WV_OK;
+        // activity per (plane, strip)
+        const int64_t n_cells = (int64_t)nz_ * pair_strips_;
+        ScopedDevice act_mem;
+        WV_HIP(hipMalloc(&act_mem.p, (size_t)n_cells));
+        wv::TileActivityArgs t{};
+        t.cls = cls_;
+        t.active = static_cast<uint8_t*>(act_mem.p);
+        t.ny = ny_;
+        t.nz = nz_;
+        t.pitch = pitch_;
+        t.cls_pitch = cls_pitch_;
+        t.tile_rows = wv::kPairRows;
+        t.tile_cols = pitch_;
+        t.tiles_x = 1;
+        t.tiles_y = pair_strips_;
+        hipLaunchKernelGGL(wv::tile_activity_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream_, t);
+        WV_HIP(hipGetLastError());
+        std::vector<uint8_t> active((size_t)n_cells);
+        WV_HIP(hipMemcpyAsync(active.data(), act_mem.p, (size_t)n_cells, hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipStreamSynchronize(stream_));
+        uint64_t live = 0;
+        for (int z = pair_z0_; z < pair_z1_; ++z)
+            for (int sidx = 0; sidx < pair_strips_; ++sidx) live += active[(size_t)z * pair_strips_ + sidx];
+        if (live * 100 >= (uint64_t)owned * pair_strips_ * 92) return WV_OK;  // (nearly) all room
+        // finer chunks than a full mesh would take: skipping works in whole units
+        const int zc = std::max(8, std::min(pair_zc_, env_int("WV_PAIR_UNIT_PLANES", 32)));
+        const int chunks = (owned + zc - 1) / zc;
+        if (chunks >= (1 << 16)) return WV_OK;
+        std::vector<std::vector<uint32_t>> of_strip((size_t)pair_strips_);
+        uint64_t total = 0;
+        for (int sidx = 0; sidx < pair_strips_; ++sidx)
+            for (int c = 0; c < chunks; ++c) {
+                bool any = false;
+                for (int z = pair_z0_ + c * zc; z < std::min(pair_z0_ + (c + 1) * zc, pair_z1_) && !any; ++z)
+                    any = active[(size_t)z * pair_strips_ + sidx] != 0;
+                if (any) {
+                    of_strip[(size_t)sidx].push_back((uint32_t)sidx | ((uint32_t)c << 16));
+                    ++total;
+                }
+            }
+        if (!total) return WV_OK;
+        std::vector<uint32_t> list;
+        list.reserve((size_t)total);
+        pair_units_longest_ = 0;
+        int sidx = 0;
+        for (int k = 0; k < 8; ++k) {
+            pair_unit_start_[k] = (uint32_t)list.size();
+            const uint64_t want = total * (uint64_t)(k + 1) / 8;  // cumulative share of XCDs 0 .. k
+            while (sidx < pair_strips_ && (list.size() < want || k == 7)) {
+                list.insert(list.end(), of_strip[(size_t)sidx].begin(), of_strip[(size_t)sidx].end());
+                ++sidx;
+            }
+            pair_units_longest_ = std::max<uint32_t>(pair_units_longest_, (uint32_t)list.size() - pair_unit_start_[k]);
+        }
+        pair_unit_start_[8] = (uint32_t)list.size();
+        pair_zc_ = zc;
+        pair_chunks_ = chunks;
+        WV_HIP(hipMalloc((void**)&pair_units_, list.size() * sizeof(uint32_t)));
+        WV_HIP(hipMemcpy(pair_units_, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         return WV_OK;
     }
 
@@ -979,7 +1049,12 @@ public:
         a.chunks = pair_chunks_;
         a.strips = pair_strips_;
         a.strips_per_xcd = (pair_strips_ + 7) / 8;
-        const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)pair_chunks_;
+        unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)pair_chunks_;
+        if (pair_units_) {
+            a.unit_list = pair_units_;
+            for (int k = 0; k < 9; ++k) a.list_start[k] = pair_unit_start_[k];
+            grid = 8u * pair_units_longest_;
+        }
         const bool timed = timing && ev_used_ + 2 <= (int)events_.size();
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
         if (pair_nw_ == 8)  // rows of 1024 doubles / 2048 floats: the row length folds into the code
@@ -1568,7 +1643,7 @@ private:
         for (int i = 0; i < 4; ++i)
             if (field_[i]) (void)hipFree(field_[i]);
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-        void* ptrs[] = {pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+        void* ptrs[] = {pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                         status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -1621,6 +1696,9 @@ private:
     uint8_t* pair_map_ = nullptr;
     uint32_t* pair_list_ = nullptr;
     uint32_t* pair_counter_ = nullptr;
+    uint32_t* pair_units_ = nullptr;               // march work list (build_pair_units), null = every unit
+    uint32_t pair_unit_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t pair_units_longest_ = 0;
     uint32_t pair_list_n_ = 0, pair_face_n_ = 0;  // fix-up nodes of the marched planes / of a slab's face planes
     int pair_z0_ = 0, pair_z1_ = 0;                // planes the march produces
     uint64_t pair_source_ = 0;

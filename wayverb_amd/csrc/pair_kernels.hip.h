@@ -49,6 +49,10 @@ struct PairArgs {
     int nw;              // waves per workgroup (pitch / wave tile width)
     int zc, chunks;      // planes per workgroup, workgroups along z
     int strips, strips_per_xcd;
+    // optional work list (rooms that leave much of the mesh outside): workgroup j of XCD k takes unit
+    // unit_list[list_start[k] + j] = strip | chunk << 16; units without a node to update are not listed
+    const uint32_t* unit_list;
+    uint32_t list_start[9];
 };
 
 template <typename Real>
@@ -157,8 +161,17 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     // XCD k (= blockIdx % 8, observed dispatch: used for locality only) takes a contiguous run of
     // strips, so that the ring rows two neighbouring strips both need meet in that XCD's L2
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int strip = xcd * a.strips_per_xcd + j % a.strips_per_xcd;
-    const int chunk = j / a.strips_per_xcd;
+    int strip, chunk;
+    if (a.unit_list) {
+        const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
+        if ((uint32_t)j >= count) return;  // whole workgroup
+        const uint32_t u = a.unit_list[first + (uint32_t)j];
+        strip = (int)(u & 0xFFFFu);
+        chunk = (int)(u >> 16);
+    } else {
+        strip = xcd * a.strips_per_xcd + j % a.strips_per_xcd;
+        chunk = j / a.strips_per_xcd;
+    }
     if (strip >= a.strips || chunk >= a.chunks) return;  // whole workgroup
     const int y0 = strip * RY;
     const int zb = a.z_begin + chunk * a.zc, ze = min(zb + a.zc, a.z_end);
