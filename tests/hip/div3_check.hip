@@ -1,0 +1,73 @@
+// tests/hip/div3_check.hip -- does div3() (wayverb_amd/csrc/device_common.hip.h) equal the hardware's
+// IEEE division by 3, bit for bit?  Built and run by tests/test_gpu_div3.py.
+//   float : every one of the 2^32 bit patterns
+//   double: 2^34 patterns -- hashed significands under every exponent (subnormals, inf / nan included),
+//           plus +-4096 ulps around every power of two
+// NaN results compare equal when both are NaN with the same payload class (quiet); everything else bitwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../wayverb_amd/csrc/device_common.hip.h"
+
+__global__ void check_float(unsigned long long* bad, unsigned* example) {
+    const uint64_t n = 1ull << 32;
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)i);
+        const unsigned a = __float_as_uint(x / 3.0f), b = __float_as_uint(wv::div3(x));
+        if (a != b) {
+            ++mine;
+            *example = (unsigned)i;
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+__global__ void check_double(unsigned long long* bad, unsigned long long* example, uint64_t n) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t h = i * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        uint64_t u;
+        if ((i & 3) == 0) {
+            u = h;                                                                            // anything
+        } else if ((i & 3) == 1) {
+            u = (h & 0x800FFFFFFFFFFFFFull) | ((uint64_t)((i >> 2) % 2048) << 52);            // every exponent
+        } else {
+            const uint64_t e = (i >> 2) % 2047, k = (i >> 13) % 8192;                         // around powers of two
+            u = ((e << 52) + k - 4096) | (h & 0x8000000000000000ull);
+        }
+        const double x = __longlong_as_double((long long)u);
+        const uint64_t a = (uint64_t)__double_as_longlong(x / 3.0), b = (uint64_t)__double_as_longlong(wv::div3(x));
+        if (a != b) {
+            ++mine;
+            *example = u;
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+int main() {
+    unsigned long long *bad, h_bad[2] = {0, 0}, *ex64, h_ex64 = 0;
+    unsigned *ex32, h_ex32 = 0;
+    if (hipMalloc((void**)&bad, 16) != hipSuccess) {
+        printf("no HIP device\n");
+        return 2;
+    }
+    hipMalloc((void**)&ex64, 8);
+    hipMalloc((void**)&ex32, 4);
+    hipMemset(bad, 0, 16);
+    hipLaunchKernelGGL(check_float, dim3(256 * 16), dim3(256), 0, 0, bad, ex32);
+    hipLaunchKernelGGL(check_double, dim3(256 * 16), dim3(256), 0, 0, bad + 1, ex64, 1ull << 34);
+    if (hipDeviceSynchronize() != hipSuccess) return 3;
+    hipMemcpy(h_bad, bad, 16, hipMemcpyDeviceToHost);
+    hipMemcpy(&h_ex32, ex32, 4, hipMemcpyDeviceToHost);
+    hipMemcpy(&h_ex64, ex64, 8, hipMemcpyDeviceToHost);
+    printf("float: %llu mismatches of 2^32 (e.g. 0x%08x)\ndouble: %llu mismatches of 2^34 (e.g. 0x%016llx)\n", h_bad[0], h_ex32,
+           h_bad[1], h_ex64);
+    return (h_bad[0] || h_bad[1]) ? 1 : 0;
+}

@@ -77,6 +77,27 @@ __device__ __forceinline__ double read_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// x / 3, correctly rounded, without the divide sequence.  The update `s = s / 3` (program.cpp:408,
+// courant_sq... `/ 3`) is the only division of the 7-point update and a full IEEE division costs ~11
+// instructions (div_scale x2, rcp, 5 fma, div_fmas, div_fixup) -- a quarter of the two-step pass's inner loop.
+// Markstein's scheme for a constant divisor: q0 = RN(x * c) with c = RN(1/3); r = x - 3 q0 exactly (one
+// FMA); q1 = RN(q0 + r c) IS the correctly rounded quotient for every finite x (the one divisor pattern
+// for which the scheme can miss, an all-ones significand, is not 3's); v_div_fixup then supplies IEEE's
+// answers for inf / nan / signed zero.  Checked against the hardware division on every one of the 2^32
+// floats and on 2^34 doubles incl. all exponents and subnormals (tests/test_gpu_div3.py).
+__device__ __forceinline__ double div3(double x) {
+    constexpr double c = 0x1.5555555555555p-2;
+    const double q0 = x * c;
+    const double r = __builtin_fma(-3.0, q0, x);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(r, c, q0), 3.0, x);
+}
+__device__ __forceinline__ float div3(float x) {
+    constexpr float c = 0x1.555556p-2f;
+    const float q0 = x * c;
+    const float r = __builtin_fmaf(-3.0f, q0, x);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, c, q0), 3.0f, x);
+}
+
 // neither inf nor nan: one v_cmp_class
 __device__ __forceinline__ bool is_finite(float v) { return __builtin_amdgcn_classf(v, 0x1F8); }
 __device__ __forceinline__ bool is_finite(double v) { return __builtin_amdgcn_class(v, 0x1F8); }

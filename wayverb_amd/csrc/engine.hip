@@ -784,9 +784,9 @@ public:
             // Measured (profiles/r02): in fp64 the two-step pass wins from 384^3 up (222 vs 203 Gnode-updates/s;
             // 512^3 248 vs 221, 768^3 261 vs 180, 1024^3 320-330 vs 243) and loses at 256^3 (171 vs 178: four
             // fields no longer fit the Infinity Cache where two almost do).  In fp32 a node is half the
-            // bytes for the same arithmetic and the march is bound by its instruction stream instead:
-            // 383 vs 444 at 1024^3, so float fields keep single steps.
-            if (sizeof(Real) != 8 || stored_nodes_ < pair_min_nodes_) return false;
+            // bytes for the same arithmetic: the march was bound by its instruction stream (383 vs 444 at
+            // 1024^3) until the divide sequence went (div3): 549 vs 452 now.
+            if (stored_nodes_ < pair_min_nodes_) return false;
         }
         return true;
     }
@@ -1065,10 +1065,10 @@ public:
         }
         const bool timed = timing && ev_used_ + 2 <= (int)events_.size();
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
-        if (pair_nw_ == 8)  // rows of 1024 doubles / 2048 floats: the row length folds into the code
-            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 8>), dim3(grid), dim3(512), 0, stream_, a);
-        else
-            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        // (a variant with the row length as a compile-time constant was worth 6 % until the divide sequence went
+        // (div3); with the shorter loop the compiler hoists its address arithmetic into registers it does not have
+        // and spills: tools/pair_tune.hip still prices it)
+        hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
         if (timed) {
             WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
             ev_used_ += 2;

@@ -99,7 +99,7 @@ __device__ __forceinline__ typename Vec16<Real>::type pair_step_row(
         s += yp[j];
         s += zm[j];
         s += zp[j];
-        s = s / Real(3);
+        s = div3(s);
         s -= pv[j];
         out[j] = s;
     }
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(256) pair_fixup_kernel(const PairFixupArgs<Rea
     s += (y + 1 < a.ny) ? a.t1[idx + a.pitch] : Real(0);
     s += (z > 0) ? a.t1[idx - plane] : Real(0);
     s += (z + 1 < a.nz) ? a.t1[idx + plane] : Real(0);
-    s = s / Real(3);
+    s = div3(s);
     s -= a.cur[idx];
     const int bad = bad_bits(s);
     if (bad) atomicOr(a.flag2, bad);

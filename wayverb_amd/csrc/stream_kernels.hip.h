@@ -59,7 +59,7 @@ __device__ __forceinline__ typename Vec16<Real>::type update_row(
         s += yp[j];
         s += zm[j];
         s += zp[j];
-        s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : s / Real(3);
+        s = (X & X_MUL_THIRD) ? s * (Real(1) / Real(3)) : div3(s);
         s -= pv[j];
         const uint32_t c = (cls_bits >> (2 * j)) & 3u;
         const Real o = (c & 1u) ? s : Real(0);
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) stream_naive_kernel(const StreamArgs<Real
             s += (y + 1 < a.ny) ? a.cur[idx + a.pitch] : Real(0);
             s += (z > 0) ? a.cur[idx - plane] : Real(0);
             s += (z + 1 < a.nz) ? a.cur[idx + plane] : Real(0);
-            s = s / Real(3);
+            s = div3(s);
             s -= a.prev[idx];
             out = s;
             bad |= bad_bits(out);
