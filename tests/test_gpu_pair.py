@@ -184,3 +184,22 @@ def test_generic_steps_and_pair_passes_interleave(oracle):
         assert eng.read_field(E.BUF_PREVIOUS).tobytes() == o_prev.tobytes()
         assert eng.read_value(node) == o_cur[node]
     eng.close()
+
+
+@pytest.mark.parametrize("dims,tag", [((384, 300, 200), "f64"), ((1000, 131, 77), "f64"), ((512, 260, 150), "f32"),
+                                      ((2048, 40, 33), "f32")])
+def test_two_step_passes_equal_single_steps_on_bigger_meshes(dims, tag):
+    """Engine against engine (no oracle in the loop, so the meshes can be big): 41 steps of a noisy field with six
+    different walls, two-step passes (several z-chunks, 3-8 waves per row, pad columns) vs single steps --
+    fields, filter memories and traces bit for bit."""
+    case = _random_case(dims, seed=sum(dims), steps=41)
+    _set_env(WV_PAIR=0)
+    want = run_engine(case, tag)
+    _set_env(WV_PAIR=1)
+    got = run_engine(case, tag)
+    assert got["steps"] == want["steps"] == 41
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    for a, b in zip(got["bd"], want["bd"]):
+        assert a.tobytes() == b.tobytes()

@@ -10,6 +10,17 @@ from wayverb_amd import mesh as M
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default", "two-step-passes"])
+def _step_mode(request, monkeypatch):
+    """Everything here also runs with two-step passes forced on (WV_PAIR=1): their spare fields and the work
+    lists of march units rely on outside nodes holding zeros exactly as the sweep's tile lists do."""
+    if request.param == "two-step-passes":
+        monkeypatch.setenv("WV_PAIR", "1")
+    else:
+        monkeypatch.delenv("WV_PAIR", raising=False)
+    return request.param
+
+
 def _two_rooms(dims=(300, 40, 24)):
     """Two separate box rooms in one mesh: most tiles hold no inside node."""
     nx, ny, nz = dims
