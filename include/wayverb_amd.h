@@ -154,7 +154,8 @@ int wv_write_boundary_data(wv_engine* e, int dimensionality, const wv_boundary_d
 int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32_t n);
 /* Device addresses of the fields (element type per precision), for zero-copy wrappers.  Once a
  * pointer has been handed out the engine stops assuming that outside nodes hold zeros (see
- * wv_options::all_tiles). */
+ * wv_options::all_tiles) and keeps to one time step per pass over two fields, so that the pointers stay
+ * the two fields (an engine that takes two-step passes rotates four). */
 int wv_device_buffer(wv_engine* e, int buffer, void** device_ptr);
 
 /* ---- stepping: the generic path ------------------------------------------------------------- */
