@@ -256,3 +256,58 @@ def test_create_run_destroy_does_not_leak_device_memory(built_library):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 40 engine life cycles" % (free0 - free1)
+
+
+def _flat_and_filtered_box(rng):
+    """Walls of three kinds on one box: frequency independent (only b0 / a0), rigid, and order-6 filters."""
+    coeffs = np.concatenate([np.array([M.flat_coefficients(0.1), M.rigid_coefficients()], dtype=M.coefficients_dtype),
+                             M.passive_peak_filter_coefficients(rng, 2)])
+    return M.box_mesh(22, 18, 20, coefficients=coeffs, surface_of_face=[0, 1, 2, 3, 0, 2])
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+@pytest.mark.parametrize("scenario", ["from-zero", "state-written", "set-goes-flat-mid-run"])
+def test_frequency_independent_walls_beside_filtered_ones(oracle, built_library, tag, dtype, scenario):
+    """Walls with only b0 / a0 (fitted_boundary.h:72-75), rigid walls (a0 = 0: the guarded taps of
+    filters.cpp:28-33 at work) and order-6 filters on one mesh.  A frequency-independent filter started from
+    zero keeps every memory word at +0; started from memories written from outside, or turned
+    frequency independent in the middle of a run, its memories drain through the delay line.  Fields and
+    EVERY memory word must equal the oracle's in all three."""
+    rng = np.random.default_rng(5)
+    mesh = _flat_and_filtered_box(rng)
+    live = mesh.nodes["boundary_type"] != 0
+    prev0 = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0).astype(dtype)
+    cur0 = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0).astype(dtype)
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    if scenario == "state-written":
+        for b in bd:
+            b["filter_memory"] = rng.uniform(-1e-3, 1e-3, b["filter_memory"].shape)
+    later = mesh.coefficients.copy()
+    later[2] = M.flat_coefficients(0.3)
+    eng = E.Engine(mesh, precision=tag)
+    o_prev, o_cur, o_bd = prev0.copy(), cur0.copy(), [b.copy() for b in bd]
+    try:
+        eng.write_field(prev0, E.BUF_PREVIOUS)
+        eng.write_field(cur0, E.BUF_CURRENT)
+        if scenario == "state-written":
+            for d in (1, 2, 3):
+                eng.write_boundary_data(d, bd[d - 1])
+        for part in range(2):
+            assert eng.run_steps(7) == (7, 0)
+            for _ in range(7):
+                assert oracle.step(o_prev, o_cur, mesh, o_bd) == 0
+                o_prev, o_cur = o_cur, o_prev
+            if part == 0 and scenario == "set-goes-flat-mid-run":
+                eng.set_coefficients(later)
+                mesh.set_coefficients(later)
+        assert eng.read_field(E.BUF_CURRENT).tobytes() == o_cur.tobytes()
+        assert eng.read_field(E.BUF_PREVIOUS).tobytes() == o_prev.tobytes()
+        for d in (1, 2, 3):
+            got = eng.read_boundary_data(d)
+            assert got["filter_memory"].tobytes() == o_bd[d - 1]["filter_memory"].tobytes(), "D=%d" % d
+    finally:
+        eng.close()
+    if scenario == "from-zero":
+        flat_rows = np.isin(o_bd[0]["coefficient_index"], [0, 1])
+        assert not o_bd[0]["filter_memory"][flat_rows].any()
+        assert o_bd[0]["filter_memory"][~flat_rows].any()

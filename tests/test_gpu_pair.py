@@ -203,3 +203,39 @@ def test_two_step_passes_equal_single_steps_on_bigger_meshes(dims, tag):
     assert got["previous"].tobytes() == want["previous"].tobytes()
     for a, b in zip(got["bd"], want["bd"]):
         assert a.tobytes() == b.tobytes()
+
+
+def _same(got, want):
+    assert (got["steps"], got["flag"]) == (want["steps"], want["flag"])
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    for a, b in zip(got["bd"], want["bd"]):
+        assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("inner_fix", [1, 0], ids=["entries-finish-faced-nodes", "list-only"])
+def test_faced_nodes_with_and_without_the_entries_finishing_them(oracle, inner_fix):
+    """In the second boundary launch of a pass a 1-D entry also finishes the inside node it faces
+    (boundary_kernel<.., FIX>); WV_PAIR_INNER_FIX=0 leaves all of them to the fix-up list.  Same bits."""
+    _set_env(WV_PAIR=1, WV_PAIR_INNER_FIX=inner_fix)
+    case = _random_case((40, 22, 18), 31, steps=25)
+    want = run_oracle(oracle, case, np.float64, threads=2)
+    got = run_engine(case, "f64")
+    _same(got, want)
+
+
+def test_a_callers_mesh_whose_direction_bits_do_not_name_the_inside_neighbours(oracle):
+    """The set-up chain types a 1-D boundary node by its one inside neighbour (mesh_setup_program.cpp:110-172);
+    a caller's own node array need not.  Here one wall node points at the `none` node behind it: entries
+    must not finish "faced" nodes on such a mesh (pair_inner_check_kernel), and the run must still equal
+    the reference's, which updates every node by its own type whatever its neighbours are."""
+    case = _random_case((24, 20, 16), 8, steps=21, reentrant=False)
+    mesh = case["mesh"]
+    t = mesh.nodes["boundary_type"]
+    at = mesh.compute_index(1, 9, 8)
+    assert t[at] == M.ID_PX
+    t[at] = M.ID_NX                                # faces x = 0, a `none` node; its inside neighbour is unnamed
+    want = run_oracle(oracle, case, np.float64, threads=2)
+    got = run_engine(case, "f64")
+    _same(got, want)

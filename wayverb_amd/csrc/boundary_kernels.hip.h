@@ -58,7 +58,13 @@ __global__ void __launch_bounds__(64) filter_test_2_kernel(const float* input, f
     for (int j = 0; j < 6; ++j) memory[(size_t)f * 6 + j] = m[j];
 }
 
-template <typename Real, int D>
+// One boundary node.  Everything it needs from memory is requested before anything is used: all six
+// neighbours of `cur` whatever the node's type (the type only decides which of them enter which sum), its
+// own old value, its filters' memories -- and, in the second launch of a two-step pass, what the inside
+// node it faces needs.  Selection is by v_cndmask, not by branch: with the loads behind per-lane branches
+// (the first form of this kernel) every one of them was waited for on its own, and eight to ten memory
+// round trips in a row, not bytes, set the kernel's time.
+template <typename Real, int D, bool FIX>
 __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t k, uint32_t entry,
                                               uint32_t slot_base, uint32_t n_d, int& bad) {
     const uint32_t idx = a.bnode[entry];
@@ -75,48 +81,20 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
     const int pos[3] = {x, y, z};
     const int lim[3] = {a.nx, a.ny, a.nz};
     const Real* cur = a.cur;
-    const Real prev = a.prev[idx];
 
-    // 2 * inner pressures, x before y before z (program.cpp:19-87, :268-276)
-    Real sum = 0;
-    bool inner_axis[3];
+    // ---- loads -----------------------------------------------------------------------------------
+    Real nb[3][2];   // cur at -/+ along x, y, z (the node's own value where that is off the grid: unused)
+    bool off[3][2];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
-        inner_axis[ax] = has_n || has_p;
-        if (inner_axis[ax]) {
-            const int c = pos[ax] + (has_p ? 1 : -1);
-            Real p = 0;
-            if (c >= 0 && c < lim[ax]) p = cur[(int64_t)idx + (has_p ? stride[ax] : -stride[ax])];
-            sum += 2 * p;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = pos[ax] + (s ? 1 : -1);
+            off[ax][s] = c < 0 || c >= lim[ax];
+            nb[ax][s] = cur[(int64_t)idx + (off[ax][s] ? 0 : (s ? stride[ax] : -stride[ax]))];
         }
     }
-    // un-doubled in-plane / along-edge neighbours, lower axis first, n before p
-    // (program.cpp:112-143, :178-227); off-grid ends the sum at 0 (statically flagged at create)
-    Real surr = 0;
-    if (D < 3) {
-        bool ok = true;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            if (!inner_axis[ax]) {
-#pragma unroll
-                for (int s = -1; s <= 1; s += 2) {
-                    const int c = pos[ax] + s;
-                    if (ok) {
-                        if (c < 0 || c >= lim[ax]) {
-                            ok = false;
-                            surr = 0;
-                        } else {
-                            surr += cur[(int64_t)idx + s * stride[ax]];
-                        }
-                    }
-                }
-            }
-        }
-    }
-    const Real csw = a.courant_sq * (sum + surr);
-
-    // this node's D filters
+    const Real prev = a.prev[idx];
     double m[D][6];
     const double* cf[D];
     uint32_t slot[D];
@@ -128,6 +106,64 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         // filter memories are read once and written once per step: keep them from displacing field lines in L2
         for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
+    // two-step pass, second launch: the inside node a 1-D entry faces (boundary_kernel<.., FIX = true>) and the
+    // seven values its update t+1 -> t+2 reads
+    bool fix = false;
+    int64_t fn = idx;
+    Real fnb[3][2];
+    Real fprev = 0;
+    if (D == 1 && FIX) {
+        int fp[3] = {x, y, z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int step = (int)((dirs >> (2 * ax + 1)) & 1u) - (int)((dirs >> (2 * ax)) & 1u);  // +1, -1 or 0
+            fp[ax] += step;
+            fn += step * stride[ax];
+        }
+        fix = fp[0] >= 0 && fp[0] < a.nx && fp[1] >= 0 && fp[1] < a.ny && fp[2] >= a.fix_z0 && fp[2] < a.fix_z1;
+        if (!fix) fn = idx;  // (loads below stay inside the field)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c = (fix ? fp[ax] : pos[ax]) + (s ? 1 : -1);
+                const bool o = c < 0 || c >= lim[ax];
+                const Real v = cur[fn + (o ? 0 : (s ? stride[ax] : -stride[ax]))];
+                fnb[ax][s] = o ? Real(0) : v;
+            }
+        }
+        fprev = a.prev[fn];
+    }
+
+    // ---- the node's new value (program.cpp:331-387) ------------------------------------------------
+    // 2 * inner pressures, x before y before z (program.cpp:19-87, :268-276)
+    Real sum = 0;
+    bool inner_axis[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
+        inner_axis[ax] = has_n || has_p;
+        const Real p = has_p ? (off[ax][1] ? Real(0) : nb[ax][1]) : (off[ax][0] ? Real(0) : nb[ax][0]);
+        const Real with = sum + 2 * p;
+        sum = inner_axis[ax] ? with : sum;
+    }
+    // un-doubled in-plane / along-edge neighbours, lower axis first, n before p
+    // (program.cpp:112-143, :178-227); off-grid ends the sum at 0 (statically flagged at create)
+    Real surr = 0;
+    if (D < 3) {
+        bool ok = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool take = !inner_axis[ax] && ok;
+                const Real with = surr + nb[ax][s];
+                surr = take ? (off[ax][s] ? Real(0) : with) : surr;
+                ok = ok && !(take && off[ax][s]);
+            }
+        }
+    }
+    const Real csw = a.courant_sq * (sum + surr);
 
     Real facc = 0, cacc = 0;
 #pragma unroll
@@ -149,17 +185,35 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
     }
     bad |= bad_bits(next);
     a.next[idx] = next;
+
+    // the faced node: 7-point update from the complete t+1 field (program.cpp:393-412, as pair_fixup_kernel
+    // does it for the nodes nobody faces)
+    if (D == 1 && FIX) {
+        Real s = 0;
+        s += fnb[0][0];
+        s += fnb[0][1];
+        s += fnb[1][0];
+        s += fnb[1][1];
+        s += fnb[2][0];
+        s += fnb[2][1];
+        s = div3(s);
+        s -= fprev;
+        if (fix) {
+            bad |= bad_bits(s);
+            a.next[fn] = s;
+        }
+    }
 }
 
 // entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
-template <typename Real>
+template <typename Real, bool FIX>
 __device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t e, int& bad) {
     if (e < a.n1) {
-        boundary_node<Real, 1>(a, coeffs, e, e, 0u, a.n1, bad);
+        boundary_node<Real, 1, FIX>(a, coeffs, e, e, 0u, a.n1, bad);
     } else if (e < a.n1 + a.n2) {
-        boundary_node<Real, 2>(a, coeffs, e - a.n1, e, a.n1, a.n2, bad);
+        boundary_node<Real, 2, FIX>(a, coeffs, e - a.n1, e, a.n1, a.n2, bad);
     } else if (e < a.n1 + a.n2 + a.n3) {
-        boundary_node<Real, 3>(a, coeffs, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
+        boundary_node<Real, 3, FIX>(a, coeffs, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
     }
 }
 
@@ -174,7 +228,9 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
 // `next`: when next.fused is set the last workgroup also does the NEXT step's source injection /
 // receiver gather (on `prev`, which is that step's `current`).  Only legal when none of those nodes
 // is a boundary node -- then they were final when the sweep before this launch ended (engine.hip).
-template <typename Real, bool LDSC>
+// FIX: the second launch of a two-step pass, where 1-D entries also finish the inside node they face
+// (BoundaryArgs::fix_z0 / fix_z1).
+template <typename Real, bool LDSC, bool FIX = false>
 __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
@@ -185,9 +241,9 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     int bad = 0;
     if (a.order) {
-        if (t < a.n_order) boundary_entry<Real>(a, coeffs, a.order[t], bad);
+        if (t < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t], bad);
     } else {
-        boundary_entry<Real>(a, coeffs, t, bad);
+        boundary_entry<Real, FIX>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
     if (next.fused && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
@@ -315,7 +371,7 @@ __global__ void __launch_bounds__(256) setup_validate_kernel(const ValidateArgs 
     if (e >= a.n_entries) return;
     const uint32_t idx = a.bnode[e];
     if (idx == INVALID_NODE) return;
-    const uint32_t dirs = a.btype[e];
+    const uint32_t dirs = a.btype[e] & 0x3Fu;
     const int pos[3] = {(int)(idx % (uint32_t)a.pitch), (int)((idx / (uint32_t)a.pitch) % (uint32_t)a.ny),
                         (int)(idx / ((uint32_t)a.pitch * (uint32_t)a.ny))};
     const int lim[3] = {a.nx, a.ny, a.nz};

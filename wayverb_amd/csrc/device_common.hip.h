@@ -128,6 +128,12 @@ struct BoundaryArgs {
     Real courant, courant_sq;
     const uint32_t* order;   // standalone kernel: entry ids to process (null = all, in list order)
     uint32_t n_order;
+    // Second boundary launch of a two-step pass only (prev / cur / next = fields t / t+1 / t+2): a 1-D entry
+    // also finishes the t+2 value of the inside node it faces -- a node the march had to leave open
+    // because this boundary node's t+1 value did not exist yet -- when it lies in planes [fix_z0, fix_z1).
+    // Its cache lines are the ones the entry touches anyway (boundary_kernel<.., FIX = true>; pair_kernels.hip.h,
+    // pair_map_kernel).
+    int fix_z0, fix_z1;
 };
 
 template <typename Real>

@@ -677,10 +677,12 @@ public:
     // those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
     // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
     int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1,
-                        const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr) {
+                        const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false) {
         if (!n_entries_ || z0 >= z1) return WV_OK;
         wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
         if (out) b.next = out;
+        b.fix_z0 = z0;  // (fix_inner: second launch of a two-step pass over the marched planes)
+        b.fix_z1 = z1;
         wv::PrePostArgs<Real> nx{};  // fused == 0: nothing rides in this launch
         if (next) {
             nx = *next;
@@ -695,10 +697,16 @@ public:
             n = b.n_order;
             if (!n) return WV_OK;
         }
-        if (n_coeffs_ <= wv::kMaxLdsCoefficientSets && env_int("WV_BOUNDARY_LDS", 1) != 0)
-            hipLaunchKernelGGL((wv::boundary_kernel<Real, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, b, nx);
+        const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && env_int("WV_BOUNDARY_LDS", 1) != 0;
+        const dim3 grid((n + 255) / 256), block(256);
+        if (lds && fix_inner)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, stream_, b, nx);
+        else if (lds)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false>), grid, block, 0, stream_, b, nx);
+        else if (fix_inner)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false, true>), grid, block, 0, stream_, b, nx);
         else
-            hipLaunchKernelGGL((wv::boundary_kernel<Real, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, b, nx);
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false>), grid, block, 0, stream_, b, nx);
         return WV_OK;
     }
 
@@ -834,6 +842,30 @@ public:
         pair_z1_ = z_end_ - (opt_.ghost_hi ? 1 : 0);
         m.march_begin = pair_z0_;
         m.march_end = pair_z1_;
+        // may boundary entries finish the inside nodes they face?  (once per mesh)
+        if (pair_inner_ok_ < 0) {
+            pair_inner_ok_ = 0;
+            if (n_entries_ && env_int("WV_PAIR_INNER_FIX", 1) != 0) {
+                wv::PairInnerCheckArgs c{};
+                c.bnode = bnode_;
+                c.btype = btype_;
+                c.cls = cls_;
+                c.n_entries = n_entries_;
+                c.nx = nx_;
+                c.ny = ny_;
+                c.nz = nz_;
+                c.pitch = pitch_;
+                c.cls_pitch = cls_pitch_;
+                c.violated = reinterpret_cast<int*>(pair_counter_);
+                int violated = 0;
+                WV_HIP(hipMemsetAsync(pair_counter_, 0, sizeof(uint32_t), stream_));
+                hipLaunchKernelGGL(wv::pair_inner_check_kernel, dim3((n_entries_ + 255) / 256), dim3(256), 0, stream_, c);
+                WV_HIP(hipMemcpyAsync(&violated, pair_counter_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+                WV_HIP(hipStreamSynchronize(stream_));
+                pair_inner_ok_ = violated ? 0 : 1;
+            }
+        }
+        m.cover = pair_inner_ok_;
         const int64_t n_bytes = (int64_t)cls_pitch_ * ny_ * nz_;
         const unsigned grid = (unsigned)((n_bytes + 255) / 256);
         uint32_t count[2] = {0, 0};
@@ -1118,8 +1150,9 @@ public:
             if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
         }
         // t+2 of the nodes next to a boundary node / the source, from the complete t+1; then the boundary nodes
+        // (most of them are faced by a boundary node and finished by its entry in the launch after this one)
         if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
-        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2))) return rc;
+        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0))) return rc;
         WV_HIP(hipGetLastError());
         if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
@@ -1547,10 +1580,11 @@ public:
         const uint32_t base = dim == 1 ? 0u : (dim == 2 ? n1_ : n1_ + 2u * n2_);
         const size_t bytes = (size_t)nd * dim * sizeof(wv_boundary_data);
         if (!host) return fail(WV_E_INVALID_ARGUMENT, "boundary data array missing");
-        if (to_device)  // same rule as wv_create: a filter must name an existing coefficient set
+        if (to_device) {  // same rule as wv_create: a filter must name an existing coefficient set
             for (size_t i = 0; i < (size_t)nd * dim; ++i)
                 if (host[i].coefficient_index >= n_coeffs_)
                     return fail(WV_E_INVALID_MESH, "coefficient index exceeds the coefficient array length");
+        }
         ScopedDevice aos_mem;
         WV_HIP(hipMalloc(&aos_mem.p, bytes));
         uint64_t* aos = static_cast<uint64_t*>(aos_mem.p);
@@ -1698,6 +1732,7 @@ private:
     uint64_t graph_max_nodes_ = 64ull << 20;
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
     // two-step passes
+    int pair_inner_ok_ = -1;  // boundary entries finish the inside nodes they face (ensure_pair): -1 not checked yet
     int pair_mode_ = env_int("WV_PAIR", -1);   // 1 always (where eligible), 0 never, -1 from pair_min_nodes_ up
     uint64_t pair_min_nodes_ = 40ull << 20;     // between 256^3 (single steps win) and 384^3 (passes win)
     bool pair_failed_ = false;

@@ -368,7 +368,46 @@ struct PairMapArgs {
     int nx, ny, nz, pitch, cls_pitch;
     int z_begin, z_end;          // planes this engine owns
     int march_begin, march_end;  // planes the march produces: all owned planes but a slab's face planes
+    // non-zero: an inside node of the marched planes that a (1-D) boundary node of the marched planes faces
+    // is finished by that node's entry in the second boundary launch (boundary_kernel<.., FIX = true>) and stays
+    // off the list.  Only for meshes that passed pair_inner_check_kernel.
+    int cover;
 };
+
+// "A boundary node has an inside node next to it exactly when it is one-dimensional, and then its one
+// direction bit names that node" -- how set_node_boundary_type types nodes (mesh_setup_program.cpp:110-172:
+// 1-D = one axial inside neighbour, 2-D / 3-D = none, only a diagonal one; two or more = re-entrant), true
+// for every mesh the set-up chain produces, not promised by a caller's own node array.  1-D entries
+// finish the node they face (above) only when it holds for all entries.
+struct PairInnerCheckArgs {
+    const uint32_t* bnode;
+    const uint8_t* btype;
+    const uint8_t* cls;
+    uint32_t n_entries;
+    int nx, ny, nz, pitch, cls_pitch;
+    int* violated;
+};
+
+__global__ void __launch_bounds__(256) pair_inner_check_kernel(const PairInnerCheckArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_entries) return;
+    const uint32_t idx = a.bnode[e];
+    if (idx == INVALID_NODE) return;
+    const uint32_t dirs = a.btype[e] & 0x3Fu;
+    const int pos[3] = {(int)(idx % (uint32_t)a.pitch), (int)((idx / (uint32_t)a.pitch) % (uint32_t)a.ny),
+                        (int)(idx / ((uint32_t)a.pitch * (uint32_t)a.ny))};
+    const int lim[3] = {a.nx, a.ny, a.nz};
+    const bool one_d = __popc(dirs) == 1;
+    bool ok = true;
+    for (int port = 0; port < 6; ++port) {
+        int p[3] = {pos[0], pos[1], pos[2]};
+        p[port >> 1] += (port & 1) ? 1 : -1;
+        const bool in_grid = p[port >> 1] >= 0 && p[port >> 1] < lim[port >> 1];
+        const uint32_t c = in_grid ? (a.cls[cls_byte_index(p[0], p[1], p[2], a.ny, a.cls_pitch)] >> ((p[0] & 3) * 2)) & 3u : CLS_NONE;
+        ok = ok && ((c == CLS_INSIDE) == (one_d && ((dirs >> port) & 1u) != 0));
+    }
+    if (!ok) *a.violated = 1;
+}
 
 // one thread per class byte (4 nodes of one row)
 __global__ void __launch_bounds__(256) pair_map_kernel(const PairMapArgs a) {
@@ -404,7 +443,15 @@ __global__ void __launch_bounds__(256) pair_map_kernel(const PairMapArgs a) {
             const bool marched = z >= a.march_begin && z < a.march_end;
             plain = plain && marched;
             code = plain ? 1u : 3u;
-            if (!plain && z >= a.z_begin && z < a.z_end) {
+            bool faced = false;  // by a boundary node whose entry finishes this node (PairMapArgs::cover)
+            if (a.cover && !plain && marched && c == CLS_INSIDE) {
+                for (int p = 0; p < 6; ++p) {
+                    const bool in_grid = nb[p][0] >= 0 && nb[p][0] < a.nx && nb[p][1] >= 0 && nb[p][1] < a.ny &&
+                                         nb[p][2] >= a.march_begin && nb[p][2] < a.march_end;
+                    faced = faced || (in_grid && cls_at(nb[p][0], nb[p][1], nb[p][2]) == CLS_BOUNDARY);
+                }
+            }
+            if (!plain && !faced && z >= a.z_begin && z < a.z_end) {
                 const uint32_t at = atomicAdd(a.counter + (marched ? 0 : 1), 1u);
                 uint32_t* dst = marched ? a.list : a.list_face;
                 if (dst) dst[at] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + x);
