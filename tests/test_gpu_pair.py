@@ -239,3 +239,46 @@ def test_a_callers_mesh_whose_direction_bits_do_not_name_the_inside_neighbours(o
     want = run_oracle(oracle, case, np.float64, threads=2)
     got = run_engine(case, "f64")
     _same(got, want)
+
+
+@pytest.mark.parametrize("receivers", ["unfaced", "one-faced", "one-on-a-wall"])
+@pytest.mark.parametrize("room", ["box", "L"])
+def test_source_and_receiver_work_riding_in_the_boundary_launches(oracle, room, receivers):
+    """A pass has three launches when nothing forbids it: march, boundary nodes t+1 (+ step t+1's source sample
+    and receivers + the source node's neighbours' t+2), boundary nodes t+2 (+ the next pass's step-t work).
+    What forbids what: a receiver or source ON a boundary node -> nothing rides; a receiver FACED by one ->
+    the t+2 launch cannot serve it early; re-entrant corners on the fix-up list (L room) -> the list keeps its
+    own launch.  Every combination must give the oracle's bits; odd step counts end a batch on a single step."""
+    dims = (36, 30, 28)
+    rng = np.random.default_rng(12)
+    coeffs = M.passive_peak_filter_coefficients(rng, 3)
+    if room == "box":
+        mesh = M.box_mesh(*dims, coefficients=coeffs, surface_of_face=[0, 1, 2, 0, 1, 2])
+    else:
+        mask = M.room_mask((dims[2], dims[1], dims[0]), "L", seed=3)
+        nodes, counts = E.classify_nodes(mask)
+        mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=[0, 1, 2, 0, 1, 2])
+    t = mesh.nodes["boundary_type"]
+    inside = (t & M.ID_INSIDE) != 0
+    is_wall = (t != 0) & ((t & (M.ID_INSIDE | M.ID_REENTRANT)) == 0)
+    nx, ny, nz = dims
+    grid = lambda a: a.reshape(nz, ny, nx)
+    near_wall = np.zeros_like(grid(is_wall))
+    for ax in range(3):
+        for sh in (1, -1):
+            near_wall |= np.roll(grid(is_wall), sh, axis=ax)
+    deep = np.nonzero((grid(inside) & ~near_wall).ravel())[0]
+    faced = np.nonzero((grid(inside) & near_wall).ravel())[0]
+    src = int(deep[len(deep) // 2])
+    recv = [src + 1, int(deep[7]), int(deep[-9])]                 # the first: a neighbour of the source (on the list)
+    if receivers == "one-faced":
+        recv.append(int(faced[len(faced) // 3]))
+    if receivers == "one-on-a-wall":
+        recv.append(int(np.nonzero(is_wall)[0][11]))
+    for steps, kind in ((27, E.SOURCE_SOFT), (20, E.SOURCE_HARD)):
+        sig = rng.uniform(-0.2, 0.2, steps)
+        case = dict(mesh=mesh, steps=steps, source_kind=kind, source_node=src, signal=sig, recv=recv, init=None)
+        want = run_oracle(oracle, case, np.float64, threads=4)
+        got = run_engine(case, "f64", all_tiles=True)
+        assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
+        _same(got, want)

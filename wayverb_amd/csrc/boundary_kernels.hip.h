@@ -272,6 +272,34 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
     }
     __syncthreads();
     if (t == 0 && has_source) a.cur[a.source_node] = injected;
+    if (a.fix_n) {
+        // (the sample above was stored by another lane, possibly another wave, of this workgroup: fence,
+        // barrier, and loads that do not stop at this CU's L1)
+        __threadfence();
+        __syncthreads();
+        const int64_t plane = (int64_t)a.pitch * a.ny;
+        int bad = 0;
+        for (uint32_t i = t; i < a.fix_n; i += width) {
+            const uint32_t idx = a.fix_nodes[i];
+            const int x = (int)(idx % (uint32_t)a.pitch);
+            const uint32_t q = idx / (uint32_t)a.pitch;
+            const int y = (int)(q % (uint32_t)a.ny);
+            const int z = (int)(q / (uint32_t)a.ny);
+            auto t1 = [&](int64_t at) { return __hip_atomic_load(a.cur + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            Real s = 0;
+            s += (x > 0) ? t1((int64_t)idx - 1) : Real(0);
+            s += (x + 1 < a.nx) ? t1((int64_t)idx + 1) : Real(0);
+            s += (y > 0) ? t1((int64_t)idx - a.pitch) : Real(0);
+            s += (y + 1 < a.ny) ? t1((int64_t)idx + a.pitch) : Real(0);
+            s += (z > 0) ? t1((int64_t)idx - plane) : Real(0);
+            s += (z + 1 < a.nz) ? t1((int64_t)idx + plane) : Real(0);
+            s = div3(s);
+            s -= a.fix_cur[idx];
+            bad |= bad_bits(s);
+            a.fix_out2[idx] = s;
+        }
+        if (bad) atomicOr(a.fix_flag, bad);
+    }
 }
 
 template <typename Real>

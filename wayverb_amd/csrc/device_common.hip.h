@@ -174,6 +174,15 @@ struct PrePostArgs {
     int* flag2;              // (two-step pass) the next step's word, reset with it; null otherwise
     int flag_init;           // ... to the mesh-static bits (0 for a well-formed mesh)
     int fused;               // non-zero: boundary_kernel's last workgroup does this work
+    // Two-step pass, riding with the source / receiver work of step t+1: the (few) nodes of the fix-up list
+    // -- t+2 of the source node's neighbours, from the t+1 field with the sample just put in.  Only when
+    // no listed node has a boundary node for a neighbour (engine.hip, pair_list_early_ok_).
+    const uint32_t* fix_nodes;
+    uint32_t fix_n;
+    const Real* fix_cur;     // field t (the listed node's own old value)
+    Real* fix_out2;          // field t+2
+    int* fix_flag;           // error_code word of step t+1 -> t+2
+    int nx, ny, nz, pitch;
 };
 
 }  // namespace wv

@@ -118,8 +118,9 @@ struct wv_engine {
     virtual int comm_destroy() = 0;
     // a batch of steps in parts, so that a group of slabs can be driven in lockstep (wv_run_group)
     virtual uint64_t plan_batch(uint64_t remaining) = 0;
-    virtual int enqueue_batch_step(uint64_t i, uint64_t batch, bool next_is_single) = 0;
-    virtual int enqueue_batch_pair(uint64_t i, int part) = 0;
+    // next_kind: what follows in the same batch -- 0 nothing, 1 a single step, 2 a two-step pass
+    virtual int enqueue_batch_step(uint64_t i, uint64_t batch, int next_kind) = 0;
+    virtual int enqueue_batch_pair(uint64_t i, int part, int next_kind) = 0;
     virtual int batch_pairs_ready(int* singles_first) = 0;
     virtual int collect_batch(uint64_t batch) = 0;
     virtual const int* batch_flags() const = 0;
@@ -730,10 +731,10 @@ public:
         return pp;
     }
 
-    // `fuse_next`: the step after this one (slot + 1, same batch) gets its pre/post work done by
-    // this step's boundary launch instead of a launch of its own -- one launch less per step,
-    // which is what small meshes are bound by.
-    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, bool fuse_next = false) {
+    // `fuse_next` (1: a single step follows in this batch, 2: a two-step pass): what follows gets its pre/post
+    // work done by this step's boundary launch instead of a launch of its own -- one launch less per
+    // step, which is what small meshes are bound by.
+    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0) {
         Real* prev = field_[prv_];
         Real* cur = field_[cur_];
         int* flag = flags_ + slot;
@@ -763,7 +764,8 @@ public:
             if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
             if (fuse_next && n_entries_) {
                 // the next step's `current` is this step's `prev`
-                const wv::PrePostArgs<Real> nx = pre_post_args(prev, slot + 1, true, signal_pos + 1, source_live);
+                wv::PrePostArgs<Real> nx = pre_post_args(prev, slot + 1, true, signal_pos + 1, source_live);
+                if (fuse_next == 2) nx.flag2 = flags_ + slot + 2;  // a two-step pass follows: both its flag words
                 if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_, &nx))) return rc;
                 pre_post_done_ = true;
             } else if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) {
@@ -789,11 +791,12 @@ public:
         // (outside nodes a caller wrote to are zeroed by two single full sweeps first: batch_pairs_ready)
         if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
         if (pair_mode_ < 0) {
-            // Measured (profiles/r02): in fp64 the two-step pass wins from 384^3 up (222 vs 203 Gnode-updates/s;
-            // 512^3 248 vs 221, 768^3 261 vs 180, 1024^3 320-330 vs 243) and loses at 256^3 (171 vs 178: four
-            // fields no longer fit the Infinity Cache where two almost do).  In fp32 a node is half the
-            // bytes for the same arithmetic: the march was bound by its instruction stream (383 vs 444 at
-            // 1024^3) until the divide sequence went (div3): 549 vs 452 now.
+            // Measured (profiles/r02/pair_vs_single_small_meshes.txt), fp64, Gnode-updates/s single / two-step:
+            // 128^3 77 / 67 (launches, not bytes), 160^3 77 / 94, 192^3 106 / 128, 256^3 178 / 188-191,
+            // 288^3 132 / 180, 352^3 183 / 225, 512^3 215 / 282, 768^3 182 / 296, 1024^3 236-243 / 317-330.
+            // (Until the fix-up launch and the two source / receiver launches of a pass went -- three launches per
+            // pass now -- single steps held out up to 256^3.)  fp32: half the bytes for the same arithmetic; the
+            // march was bound by its instruction stream (383 vs 444 at 1024^3) until div3: 532-557 vs 452.
             if (stored_nodes_ < pair_min_nodes_) return false;
         }
         return true;
@@ -824,7 +827,7 @@ public:
             WV_HIP(hipMalloc((void**)&pair_map_, cls_bytes + 16));
             WV_HIP(hipMemsetAsync(pair_map_, 0, cls_bytes + 16, stream_));
         }
-        if (!pair_counter_) WV_HIP(hipMalloc((void**)&pair_counter_, 2 * sizeof(uint32_t)));
+        if (!pair_counter_) WV_HIP(hipMalloc((void**)&pair_counter_, 3 * sizeof(uint32_t)));
         wv::PairMapArgs m{};
         m.cls = cls_;
         m.pair_map = pair_map_;
@@ -868,11 +871,14 @@ public:
         m.cover = pair_inner_ok_;
         const int64_t n_bytes = (int64_t)cls_pitch_ * ny_ * nz_;
         const unsigned grid = (unsigned)((n_bytes + 255) / 256);
-        uint32_t count[2] = {0, 0};
-        WV_HIP(hipMemsetAsync(pair_counter_, 0, 2 * sizeof(uint32_t), stream_));
+        uint32_t count[3] = {0, 0, 0};
+        WV_HIP(hipMemsetAsync(pair_counter_, 0, 3 * sizeof(uint32_t), stream_));
         hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // count
-        WV_HIP(hipMemcpyAsync(count, pair_counter_, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+        WV_HIP(hipMemcpyAsync(count, pair_counter_, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
+        // a short list none of whose nodes has a boundary node for a neighbour (typically: the source node's
+        // neighbours) can be served by the workgroup that puts the t+1 source sample in place (enqueue_pair_a)
+        pair_list_early_ok_ = count[2] == 0 && count[0] <= 2048;
         if (pair_list_) {
             (void)hipFree(pair_list_);
             pair_list_ = nullptr;
@@ -885,7 +891,7 @@ public:
             WV_HIP(hipMalloc((void**)&pair_list_, (size_t)total * sizeof(uint32_t)));
             m.list = pair_list_;
             m.list_face = pair_list_ + count[0];
-            WV_HIP(hipMemsetAsync(pair_counter_, 0, 2 * sizeof(uint32_t), stream_));
+            WV_HIP(hipMemsetAsync(pair_counter_, 0, 3 * sizeof(uint32_t), stream_));
             hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // fill
             WV_HIP(hipGetLastError());
             // processing order: 64 x 8 x 8 bricks like the boundary entries (init), so that a wave's
@@ -1046,7 +1052,8 @@ public:
     //           their nodes + boundary nodes) -> exchange #2 of the t+2 field -> the other fix-up nodes and
     //           boundary nodes to t+2, overlapping it.
     // A chain inside one process (wv_run_group) enqueues part A of every slab before part B of any.
-    int enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live) {
+    // `fuse_mid`: the source / receiver work of step t+1 (and a short fix-up list) rides in the t+1 boundary launch
+    int enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live, bool fuse_mid) {
         Real* A = field_[prv_];
         Real* B = field_[cur_];
         Real* O1 = field_[spare_[0]];
@@ -1056,12 +1063,12 @@ public:
         int rc;
         std::string cerr;
         if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-        if (pre_post_done_) return fail(WV_E_STATE, "a two-step pass cannot follow a step that served its source / receivers early");
-        {   // step t: flag words of both steps, source sample into t, receivers from t
+        if (!pre_post_done_) {  // step t: flag words of both steps, source sample into t, receivers from t
             wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
             pp.flag2 = flag2;
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
         }
+        pre_post_done_ = false;  // (else: the boundary launch before this pass has done it)
         if (comm_) {
             if ((rc = launch_stream(A, B, flag1, z_begin_, pair_z0_, false, O1))) return rc;
             if ((rc = launch_stream(A, B, flag1, pair_z1_, z_end_, false, O1))) return rc;
@@ -1107,7 +1114,29 @@ public:
             timed_steps_ += 2;
         }
         // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
-        if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, nullptr, O1))) return rc;
+        pair_mid_done_ = pair_list_done_ = false;
+        if (fuse_mid && n_entries_ && (n_recv_ || source_live)) {
+            // ... and, by its last workgroup, step t+1's source sample / receivers (none of those nodes is a
+            // boundary node: they have been final since the march) and then the few listed nodes
+            wv::PrePostArgs<Real> nx = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
+            nx.flag = nullptr;  // reset with step t's, and already written to by the march
+            if (pair_list_early_ok_ && pair_list_n_) {
+                nx.fix_nodes = pair_list_;
+                nx.fix_n = pair_list_n_;
+                nx.fix_cur = B;
+                nx.fix_out2 = O2;
+                nx.fix_flag = flag2;
+                nx.nx = nx_;
+                nx.ny = ny_;
+                nx.nz = nz_;
+                nx.pitch = pitch_;
+                pair_list_done_ = true;
+            }
+            if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, &nx, O1))) return rc;
+            pair_mid_done_ = true;
+        } else if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, nullptr, O1))) {
+            return rc;
+        }
         WV_HIP(hipGetLastError());
         return WV_OK;
     }
@@ -1129,7 +1158,9 @@ public:
         return WV_OK;
     }
 
-    int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live) {
+    // `fuse_next` (1: a single step follows in this batch, 2: another pass): its pre/post work rides in the
+    // t+2 boundary launch
+    int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live, int fuse_next) {
         Real* B = field_[cur_];
         Real* O1 = field_[spare_[0]];
         Real* O2 = field_[spare_[1]];
@@ -1137,7 +1168,7 @@ public:
         int rc;
         std::string cerr;
         if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
-        if (n_recv_ || source_live) {  // step t+1: source sample into t+1, receivers from it
+        if (!pair_mid_done_ && (n_recv_ || source_live)) {  // step t+1: source sample into t+1, receivers from it
             wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
             pp.flag = nullptr;  // reset in part A, and already written to by the march
             hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
@@ -1151,8 +1182,17 @@ public:
         }
         // t+2 of the nodes next to a boundary node / the source, from the complete t+1; then the boundary nodes
         // (most of them are faced by a boundary node and finished by its entry in the launch after this one)
-        if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
-        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0))) return rc;
+        if (!pair_list_done_ && (rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+        if (fuse_next && n_entries_ && io_nodes_unfaced()) {
+            // what follows reads its source / receiver nodes from the t+2 field: none of them is written by
+            // this launch (no boundary node, no node an entry finishes)
+            wv::PrePostArgs<Real> nx = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
+            if (fuse_next == 2) nx.flag2 = flags_ + slot + 3;
+            if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, &nx, O2, pair_inner_ok_ > 0))) return rc;
+            pre_post_done_ = true;
+        } else if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0))) {
+            return rc;
+        }
         WV_HIP(hipGetLastError());
         if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
@@ -1165,10 +1205,10 @@ public:
     }
 
     // part 0 / 1 of the two-step pass that covers steps i and i + 1 of the batch
-    int enqueue_batch_pair(uint64_t i, int part) override {
+    int enqueue_batch_pair(uint64_t i, int part, int next_kind) override {
         DeviceGuard guard(device_);
-        return part == 0 ? enqueue_pair_a((int)i, signal_pos_ + i, batch_source_live_)
-                         : enqueue_pair_b((int)i, signal_pos_ + i, batch_source_live_);
+        return part == 0 ? enqueue_pair_a((int)i, signal_pos_ + i, batch_source_live_, batch_can_fuse_)
+                         : enqueue_pair_b((int)i, signal_pos_ + i, batch_source_live_, batch_can_fuse_ ? next_kind : 0);
     }
 
     // Would this engine take two-step passes in the batch being planned?  *singles_first = -1: no;
@@ -1236,7 +1276,7 @@ public:
             graph_capturing_ = true;
             int rc = WV_OK;
             for (uint64_t i = 0; i < batch && rc == WV_OK; ++i) {
-                rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch);
+                rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch ? 1 : 0);
                 std::swap(cur_, prv_);
             }
             graph_capturing_ = false;
@@ -1275,12 +1315,12 @@ public:
         return batch;
     }
 
-    // `next_is_single`: step i + 1 of the batch is a single step too (its source / receiver work may
-    // then ride in this step's boundary launch; a two-step pass does its own)
-    int enqueue_batch_step(uint64_t i, uint64_t batch, bool next_is_single) override {
+    // `next_kind`: what step i + 1 of the batch starts (its source / receiver work may ride in this step's
+    // boundary launch)
+    int enqueue_batch_step(uint64_t i, uint64_t batch, int next_kind) override {
         DeviceGuard guard(device_);
         const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_,
-                                    batch_can_fuse_ && next_is_single && i + 1 < batch);
+                                    batch_can_fuse_ && i + 1 < batch ? next_kind : 0);
         if (rc) return rc;
         std::swap(cur_, prv_);
         return WV_OK;
@@ -1364,13 +1404,14 @@ public:
                 }
                 const bool pairs = singles_first >= 0;
                 auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+                auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
                 for (uint64_t i = 0; i < batch;) {
                     if (pair_at(i)) {
-                        if ((rc = enqueue_batch_pair(i, 0))) return rc;
-                        if ((rc = enqueue_batch_pair(i, 1))) return rc;
+                        if ((rc = enqueue_batch_pair(i, 0, 0))) return rc;
+                        if ((rc = enqueue_batch_pair(i, 1, kind_at(i + 2)))) return rc;
                         i += 2;
                     } else {
-                        if ((rc = enqueue_batch_step(i, batch, !pair_at(i + 1)))) return rc;
+                        if ((rc = enqueue_batch_step(i, batch, kind_at(i + 1)))) return rc;
                         i += 1;
                     }
                 }
@@ -1399,6 +1440,7 @@ public:
         signal_len_ = 0;
         signal_pos_ = 0;
         io_plain_known_ = false;
+        io_unfaced_known_ = false;
         if (kind == WV_SOURCE_NONE) return WV_OK;
         if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
         if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
@@ -1441,6 +1483,7 @@ public:
         recv_first_step_ = steps_done;
         n_recv_ = n;
         io_plain_known_ = false;
+        io_unfaced_known_ = false;
         return WV_OK;
     }
 
@@ -1466,6 +1509,37 @@ public:
             if (cls == wv::CLS_BOUNDARY) return false;
         }
         io_plain_ = true;
+        return true;
+    }
+
+    // true when, besides, no source / receiver node is an inside node faced by a boundary node: in a two-step
+    // pass such a node gets its t+2 value from that node's entry in the second boundary launch, which
+    // therefore cannot serve it early
+    bool io_nodes_unfaced() {
+        if (!io_nodes_plain()) return false;
+        if (io_unfaced_known_) return io_unfaced_;
+        io_unfaced_known_ = true;
+        io_unfaced_ = false;
+        std::vector<uint64_t> stored;
+        if (source_kind_ != WV_SOURCE_NONE) stored.push_back(source_node_);
+        if (n_recv_) {
+            std::vector<uint64_t> r(n_recv_);
+            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (uint64_t v : r)
+                if (v != ~0ull) stored.push_back(v);
+        }
+        for (uint64_t idx : stored) {
+            const int64_t x = (int64_t)(idx % (uint64_t)pitch_), row = (int64_t)(idx / (uint64_t)pitch_);
+            const int64_t y = row % ny_, z = row / ny_;
+            const int64_t nb[6][3] = {{x - 1, y, z}, {x + 1, y, z}, {x, y - 1, z}, {x, y + 1, z}, {x, y, z - 1}, {x, y, z + 1}};
+            for (const auto& n : nb) {
+                if (n[0] < 0 || n[0] >= pitch_ || n[1] < 0 || n[1] >= ny_ || n[2] < 0 || n[2] >= nz_) continue;
+                uint32_t cls = 0;
+                if (class_of((uint64_t)n[0], (uint64_t)(n[2] * ny_ + n[1]), &cls) != hipSuccess) return false;
+                if (cls == wv::CLS_BOUNDARY) return false;
+            }
+        }
+        io_unfaced_ = true;
         return true;
     }
 
@@ -1734,7 +1808,7 @@ private:
     // two-step passes
     int pair_inner_ok_ = -1;  // boundary entries finish the inside nodes they face (ensure_pair): -1 not checked yet
     int pair_mode_ = env_int("WV_PAIR", -1);   // 1 always (where eligible), 0 never, -1 from pair_min_nodes_ up
-    uint64_t pair_min_nodes_ = 40ull << 20;     // between 256^3 (single steps win) and 384^3 (passes win)
+    uint64_t pair_min_nodes_ = 4ull << 20;      // stored nodes: between 128^3 (single steps win) and 160^3 (passes win)
     bool pair_failed_ = false;
     uint8_t* pair_map_ = nullptr;
     uint32_t* pair_list_ = nullptr;
@@ -1751,6 +1825,9 @@ private:
     uint64_t timed_steps_ = 0;
     bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
+    bool io_unfaced_known_ = false, io_unfaced_ = false;
+    bool pair_list_early_ok_ = false;             // ensure_pair
+    bool pair_mid_done_ = false, pair_list_done_ = false;  // part A of the pass in flight has served t+1's source / receivers, the list
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
     uint8_t* btype_ = nullptr;
@@ -1978,13 +2055,13 @@ int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_
             if (pair_at(i)) {
                 for (int part = 0; part < 2; ++part)
                     for (int k = 0; k < n; ++k) {
-                        const int rc = engines[k]->enqueue_batch_pair(i, part);
+                        const int rc = engines[k]->enqueue_batch_pair(i, part, 0);
                         if (rc) return rc;
                     }
                 i += 2;
             } else {
                 for (int k = 0; k < n; ++k) {
-                    const int rc = engines[k]->enqueue_batch_step(i, batch, !pair_at(i + 1));
+                    const int rc = engines[k]->enqueue_batch_step(i, batch, 0);
                     if (rc) return rc;
                 }
                 i += 1;

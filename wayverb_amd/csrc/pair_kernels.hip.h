@@ -363,7 +363,8 @@ struct PairMapArgs {
     uint8_t* pair_map;
     uint32_t* list;        // null: count only.  Nodes of the marched planes first ...
     uint32_t* list_face;   // ... nodes of a slab's face planes here (the march does not produce those planes)
-    uint32_t* counter;     // [2]: code-3 nodes of the marched planes / of the face planes (count pass), write cursors (fill pass)
+    uint32_t* counter;     // [3]: code-3 nodes of the marched planes / of the face planes (count pass), write cursors (fill
+                           // pass); [2]: listed nodes of the marched planes with a boundary node for a neighbour
     uint64_t source_node;  // stored index of the source node, ~0 = none
     int nx, ny, nz, pitch, cls_pitch;
     int z_begin, z_end;          // planes this engine owns
@@ -452,6 +453,11 @@ __global__ void __launch_bounds__(256) pair_map_kernel(const PairMapArgs a) {
                 }
             }
             if (!plain && !faced && z >= a.z_begin && z < a.z_end) {
+                if (marched) {
+                    bool wall = false;
+                    for (int p = 0; p < 6; ++p) wall = wall || cls_at(nb[p][0], nb[p][1], nb[p][2]) == CLS_BOUNDARY;
+                    if (wall) atomicAdd(a.counter + 2, 1u);
+                }
                 const uint32_t at = atomicAdd(a.counter + (marched ? 0 : 1), 1u);
                 uint32_t* dst = marched ? a.list : a.list_face;
                 if (dst) dst[at] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + x);
