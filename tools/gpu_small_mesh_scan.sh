@@ -1,6 +1,6 @@
 #!/bin/bash
 # where do two-step passes start to pay?  (pair_min_nodes_ in engine.hip)  + chunking of the march on small meshes
-O=gpurun_out/x3; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/${1:-scan}; mkdir -p $O; export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q -x > $O/pytest.txt 2>&1; grep -h "passed\|failed" $O/pytest.txt | tail -1
 B="python bench.py --no-cpu-baseline --no-small --no-reference-on-gpu"
 val() { python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('kernel_ms'))" 2>/dev/null; }
