@@ -130,8 +130,8 @@ def test_pair_path_stops_at_the_failing_step(bad_step):
 
 
 def test_pair_path_is_what_runs_and_changing_the_source_rebuilds_the_map(oracle):
-    """kernel_time_detail reports two steps per timed launch; moving the source between runs moves
-    the nodes whose t+2 waits for the source sample."""
+    """kernel_time_detail reports two steps per timed launch (on a mesh this small one launch in eight is timed);
+    moving the source between runs moves the nodes whose t+2 waits for the source sample."""
     mesh = M.box_mesh(24, 20, 18)
     eng = E.Engine(mesh, precision="f64")
     eng.enable_kernel_timing(True)
@@ -145,7 +145,7 @@ def test_pair_path_is_what_runs_and_changing_the_source_rebuilds_the_map(oracle)
         eng.set_source(E.SOURCE_SOFT, src, sig)
         assert eng.run_steps(10) == (10, 0)
         ms, launches, steps = eng.kernel_time_detail()
-        assert launches == 5 and steps == 10
+        assert launches >= 1 and steps == 2 * launches
         for s in range(10):
             o_cur[src] += sig[s]
             assert oracle.step(o_prev, o_cur, mesh, bd) == 0
@@ -282,3 +282,23 @@ def test_source_and_receiver_work_riding_in_the_boundary_launches(oracle, room, 
         got = run_engine(case, "f64", all_tiles=True)
         assert want["flag"] == 0 and np.abs(want["trace"]).max() > 0
         _same(got, want)
+
+
+def test_configs1_at_full_length_two_step_passes_equal_single_steps():
+    """BASELINE configs[1] as written: 256^3 fp64, 10 000 steps (bench materials, impulse at the centre, which
+    reaches every wall some 220 steps in and has been round the room 45 times by the end).  Engine against
+    engine: the default stepping of this size (two-step passes, three launches per pass, ten batches) and single
+    steps end on the same bits -- both fields, every filter memory word, all 10 000 samples of three receivers."""
+    n, steps = 256, 10000
+    mesh = M.box_mesh(n, n, n, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
+    ci = mesh.compute_index
+    sig = np.zeros(steps)
+    sig[0] = 1.0
+    case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_HARD, source_node=ci(n // 2, n // 2, n // 2), signal=sig,
+                recv=[ci(n // 2 + 3, n // 2, n // 2), ci(2, 2, 2), ci(n - 3, 40, 70)], init=None)
+    _set_env(WV_PAIR=0)
+    want = run_engine(case, "f64")
+    _set_env()                                           # the engine's own choice
+    got = run_engine(case, "f64")
+    assert np.isfinite(want["trace"]).all() and np.abs(want["trace"][-100:]).max() > 0
+    _same(got, want)
