@@ -792,11 +792,11 @@ public:
         if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
         if (pair_mode_ < 0) {
             // Measured (profiles/r02/pair_vs_single_small_meshes.txt), fp64, Gnode-updates/s single / two-step:
-            // 128^3 77 / 67 (launches, not bytes), 160^3 77 / 94, 192^3 106 / 128, 256^3 178 / 188-191,
-            // 288^3 132 / 180, 352^3 183 / 225, 512^3 215 / 282, 768^3 182 / 296, 1024^3 236-243 / 317-330.
+            // 96^3 55 / 35, 128^3 96 / 72 (launches, not bytes), 160^3 86 / 101, 192^3 115 / 134, 256^3 191 / 205,
+            // 288^3 136 / 183, 384^3 210 / 253, 512^3 220 / 264-282, 768^3 180 / 282-296, 1024^3 236-243 / 317-334.
             // (Until the fix-up launch and the two source / receiver launches of a pass went -- three launches per
             // pass now -- single steps held out up to 256^3.)  fp32: half the bytes for the same arithmetic; the
-            // march was bound by its instruction stream (383 vs 444 at 1024^3) until div3: 532-557 vs 452.
+            // march was bound by its instruction stream (383 vs 444 at 1024^3) until div3: 532-558 vs 452.
             if (stored_nodes_ < pair_min_nodes_) return false;
         }
         return true;
