@@ -1502,22 +1502,27 @@ public:
         if (io_plain_known_) return io_plain_;
         io_plain_known_ = true;
         io_plain_ = false;
-        if (n_recv_ > 64) return false;  // not worth a class lookup per receiver
         std::vector<uint64_t> stored;
-        if (source_kind_ != WV_SOURCE_NONE) stored.push_back(source_node_);
-        if (n_recv_) {
-            std::vector<uint64_t> r(n_recv_);
-            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
-                return false;
-            for (uint64_t v : r)
-                if (v != ~0ull) stored.push_back(v);
-        }
+        if (!io_nodes(&stored)) return false;
         for (uint64_t idx : stored) {
             uint32_t cls = 0;
             if (class_of(idx % (uint64_t)pitch_, idx / (uint64_t)pitch_, &cls) != hipSuccess) return false;
             if (cls == wv::CLS_BOUNDARY) return false;
         }
         io_plain_ = true;
+        return true;
+    }
+
+    // stored indices of the source node and the receiver nodes; false: too many to be worth looking at one by one
+    bool io_nodes(std::vector<uint64_t>* stored) {
+        if (n_recv_ > 64) return false;
+        if (source_kind_ != WV_SOURCE_NONE) stored->push_back(source_node_);
+        if (n_recv_) {
+            std::vector<uint64_t> r(n_recv_);
+            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (uint64_t v : r)
+                if (v != ~0ull) stored->push_back(v);
+        }
         return true;
     }
 
@@ -1530,13 +1535,7 @@ public:
         io_unfaced_known_ = true;
         io_unfaced_ = false;
         std::vector<uint64_t> stored;
-        if (source_kind_ != WV_SOURCE_NONE) stored.push_back(source_node_);
-        if (n_recv_) {
-            std::vector<uint64_t> r(n_recv_);
-            if (hipMemcpy(r.data(), recv_nodes_, n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
-            for (uint64_t v : r)
-                if (v != ~0ull) stored.push_back(v);
-        }
+        if (!io_nodes(&stored)) return false;
         for (uint64_t idx : stored) {
             const int64_t x = (int64_t)(idx % (uint64_t)pitch_), row = (int64_t)(idx / (uint64_t)pitch_);
             const int64_t y = row % ny_, z = row / ny_;
