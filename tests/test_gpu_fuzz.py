@@ -1,0 +1,80 @@
+"""Seeded random cases through the engine against the oracle: room shape, mesh dimensions (rows of one to
+three waves, ragged), wall materials, source kind and place (any node that is not `none`: inside, next to a wall,
+ON a wall, re-entrant), receivers anywhere (inside, faced by a wall, on walls, outside), step count, precision
+-- each case with the engine's own choice of stepping, with two-step passes forced on, and with two-step
+passes whose wall-adjacent nodes all go through the fix-up list.  Everything the run leaves behind must be
+the oracle's bit for bit: receiver traces, both fields, every filter memory word, the step count and flag."""
+import numpy as np
+import pytest
+
+from helpers import run_engine, run_oracle
+from test_gpu_parity import _set_env
+from wayverb_amd import engine as E
+from wayverb_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"default": {}, "passes": dict(WV_PAIR=1), "passes-list-only": dict(WV_PAIR=1, WV_PAIR_INNER_FIX=0),
+         "passes-own-launches": dict(WV_PAIR=1, WV_FUSE_PRE_POST=0), "single-steps": dict(WV_PAIR=0)}
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    room = ["box", "L", "sphere", "blob"][seed % 4]
+    nx = int(rng.choice([rng.integers(7, 40), rng.integers(120, 140), rng.integers(250, 300)], p=[0.6, 0.25, 0.15]))
+    ny, nz = int(rng.integers(7, 34)), int(rng.integers(7, 30))
+    if room != "box":
+        nx, ny, nz = max(nx, 14), max(ny, 14), max(nz, 14)
+    dims = (nx, ny, nz)
+    n_filtered = int(rng.integers(1, 4))
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, n_filtered, sections=int(rng.integers(1, 4))),
+                             np.array([M.flat_coefficients(float(rng.uniform(0.05, 0.6))), M.rigid_coefficients()],
+                                      dtype=M.coefficients_dtype)])
+    surfaces = [int(s) for s in rng.integers(0, len(coeffs), 6)]
+    if room == "box":
+        mesh = M.box_mesh(*dims, coefficients=coeffs, surface_of_face=surfaces)
+    else:
+        mask = M.room_mask((nz, ny, nx), room, seed=seed)
+        nodes, counts = E.classify_nodes(mask)
+        mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=surfaces)
+    t = mesh.nodes["boundary_type"]
+    live = np.nonzero(t != 0)[0]
+    inside = np.nonzero(t & M.ID_INSIDE)[0]
+    steps = int(rng.integers(3, 34))
+    # the source: mostly inside, sometimes any live node (a wall node, a re-entrant corner)
+    src = int(rng.choice(inside)) if rng.random() < 0.7 else int(rng.choice(live))
+    n_recv = int(rng.integers(0, 7))
+    recv = [int(rng.choice(inside)) if rng.random() < 0.5 else int(rng.integers(0, mesh.num_nodes)) for _ in range(n_recv)]
+    if n_recv and rng.random() < 0.5:
+        recv[0] = src                                  # a receiver on the source node reads the injected sample
+    kind = int(rng.choice([E.SOURCE_HARD, E.SOURCE_SOFT]))
+    sig = rng.uniform(-0.3, 0.3, steps)
+    init = None
+    if rng.random() < 0.5:                             # noise in the room to start with
+        prev = np.where(t != 0, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+        cur = np.where(t != 0, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+        init = (prev, cur)
+    return dict(mesh=mesh, steps=steps, source_kind=kind, source_node=src, signal=sig, recv=recv, init=init), room, dims
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_case_equals_the_oracle_in_every_stepping_mode(oracle, built_library, seed):
+    case, room, dims = random_case(1000 + seed)
+    tag, dtype = ("f64", np.float64) if seed % 3 else ("f32", np.float32)
+    want = run_oracle(oracle, case, dtype, threads=2)
+    assert want["flag"] == 0, (room, dims)
+    modes = dict(MODES)
+    modes["passes-in-z-chunks"] = dict(WV_PAIR=1, WV_PAIR_CHUNKS=2 + seed % 3)
+    for mode, env in modes.items():
+        _set_env(**env)
+        try:
+            got = run_engine(case, tag, all_tiles=bool(seed % 2))
+        finally:
+            _set_env()
+        where = "%s %s %s seed %d" % (mode, room, dims, seed)
+        assert got["steps"] == want["steps"], where
+        assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8)), where
+        assert got["current"].tobytes() == want["current"].tobytes(), where
+        assert got["previous"].tobytes() == want["previous"].tobytes(), where
+        for d, (a, b) in enumerate(zip(got["bd"], want["bd"])):
+            assert a.tobytes() == b.tobytes(), where + " D=%d" % (d + 1)
