@@ -216,3 +216,35 @@ def test_exhausted_source_ends_a_chain(built_library):
     group = E.LocalSlabGroup(engines)
     assert group.run_steps(100) == (5, 0)
     group.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_slab_chains_equal_the_single_domain(built_library, seed, _step_mode):
+    """Seeded random chains: 2-7 slabs of unequal thickness (down to one plane, where the whole chain falls back to
+    single steps), box / L / blob rooms, the source anywhere that is not `none` (inside, on a wall, on a slab face),
+    receivers anywhere, noise to start with -- against the single-domain engine in the same stepping mode."""
+    rng = np.random.default_rng(700 + seed)
+    world = int(rng.integers(2, 8))
+    room = ["box", "L", "blob"][seed % 3]
+    nx = int(rng.choice([rng.integers(14, 40), rng.integers(125, 135)], p=[0.8, 0.2]))
+    ny = int(rng.integers(14, 30))
+    nz = int(max(14, world * rng.integers(1, 8) + rng.integers(0, world)))
+    dims = (nx, ny, nz)
+    gmesh = global_mesh(dims, room, rng)
+    precision = "f64" if seed % 2 else "f32"
+    dtype = np.float64 if precision == "f64" else np.float32
+    t = gmesh.nodes["boundary_type"]
+    live = t != 0
+    gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    steps = int(rng.integers(4, 30))
+    signal = rng.uniform(-0.1, 0.1, steps)
+    inside = np.nonzero(t & M.ID_INSIDE)[0]
+    source = int(rng.choice(inside)) if rng.random() < 0.6 else int(rng.choice(np.nonzero(live)[0]))
+    receivers = [int(rng.choice(inside)) if rng.random() < 0.6 else int(rng.integers(0, gmesh.num_nodes))
+                 for _ in range(int(rng.integers(1, 6)))]
+    kind = int(rng.choice([E.SOURCE_SOFT, E.SOURCE_HARD]))
+    want = single_domain(gmesh, precision, gprev, gcur, kind, source, signal, receivers, steps)
+    got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps)
+    assert want["done"] == steps and want["flag"] == 0
+    assert_same(got, want, gmesh)
