@@ -1248,6 +1248,7 @@ public:
     // -------------------------------------------------------------------------------------------
     int step(int32_t* flag) override {
         DeviceGuard guard(device_);
+        pre_post_done_ = false;  // (a batch that failed while being enqueued may have left it set)
         int rc = enqueue_step(0, false, 0, false);
         if (rc) return rc;
         WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -1321,6 +1322,8 @@ public:
         }
         batch_can_fuse_ = !comm_ && io_nodes_plain() && env_int("WV_FUSE_PRE_POST", 1) != 0;
         batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
+        // nothing rides across batches: whatever a batch that failed half-way left behind does not count
+        pre_post_done_ = pair_mid_done_ = pair_list_done_ = false;
         return batch;
     }
 
