@@ -107,3 +107,17 @@ def test_concert_hall_in_z_slabs(hall, world, pair, monkeypatch):
     got = slab_chain(mesh, world, "f64", zeros, zeros, E.SOURCE_HARD, src, sig, receivers, steps)
     assert want["done"] == steps and want["flag"] == 0 and np.abs(want["cur"]).max() > 0
     assert_same(got, want, mesh)
+
+
+@pytest.mark.parametrize("slabs", [2, 5])
+def test_canonical_on_the_hall_cut_into_slabs(hall, slabs):
+    """simulation.canonical(..., slabs=K): the caller-level form of "1 -> K GPUs" (all K slabs on this one GPU
+    here) returns the single-domain run's directional records bit for bit."""
+    vm, wg = hall["vm"], hall["wg"]
+    env = sim.Environment()
+    one = sim.canonical(vm, hall["source"], hall["receiver"], env, wg["cutoff"], wg["usable_portion"], 0.12)
+    cut = sim.canonical(vm, hall["source"], hall["receiver"], env, wg["cutoff"], wg["usable_portion"], 0.12, slabs=slabs)
+    (d1, fs1, band1), (dk, fsk, bandk) = one[0], cut[0]
+    assert (fs1, band1) == (fsk, bandk) and len(d1) == len(dk) > 100
+    assert np.asarray(d1).tobytes() == np.asarray(dk).tobytes()
+    assert np.abs(d1["pressure"]).max() > 0

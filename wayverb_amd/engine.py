@@ -493,6 +493,50 @@ def run_fast(engine, source_kind, source_node, signal, receivers, keep_going=lam
     return done_total, engine.fetch_receivers(first, done_total)
 
 
+def run_fast_slabs(mesh, slabs, source_kind, source_node, signal, receivers, precision="f64", devices=None,
+                   keep_going=lambda: True, chunk=1024):
+    """`run_fast` on a mesh cut into `slabs` z-slabs that live in THIS process -- on the GPUs listed in `devices`
+    (slab r on devices[r % len(devices)]; default: all on the current device) -- joined by the in-process transport
+    and stepped together (wv_comm_init_local / wv_run_group: the step code of the one-rank-per-GPU RCCL chain,
+    face planes travelling by device-to-device copies).  Returns (steps, out[steps, n_receivers]) exactly as
+    run_fast on the whole mesh does, bit for bit."""
+    from .slab import SlabLayout, place_source_and_receivers, slab_mesh
+    devices = list(devices) if devices else [-1]
+    engines, owners = [], []
+    try:
+        for r in range(slabs):
+            L = SlabLayout(mesh.dims, r, slabs)
+            eng = Engine(slab_mesh(mesh, L), precision=precision, device=devices[r % len(devices)],
+                         ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi)
+            engines.append(eng)
+            src_local, mine = place_source_and_receivers(L, source_node, receivers)
+            if src_local is not None:
+                eng.set_source(source_kind, src_local, signal)
+            eng.set_receivers([idx for _, idx in mine])
+            owners.append([pos for pos, _ in mine])
+        group = LocalSlabGroup(engines)
+    except Exception:
+        for e in engines:
+            e.close()
+        raise
+    try:
+        n = len(signal)
+        done_total = 0
+        while done_total < n and keep_going():
+            done, flag = group.run_steps(min(chunk, n - done_total))
+            done_total += done
+            raise_for_flag(flag)
+            if done == 0:
+                break
+        out = np.zeros((done_total, len(receivers)))
+        for eng, cols in zip(engines, owners):
+            if cols:
+                out[:, cols] = eng.fetch_receivers(0, done_total)
+        return done_total, out
+    finally:
+        group.close()
+
+
 class _ResidentMesh:
     """What Engine's buffer helpers need to know about a mesh whose nodes never came to the host."""
 

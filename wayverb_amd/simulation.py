@@ -108,11 +108,13 @@ def compute_voxels_and_mesh(vertices, triangles, surface_absorptions, anchor, sa
 
 
 def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulation_time, precision="f64",
-              device=-1, keep_going=lambda: True):
+              device=-1, keep_going=lambda: True, slabs=1, devices=None):
     """canonical (single band): hard source at `source`, directional receiver at `receiver`, for
     ceil(sample_rate * simulation_time) steps.  Returns [(directional records, sample_rate,
     (0, cutoff))] -- the bandpass_band list waveguide::postprocess takes -- or None when stopped early.
-    `precision`: "f32" is the reference's pressure type; "f64" the fp64 engine."""
+    `precision`: "f32" is the reference's pressure type; "f64" the fp64 engine.
+    `slabs` > 1: the mesh is cut into that many z-slabs, on the GPUs in `devices` (BASELINE configs[4], "1 -> 8
+    GPUs"; engine.run_fast_slabs) -- same records, bit for bit."""
     mesh = vm.mesh
     sample_rate = compute_sample_rate(mesh.spacing, environment.speed_of_sound)
 
@@ -130,12 +132,17 @@ def canonical(vm, source, receiver, environment, cutoff, usable_portion, simulat
     neighbours = mesh.compute_neighbors(receiver_index)
     if any(n == 0xFFFFFFFF for n in neighbours):
         raise RuntimeError("Can't place directional_receiver at this node as it is adjacent to a boundary.")
-    eng = E.Engine(mesh, precision=precision, device=device)
-    try:
-        done, traces = E.run_fast(eng, E.SOURCE_HARD, mesh_index(source), signal, [receiver_index] + list(neighbours),
-                                  keep_going=keep_going)
-    finally:
-        eng.close()
+    if slabs > 1:
+        done, traces = E.run_fast_slabs(mesh, slabs, E.SOURCE_HARD, mesh_index(source), signal,
+                                        [receiver_index] + list(neighbours), precision=precision,
+                                        devices=devices or [device], keep_going=keep_going)
+    else:
+        eng = E.Engine(mesh, precision=precision, device=device)
+        try:
+            done, traces = E.run_fast(eng, E.SOURCE_HARD, mesh_index(source), signal, [receiver_index] + list(neighbours),
+                                      keep_going=keep_going)
+        finally:
+            eng.close()
     if done != ideal_steps:
         return None
     directional = P.directional_receiver(traces, mesh.spacing, sample_rate, environment.ambient_density)
