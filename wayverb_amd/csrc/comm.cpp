@@ -163,6 +163,7 @@ bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_str
     }
     if (!hip_ok(hipSetDevice(device), "hipSetDevice", err)) return false;
     local_ = true;
+    device_ = device;
     rank_ = rank;
     nranks_ = nranks;
     has_lo_ = has_lo;
@@ -171,6 +172,27 @@ bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_str
     for (hipEvent_t* e : {&faces_ready_, &ghosts_ready_, &pushed_lo_, &pushed_hi_, &step_done_})
         if (!hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
     return true;
+}
+
+void SlabComm::link_local(SlabComm* lo, SlabComm* hi) {
+    lo_ = lo;
+    hi_ = hi;
+    for (SlabComm* peer : {lo, hi}) {
+        if (!peer || peer->device_ == device_) continue;
+        int can = 0, before = 0;
+        (void)hipGetDevice(&before);
+        if (hipDeviceCanAccessPeer(&can, device_, peer->device_) == hipSuccess && can && hipSetDevice(device_) == hipSuccess) {
+            (void)hipDeviceEnablePeerAccess(peer->device_, 0);  // "already enabled" is fine
+            (void)hipGetLastError();
+        }
+        (void)hipSetDevice(before);
+    }
+}
+
+// one face plane into a neighbour's ghost plane, on this slab's halo stream
+static hipError_t push_plane(void* dst, int dst_device, const void* src, int src_device, size_t bytes, hipStream_t stream) {
+    if (dst_device == src_device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    return hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, stream);
 }
 
 void SlabComm::set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz) {
@@ -236,8 +258,7 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
                 *err = "neighbouring slabs disagree about the plane size";
                 return false;
             }
-            if (!hip_ok(hipMemcpyAsync(dst, base + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, stream_),
-                        "hipMemcpyAsync", err))
+            if (!hip_ok(push_plane(dst, lo_->device_, base + plane_bytes, device_, plane_bytes, stream_), "hipMemcpyAsync", err))
                 return false;
             if (!hip_ok(hipEventRecord(pushed_lo_, stream_), "hipEventRecord", err)) return false;
             pushed_lo_set_ = true;
@@ -251,8 +272,7 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
                 return false;
             }
             char* dst = static_cast<char*>(hi_->fields_[field]);
-            if (!hip_ok(hipMemcpyAsync(dst, base + (size_t)(nz - 2) * plane_bytes, plane_bytes, hipMemcpyDeviceToDevice,
-                                       stream_),
+            if (!hip_ok(push_plane(dst, hi_->device_, base + (size_t)(nz - 2) * plane_bytes, device_, plane_bytes, stream_),
                         "hipMemcpyAsync", err))
                 return false;
             if (!hip_ok(hipEventRecord(pushed_hi_, stream_), "hipEventRecord", err)) return false;

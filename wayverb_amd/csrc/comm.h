@@ -38,10 +38,8 @@ public:
     bool init_local(int rank, int nranks, int device, hipStream_t comm_stream, bool has_lo, bool has_hi,
                     std::string* err);
     // local transport: the neighbouring slabs' communicators (null at the ends of the chain)
-    void link_local(SlabComm* lo, SlabComm* hi) {
-        lo_ = lo;
-        hi_ = hi;
-    }
+    // (slabs on different GPUs of this process: peer access is switched on where the devices offer it)
+    void link_local(SlabComm* lo, SlabComm* hi);
     // The engine's field buffers: base pointers, bytes per plane, planes (ghosts included).
     void set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz);
 
@@ -66,6 +64,7 @@ public:
 private:
     void* comm_ = nullptr;
     int rank_ = 0, nranks_ = 1;
+    int device_ = 0;  // local transport: the GPU this slab lives on
     bool has_lo_ = false, has_hi_ = false, loopback_ = false, local_ = false;
     hipStream_t stream_ = nullptr;
     hipEvent_t faces_ready_ = nullptr;
