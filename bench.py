@@ -254,7 +254,7 @@ def main():
         "config": {"workload": "%dx%dx%d box mesh, %s pressures, walls of 4 mixed materials (2 flat, 2 frequency-dependent order-6 IIR), hard-source impulse + 1 receiver"
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
                    "per_gpu": "%dx%dx%d z-slab" % (nx, ny, args.nz), "decomposition": "z-slabs x%d" % world,
-                   "halo": "RCCL send/recv, 1 plane per neighbour per step" if world > 1 else "none",
+                   "halo": "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass), overlapped with the interior" if world > 1 else "none",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
