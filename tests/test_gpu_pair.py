@@ -302,3 +302,50 @@ def test_configs1_at_full_length_two_step_passes_equal_single_steps():
     got = run_engine(case, "f64")
     assert np.isfinite(want["trace"]).all() and np.abs(want["trace"][-100:]).max() > 0
     _same(got, want)
+
+
+@pytest.mark.parametrize("room,dims", [("sphere", (300, 40, 36)), ("blob", (520, 36, 30)), ("L", (260, 44, 38)), ("sphere", (140, 60, 50))])
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_rooms_much_narrower_than_their_rows(oracle, room, dims, tag, dtype):
+    """Whole 128-column blocks of a row are `none` for many planes; work lists on (the default), two-step passes
+    forced: the march runs over the live units only, waves full of outside nodes beside live ones."""
+    mask = M.room_mask((dims[2], dims[1], dims[0]), room, seed=11)
+    nodes, counts = E.classify_nodes(mask)
+    rng = np.random.default_rng(23)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2), np.array([M.flat_coefficients(0.25)], dtype=M.coefficients_dtype)])
+    mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=[0, 1, 2, 0, 1, 2])
+    assert mask.mean() < 0.65
+    t = mesh.nodes["boundary_type"]
+    inside = np.nonzero(t & M.ID_INSIDE)[0]
+    live = t != 0
+    prev = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    cur = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    steps = 29
+    case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_SOFT, source_node=int(inside[len(inside) // 2]),
+                signal=rng.uniform(-0.1, 0.1, steps), recv=[int(inside[5]), int(inside[-7]), 3], init=(prev, cur))
+    want = run_oracle(oracle, case, dtype, threads=4)
+    _set_env(WV_PAIR=1)
+    got = run_engine(case, tag)
+    _same(got, want)
+
+
+def test_passes_on_a_bigger_sparse_room_equal_single_steps():
+    """Engine against engine: a sphere inscribed in 384 x 200 x 160 (three waves per row, half the mesh outside),
+    41 steps from noise: two-step passes over the live units vs single steps over the live tiles."""
+    dims = (384, 200, 160)
+    mask = M.room_mask((dims[2], dims[1], dims[0]), "sphere")
+    nodes, counts = E.classify_nodes(mask)
+    rng = np.random.default_rng(3)
+    mesh = M.mesh_from_nodes(dims, nodes, counts, M.bench_materials(), surface_of_port=[0, 1, 2, 3, 2, 3])
+    t = mesh.nodes["boundary_type"]
+    live = t != 0
+    inside = np.nonzero(t & M.ID_INSIDE)[0]
+    prev = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    cur = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    case = dict(mesh=mesh, steps=41, source_kind=E.SOURCE_HARD, source_node=int(inside[len(inside) // 2]),
+                signal=rng.uniform(-0.1, 0.1, 41), recv=[int(inside[9]), int(inside[-3])], init=(prev, cur))
+    _set_env(WV_PAIR=0)
+    want = run_engine(case, "f64")
+    _set_env(WV_PAIR=1)
+    got = run_engine(case, "f64")
+    _same(got, want)
