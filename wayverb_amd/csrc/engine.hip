@@ -582,8 +582,13 @@ public:
         }
         list_start_[8] = (uint32_t)list.size();
         if (list.empty()) return WV_OK;
-        WV_HIP(hipMalloc((void**)&tile_list_, list.size() * sizeof(uint64_t)));
-        WV_HIP(hipMemcpy(tile_list_, list.data(), list.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        uint64_t* staged = nullptr;  // (a list that did not arrive whole must never be launched with)
+        WV_HIP(hipMalloc((void**)&staged, list.size() * sizeof(uint64_t)));
+        if (hipMemcpy(staged, list.data(), list.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(staged);
+            return fail(WV_E_HIP, "copying the tile work list to the device failed");
+        }
+        tile_list_ = staged;
         return WV_OK;
     }
 
@@ -1019,8 +1024,13 @@ public:
         pair_unit_start_[8] = (uint32_t)list.size();
         pair_zc_ = zc;
         pair_chunks_ = chunks;
-        WV_HIP(hipMalloc((void**)&pair_units_, list.size() * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(pair_units_, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        uint32_t* staged = nullptr;
+        WV_HIP(hipMalloc((void**)&staged, list.size() * sizeof(uint32_t)));
+        if (hipMemcpy(staged, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(staged);
+            return fail(WV_E_HIP, "copying the march's unit list to the device failed");
+        }
+        pair_units_ = staged;
         return WV_OK;
     }
 
@@ -1442,30 +1452,32 @@ public:
     // -------------------------------------------------------------------------------------------
     int set_source(int kind, uint64_t node, const double* signal, uint64_t n) override {
         DeviceGuard guard(device_);
+        // validate and stage first; the engine's source changes only once nothing can fail any more
         if (kind != WV_SOURCE_NONE && kind != WV_SOURCE_HARD && kind != WV_SOURCE_SOFT)
             return fail(WV_E_INVALID_ARGUMENT, "unknown source kind");
-        if (signal_) {
-            WV_HIP(hipFree(signal_));
-            signal_ = nullptr;
+        double* staged = nullptr;
+        uint32_t cls = wv::CLS_INSIDE;
+        if (kind != WV_SOURCE_NONE) {
+            if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
+            if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
+            WV_HIP(class_of(node % (uint64_t)nx_, node / (uint64_t)nx_, &cls));
+            WV_HIP(hipMalloc((void**)&staged, std::max<uint64_t>(n, 1) * sizeof(double)));
+            if (n && hipMemcpy(staged, signal, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(staged);
+                return fail(WV_E_HIP, "copying the source signal to the device failed");
+            }
         }
+        if (signal_) (void)hipFree(signal_);
+        signal_ = staged;
         source_kind_ = kind;
-        signal_len_ = 0;
+        signal_len_ = kind == WV_SOURCE_NONE ? 0 : n;
         signal_pos_ = 0;
         io_plain_known_ = false;
         io_unfaced_known_ = false;
         if (kind == WV_SOURCE_NONE) return WV_OK;
-        if (node >= n_nodes_) return fail(WV_E_INVALID_ARGUMENT, "source node outside the mesh");
-        if (n && !signal) return fail(WV_E_INVALID_ARGUMENT, "signal missing");
         source_node_ = stored_index(node);
-        {
-            // a source in an outside node keeps writing non-zero values there: no work lists then
-            uint32_t cls = 0;
-            WV_HIP(class_of(node % (uint64_t)nx_, node / (uint64_t)nx_, &cls));
-            if (cls == wv::CLS_NONE) outside_dirty_ = 1 << 30;
-        }
-        signal_len_ = n;
-        WV_HIP(hipMalloc((void**)&signal_, std::max<uint64_t>(n, 1) * sizeof(double)));
-        if (n) WV_HIP(hipMemcpy(signal_, signal, n * sizeof(double), hipMemcpyHostToDevice));
+        // a source in an outside node keeps writing non-zero values there: no work lists then
+        if (cls == wv::CLS_NONE) outside_dirty_ = 1 << 30;
         return WV_OK;
     }
 
