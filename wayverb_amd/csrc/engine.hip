@@ -381,8 +381,13 @@ public:
         std::vector<uint32_t> order(std::max<uint32_t>(plane_start_[nz_], 1)), cursor(plane_start_.begin(), plane_start_.end() - 1);
         for (uint32_t e = 0; e < n_entries_; ++e)
             if (bnode[e] != wv::INVALID_NODE) order[cursor[bnode[e] / plane]++] = e;
-        WV_HIP(hipMalloc((void**)&zorder_, order.size() * sizeof(uint32_t)));
-        WV_HIP(hipMemcpy(zorder_, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        uint32_t* staged = nullptr;
+        WV_HIP(hipMalloc((void**)&staged, order.size() * sizeof(uint32_t)));
+        if (hipMemcpy(staged, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(staged);
+            return fail(WV_E_HIP, "copying the plane order of the boundary entries to the device failed");
+        }
+        zorder_ = staged;
         return WV_OK;
     }
 
