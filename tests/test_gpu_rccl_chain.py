@@ -1,0 +1,56 @@
+"""The RCCL branch of csrc/comm.cpp with more than one rank, on ONE GPU: tests/mock_rccl stands in for librccl (its
+ranks are threads of the worker process), everything above it is the product -- wv_comm_init, the open-chain
+exchange with rank-1 / rank+1, the flag all-reduce over the ranks, the per-batch agreement on the stepping mode,
+wv_run called by every rank.  The chain must equal the single-domain engine bit for bit, stop on the same
+step when one rank sees a non-finite value, and take two-step passes when told to."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def mock_dir(tmp_path_factory, built_library):
+    d = tmp_path_factory.mktemp("mock_rccl")
+    out = subprocess.run([HIPCC, "-O2", "-fPIC", "-shared", "-std=c++17", os.path.join(HERE, "mock_rccl", "mock_rccl.cpp"),
+                          "-o", str(d / "librccl.so.1")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return str(d)
+
+
+def run_worker(mock_dir, *args, pair=None, timeout=300):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["WV_NO_TORCH_PRELOAD"] = "1"   # torch would bring the real librccl (same soname) into the process
+    env.pop("WV_PAIR", None)
+    if pair is not None:
+        env["WV_PAIR"] = str(pair)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py")] + [str(a) for a in args],
+                         capture_output=True, text=True, env=env, timeout=timeout)
+    last = (out.stdout.strip().splitlines() or [""])[-1]
+    assert out.returncode == 0 and last.startswith("OK"), (out.stdout[-1500:], out.stderr[-1500:])
+    return last
+
+
+@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
+@pytest.mark.parametrize("world,room,dims,precision", [(2, "box", (20, 18, 24), "f64"), (3, "L", (28, 24, 30), "f64"),
+                                                       (4, "blob", (30, 26, 33), "f32"), (8, "box", (140, 12, 40), "f64")])
+def test_chain_of_ranks_over_the_rccl_path_equals_the_single_domain(mock_dir, world, room, dims, precision, pair):
+    last = run_worker(mock_dir, world, room, *dims, precision, 27, 100 + world, pair=pair)
+    planes = dims[2] // world
+    if pair and planes >= 4:
+        assert "two_step_passes True" in last, last
+
+
+@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
+def test_a_non_finite_value_on_one_rank_stops_every_rank_at_that_step(mock_dir, pair):
+    """The flag words are OR-ed over the ranks per batch (comm.cpp, or_flags): steps and flag of every rank equal the
+    single domain's -- the run ends on the step that produced the value (waveguide.h:100-119)."""
+    last = run_worker(mock_dir, 3, "box", 18, 16, 27, "f64", 40, 7, 17, pair=pair)
+    assert last.startswith("OK steps 17 ") and " flag 0 " not in last, last
