@@ -104,3 +104,26 @@ def test_plain_c_example_runs(built_library):
     p = subprocess.run([C_EXE], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "first arrival at step 5" in p.stdout
+
+
+CHAIN_SRC = os.path.join(ROOT, "examples", "slab_chain.c")
+CHAIN_EXE = os.path.join(ROOT, "examples", "slab_chain")
+
+
+def _build_chain_example(built_library):
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), CHAIN_SRC,
+                           "-o", CHAIN_EXE, "-L", os.path.join(ROOT, "wayverb_amd"), "-lwayverb_amd", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "wayverb_amd")])
+
+
+def test_c_slab_chain_example_compiles(built_library):
+    """examples/slab_chain.c: wv_comm_init_local / wv_run_group from C99 as declared."""
+    _build_chain_example(built_library)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs", [1, 3, 7])
+def test_c_slab_chain_example_runs(built_library, slabs):
+    _build_chain_example(built_library)
+    p = subprocess.run([CHAIN_EXE, str(slabs)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "identical to the single domain" in p.stdout, p.stdout + p.stderr
