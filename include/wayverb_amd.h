@@ -180,7 +180,8 @@ int wv_set_receivers(wv_engine* e, const uint64_t* nodes, uint32_t n);
 /* Run up to n_steps loop iterations on the device.  Stops early at the first step whose flag
  * is non-zero: *steps_done = completed steps (that step excluded), *flag = its error bits. */
 int wv_run(wv_engine* e, uint64_t n_steps, uint64_t* steps_done, int32_t* flag);
-/* Receiver samples of steps [first, first+n) as double[n][num_receivers]. */
+/* Receiver samples of steps [first, first+n) as double[n][num_receivers]; steps driven by wv_step / wv_swap
+ * record nothing (their rows are NaN). */
 int wv_fetch_receivers(wv_engine* e, uint64_t first, uint64_t n, double* dst);
 /* Number of loop iterations completed since creation. */
 int wv_step_count(wv_engine* e, uint64_t* steps);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <thread>
@@ -1276,6 +1277,9 @@ public:
     int swap() override {
         std::swap(cur_, prv_);
         ++steps_done;
+        // a step driven from outside (wv_step / wv_swap) records no receiver samples: its row of the log is NaN,
+        // so that wv_fetch_receivers keeps addressing rows by step
+        if (n_recv_) recv_log_.insert(recv_log_.end(), n_recv_, std::numeric_limits<double>::quiet_NaN());
         return WV_OK;
     }
 
