@@ -290,3 +290,40 @@ def test_config2_1024cubed_full_size(oracle, built_library):
                 assert np.ascontiguousarray(got_rows).tobytes() == np.ascontiguousarray(want_rows).tobytes(), \
                     "filter memories of plane %d differ (D=%d)" % (z, d)
                 assert np.any(got_rows != 0) or hi == lo
+
+
+def test_config2_1024cubed_long_run_two_step_passes_equal_single_steps(built_library):
+    """BASELINE configs[2] beyond the few steps an oracle window can follow: 1024^3 fp64 with the bench's four wall
+    materials, an impulse at the centre, 1 200 steps (the wave front has crossed the room and come back) -- the
+    engine's own stepping (two-step passes, three launches each, a batch boundary in between) against single steps:
+    16 sampled planes of both fields, every filter memory word of all six walls and 1 200 samples of four
+    receivers, bit for bit."""
+    from wayverb_amd import engine as E
+    from wayverb_amd.slab import box_slab_mesh
+    n, steps = 1024, 1200
+    sig = np.zeros(steps)
+    sig[0] = 1.0
+    ci = lambda x, y, z: (z * n + y) * n + x
+    recv = [ci(n // 2 + 3, n // 2, n // 2), ci(2, 2, 2), ci(n - 3, 400, 700), ci(1, 512, 512)]
+    planes = [1, 2, 3, 255, 256, 510, 511, 512, 513, 700, 767, 768, 1020, 1021, 1022, 64]
+    runs = {}
+    for pair in (0, -1):
+        _set_env(**({"WV_PAIR": 0} if pair == 0 else {}))
+        mesh = box_slab_mesh(n, n, n, _Window((n, n, n), 0, n), coefficients=M.bench_materials())
+        eng = E.Engine(mesh, precision="f64")
+        mesh.nodes = None
+        try:
+            done, out = E.run_fast(eng, E.SOURCE_HARD, ci(n // 2, n // 2, n // 2), sig, recv)
+            assert done == steps
+            runs[pair] = dict(trace=out, bd=[eng.read_boundary_data(d)["filter_memory"].copy() for d in (1, 2, 3)],
+                              planes={(z, b): eng.read_planes(z, 1, b).copy() for z in planes for b in (E.BUF_CURRENT, E.BUF_PREVIOUS)})
+        finally:
+            eng.close()
+    a, b = runs[0], runs[-1]
+    assert np.isfinite(a["trace"]).all() and np.abs(a["trace"][-200:, 0]).max() > 0
+    assert a["trace"].tobytes() == b["trace"].tobytes(), "receiver traces differ"
+    for d in range(3):
+        assert a["bd"][d].tobytes() == b["bd"][d].tobytes(), "filter memories differ (D=%d)" % (d + 1)
+    for key in a["planes"]:
+        assert a["planes"][key].tobytes() == b["planes"][key].tobytes(), "plane %d of buffer %d differs" % key
+        assert np.any(a["planes"][key] != 0)
