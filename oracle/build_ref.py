@@ -242,8 +242,9 @@ def build_cl(tmp, verbose):
         return
     gen = os.path.join(tmp, "program_text.c")
     with open(gen, "w") as f:
-        for tag, promote in (("f32", False), ("f64", True)):
-            data = assemble(promote).encode("utf-8") + b"\0"
+        texts = [("f32", assemble(False)), ("f64", assemble(True)), ("setup", assemble_setup()), ("bcf", assemble_bcf())]
+        for tag, text in texts:
+            data = text.encode("utf-8") + b"\0"
             f.write("const char wvref_program_text_%s[] = {%s};\n" % (tag, ",".join(str(b) for b in data)))
     so = os.path.join(OUT, "libwvref_cl.so")
     obj = os.path.join(tmp, "program_text.o")

@@ -335,6 +335,33 @@ class ReferenceOnDevice:
                 dst[...] = out[key]
             return int(out["steps"]), int(out["flag"]), out["trace"], float(out["seconds"])
 
+    def mesh_setup(self, dims, min_corner, spacing, voxel_index, aabb, side, triangles, vertices, contract_off=True):
+        """set_node_inside + set_node_boundary_type (src/waveguide/src/mesh.cpp:75-111) on the OpenCL device:
+        condensed_node[n] as (boundary_type int32, boundary_index uint32) pairs, boundary_index still 0."""
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="wvrefcl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            fin, fout = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
+            np.savez(fin, dims=np.array(dims), min_corner=np.asarray(min_corner, dtype=np.float32), spacing=np.float32(spacing),
+                     voxel_index=np.asarray(voxel_index, dtype=np.uint32), aabb_c0=np.asarray(aabb[0], dtype=np.float32),
+                     aabb_c1=np.asarray(aabb[1], dtype=np.float32), side=side, triangles=np.asarray(triangles, dtype=np.uint32),
+                     vertices=np.asarray(vertices, dtype=np.float32), contract_off=bool(contract_off))
+            self._worker("setup", fin, fout)
+            return np.load(fout)["nodes"].reshape(-1, 2)
+
+    def boundary_coefficient_finder(self, dims, min_corner, spacing, nodes, counts, triangles, vertices, contract_off=True):
+        """boundary_coefficient_finder_{1,2,3}d (src/waveguide/src/boundary_coefficient_finder.cpp:73-124) on the OpenCL
+        device; `nodes` with the FIRST numbering of compute_boundary_index_data, `counts` the three array lengths.
+        Entry 0 of the 1-D array is raced for by every inside node on a real device and means nothing."""
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="wvrefcl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            fin, fout = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
+            np.savez(fin, dims=np.array(dims), min_corner=np.asarray(min_corner, dtype=np.float32), spacing=np.float32(spacing),
+                     nodes=np.ascontiguousarray(nodes), counts=np.array(counts), triangles=np.asarray(triangles, dtype=np.uint32),
+                     vertices=np.asarray(vertices, dtype=np.float32), contract_off=bool(contract_off))
+            self._worker("bcf", fin, fout)
+            out = np.load(fout)
+            return [out["b1"], out["b2"], out["b3"]]
+
     def bench(self, n, steps, tag):
         """Gnode-updates/s of the reference's kernel on an n^3 box (built inside the worker): a dict."""
         import json

@@ -8,6 +8,8 @@ torch nor the engine:
     python oracle/ref_cl_worker.py run   <in.npz> <out.npz>     one waveguide::run from arrays on disk
     python oracle/ref_cl_worker.py bench <n> <steps> <f32|f64>  n^3 box built here, timed; prints one JSON line
     python oracle/ref_cl_worker.py name                          prints the OpenCL GPU device name (or nothing)
+    python oracle/ref_cl_worker.py setup <in.npz> <out.npz>     set_node_inside + set_node_boundary_type (mesh.cpp:75-111)
+    python oracle/ref_cl_worker.py bcf   <in.npz> <out.npz>     the three boundary_coefficient_finder kernels
 """
 import ctypes as C
 import json
@@ -33,6 +35,12 @@ def load():
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64,
                                 C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int),
                                 C.POINTER(C.c_double)]
+    lib.wvrefcl_mesh_setup.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.c_void_p]
+    lib.wvrefcl_boundary_coefficient_finder.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     return lib
 
 
@@ -68,6 +76,37 @@ def main():
                                       int(d["source_node"]), d["signal"], int(d["n_steps"]), d["recv"], bool(d["contract_off"]))
         np.savez(sys.argv[3], steps=done, flag=flag, trace=trace, seconds=secs, previous=prev, current=cur,
                  bd1=bd[0], bd2=bd[1], bd3=bd[2])
+        return
+    if mode == "setup":
+        d = np.load(sys.argv[2])
+        nx, ny, nz = (int(v) for v in d["dims"])
+        nodes = np.zeros(nx * ny * nz * 2, dtype=np.uint32)          # condensed_node[n], zero-filled
+        mc = np.ascontiguousarray(d["min_corner"], dtype=np.float32)
+        vox = np.ascontiguousarray(d["voxel_index"], dtype=np.uint32)
+        a0, a1 = (np.ascontiguousarray(d[k], dtype=np.float32) for k in ("aabb_c0", "aabb_c1"))
+        tri = np.ascontiguousarray(d["triangles"], dtype=np.uint32)
+        ver = np.ascontiguousarray(d["vertices"], dtype=np.float32)
+        err = lib.wvrefcl_mesh_setup(int(d["contract_off"]), nx, ny, nz, float(d["spacing"]), _ptr(mc), _ptr(vox), vox.shape[0],
+                                     _ptr(a0), _ptr(a1), int(d["side"]), _ptr(tri), tri.shape[0], _ptr(ver), ver.shape[0], _ptr(nodes))
+        if err:
+            raise SystemExit("reference set-up on the OpenCL device: " + lib.wvrefcl_last_error().decode())
+        np.savez(sys.argv[3], nodes=nodes)
+        return
+    if mode == "bcf":
+        d = np.load(sys.argv[2])
+        nx, ny, nz = (int(v) for v in d["dims"])
+        mc = np.ascontiguousarray(d["min_corner"], dtype=np.float32)
+        nodes = np.ascontiguousarray(d["nodes"])
+        tri = np.ascontiguousarray(d["triangles"], dtype=np.uint32)
+        ver = np.ascontiguousarray(d["vertices"], dtype=np.float32)
+        n1, n2, n3 = (int(v) for v in d["counts"])
+        o1, o2, o3 = np.zeros(max(n1, 1), np.uint32), np.zeros((max(n2, 1), 2), np.uint32), np.zeros((max(n3, 1), 3), np.uint32)
+        err = lib.wvrefcl_boundary_coefficient_finder(int(d["contract_off"]), nx, ny, nz, float(d["spacing"]), _ptr(mc), _ptr(nodes),
+                                                      _ptr(tri), tri.shape[0], _ptr(ver), ver.shape[0], _ptr(o1), n1, _ptr(o2), n2,
+                                                      _ptr(o3), n3)
+        if err:
+            raise SystemExit("reference boundary coefficient finder on the OpenCL device: " + lib.wvrefcl_last_error().decode())
+        np.savez(sys.argv[3], b1=o1[:n1], b2=o2[:n2], b3=o3[:n3])
         return
     if mode == "bench":
         from wayverb_amd import mesh as M          # pure numpy: no engine, no torch

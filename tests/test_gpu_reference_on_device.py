@@ -74,3 +74,100 @@ def test_engine_against_the_reference_as_its_device_compiler_builds_it(ref_cl, b
         assert np.abs(got[key].astype(np.float64) - want[key].astype(np.float64)).max() / scale <= bound
     scale = np.abs(want["trace"]).max()
     assert np.abs(got["trace"].astype(np.float64) - want["trace"].astype(np.float64)).max() / scale <= bound
+
+
+# ---- the reference's SET-UP programs on this device ---------------------------------------
+# set_node_inside / set_node_boundary_type (mesh_setup_program.cpp) and the three boundary_coefficient_finder
+# kernels, as program text handed to ROCm's OpenCL: dot / cross / normalize / length / distance are now the DEVICE's
+# builtins, not the plain expressions of oracle/ref_shim_builtins.h the host build of that text is linked against.
+
+def _golden_scene(name):
+    from conftest import golden
+    g = golden("setup_" + name)
+    dims = tuple(int(d) for d in g["dims"])
+    return g, dims, (g["aabb"][0], g["aabb"][1])
+
+
+@pytest.mark.parametrize("name", ["box", "L", "sphere"])
+def test_reference_mesh_setup_on_this_device_equals_the_golden_vectors(ref_cl, oracle, name):
+    """The golden set-up vectors (made by the host build of the reference's kernels, tests/golden/make_golden_setup.py)
+    against the same kernels on the MI355X's OpenCL: inside flags and node types bit for bit in the IEEE
+    build; the surfaces per boundary filter too, except where a kernel reads entry 0 of the 1-D array, which every
+    inside node races to write on a real device (popcount(id_inside) == 1: boundary_coefficient_program.cpp)."""
+    g, dims, aabb = _golden_scene(name)
+    v, t, vox, side, spacing = g["vertices"], g["triangles"], g["voxel_index"], int(g["side"]), float(g["spacing"])
+    n = dims[0] * dims[1] * dims[2]
+    nodes = ref_cl.mesh_setup(dims, aabb[0], spacing, vox, aabb, side, t, v, contract_off=True)
+    types = nodes[:, 0].view(np.int32)
+    assert np.array_equal(types, g["boundary_type"]), "%d node types differ" % int((types != g["boundary_type"]).sum())
+    assert np.array_equal((types == 1).astype(np.uint8), np.unpackbits(g["inside_bits"])[:n])
+    # as the reference builds it ("-Werror" only: contraction and the device's own builtin precision)
+    loose = ref_cl.mesh_setup(dims, aabb[0], spacing, vox, aabb, side, t, v, contract_off=False)[:, 0].view(np.int32)
+    assert (loose != g["boundary_type"]).mean() < 1e-3
+    # surfaces per filter
+    mask = (types == 1).reshape(dims[2], dims[1], dims[0])
+    first, counts = oracle.classify(mask)                      # first numbering of compute_boundary_index_data
+    assert counts == tuple(int(c) for c in g["counts"])
+    out = ref_cl.boundary_coefficient_finder(dims, aabb[0], spacing, first, counts, t, v, contract_off=True)
+    want = [g["out1"], g["out2"], g["out3"]]
+    got1, want1 = out[0].reshape(-1), want[0].reshape(-1)
+    other = np.nonzero(got1[1:] != want1[1:])[0] + 1
+    if name != "sphere":
+        assert other.size == 0
+    else:
+        # A tessellated sphere is the worst case for "closest triangle": neighbouring triangles are (nearly) equally
+        # far from a node, and which one wins is decided in the last bit of distance(), a builtin whose evaluation
+        # OpenCL leaves to the device.  Where the device's answer differs from the host build's, the two surfaces
+        # must be equally close to the node to float precision -- a tie, not a different algorithm.
+        assert other.size < 0.05 * got1.size
+        tb = first["boundary_type"]
+        one_d = ((tb & 1) == 0) & (tb != 0) & (np.array([bin(int(x)).count("1") for x in tb]) == 1)
+        node_of_entry = np.full(got1.size, -1, dtype=np.int64)
+        idx = np.nonzero(one_d | (tb == 128))[0]
+        node_of_entry[first["boundary_index"][idx]] = idx
+        tri_v = v[:, :3][t[:, 1:4].astype(np.int64)].astype(np.float64)       # [m, 3, 3]
+
+        def surface_distance(p, surface):
+            best = np.inf
+            for a, b, c in tri_v[t[:, 0] == surface]:
+                best = min(best, float(oracle.point_triangle_dist2(a, b, c, p)))
+            return best ** 0.5
+
+        for k in other[:40]:
+            node = int(node_of_entry[k])
+            assert node >= 0
+            x, y, z = node % dims[0], (node // dims[0]) % dims[1], node // (dims[0] * dims[1])
+            p = np.asarray(aabb[0][:3], dtype=np.float64) + spacing * np.array([x, y, z], dtype=np.float64)
+            d_dev, d_host = surface_distance(p, int(got1[k])), surface_distance(p, int(want1[k]))
+            assert abs(d_dev - d_host) <= 2e-5 * max(d_dev, d_host, spacing), (k, d_dev, d_host)
+    for d in (1, 2):
+        differs = out[d].reshape(want[d].shape) != want[d]
+        explained = (want[d] == want1[0]) | np.isin(want[d], want1[other]) | np.isin(out[d].reshape(want[d].shape), got1[other])
+        assert np.all(explained[differs]), "a 2-D / 3-D filter differs where neither entry 0 nor a tie was involved"
+
+
+def test_reference_mesh_setup_on_this_device_equals_the_engines_chain_on_the_concert_hall(ref_cl, oracle, built_library):
+    """BASELINE configs[4]'s scene: the engine's device-resident set-up chain (wayverb_amd/csrc/{node_inside,
+    mesh_setup,boundary_surfaces}.hip) against the reference's own kernels on the same GPU."""
+    import os
+    from wayverb_amd import simulation as sim
+    from wayverb_amd import wayfile as W
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg, v, t, absorptions = W.read_way(os.path.join(here, "golden", "concert.way"))
+    wg = cfg["waveguide"]["single"]
+    fs = sim.compute_sampling_frequency(wg["cutoff"], wg["usable_portion"])
+    vm = sim.compute_voxels_and_mesh(v, t, absorptions, cfg["receivers"][0]["position"], fs, 340.0)
+    mesh = vm.mesh
+    dims, c0, spacing = mesh.dims, vm.min_corner, float(mesh.spacing)
+    nodes = ref_cl.mesh_setup(dims, c0, spacing, vm.voxel_index, vm.aabb, vm.side, t, v, contract_off=True)
+    types = nodes[:, 0].view(np.int32)
+    differing = int((types != mesh.nodes["boundary_type"]).sum())
+    assert differing == 0, "%d of %d node types differ" % (differing, types.size)
+    mask = (types == 1).reshape(dims[2], dims[1], dims[0])
+    first, counts = oracle.classify(mask)
+    out = ref_cl.boundary_coefficient_finder(dims, c0, spacing, first, counts, t, v, contract_off=True)
+    want = oracle.boundary_coefficient_finder(first, dims, c0, spacing, t, v, counts, entry0_last_writer=True)
+    assert np.array_equal(out[0].reshape(-1)[1:], want[0].reshape(-1)[1:])
+    for d in (1, 2):
+        differs = out[d].reshape(want[d].shape) != want[d]
+        assert np.all(want[d][differs] == want[0].reshape(-1)[0])
