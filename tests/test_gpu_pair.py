@@ -349,3 +349,22 @@ def test_passes_on_a_bigger_sparse_room_equal_single_steps():
     _set_env(WV_PAIR=1)
     got = run_engine(case, "f64")
     _same(got, want)
+
+
+@pytest.mark.parametrize("dims,tag", [((1100, 11, 9), "f64"), ((1300, 14, 12), "f64"), ((2047, 9, 13), "f64"), ((2600, 10, 9), "f64"),
+                                      ((6300, 6, 7), "f64"), ((2300, 12, 10), "f32"), ((5000, 9, 8), "f32")])
+def test_rows_longer_than_one_workgroup(oracle, dims, tag):
+    """Rows of 9 to 50 waves: several workgroups share a row, overlapping by two waves (pair_march_kernel<.., WIDE>;
+    the wave a window runs beyond either end of what it stores contributes its t+1 values and stores nothing).
+    Against the oracle: fields, filter memories, traces -- with receivers on both sides of every seam."""
+    dtype = np.float64 if tag == "f64" else np.float32
+    case = _random_case(dims, seed=dims[0], steps=13, reentrant=False)
+    ci = case["mesh"].compute_index
+    wave_cols = 128 if tag == "f64" else 256
+    seams = [x for k in range(1, dims[0] // wave_cols + 1) for x in (k * wave_cols - 1, k * wave_cols) if 2 <= x < dims[0] - 2]
+    case["recv"] = [ci(x, dims[1] // 2, dims[2] // 2) for x in seams[:48]]
+    want = run_oracle(oracle, case, dtype, threads=4)
+    got = run_engine(case, tag)
+    _same(got, want)
+    _set_env(WV_PAIR=1, WV_PAIR_WIDE=0)          # without the WIDE march such rows fall back to single steps: same bits
+    _same(run_engine(case, tag), want)

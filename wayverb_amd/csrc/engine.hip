@@ -800,7 +800,9 @@ public:
         if (pair_mode_ == 0 || pair_failed_) return false;
         if ((opt_.ghost_lo || opt_.ghost_hi) && (!comm_ || z_end_ - z_begin_ < 4)) return false;
         // (outside nodes a caller wrote to are zeroed by two single full sweeps first: batch_pairs_ready)
-        if (plan_.variant != 2 || pitch_ > wv::kPairMaxWaves * WX || outside_dirty_ > 2) return false;
+        // (rows of more than kPairMaxWaves waves are shared by several workgroups: the WIDE march, up to 50 waves)
+        const int max_waves = env_int("WV_PAIR_WIDE", 1) ? wv::kPairMaxWindows * (wv::kPairMaxWaves - 2) + 2 : wv::kPairMaxWaves;
+        if (plan_.variant != 2 || pitch_ > max_waves * WX || outside_dirty_ > 2) return false;
         if (pair_mode_ < 0) {
             // Measured (profiles/r02/pair_vs_single_small_meshes.txt), fp64, Gnode-updates/s single / two-step:
             // 96^3 55 / 35, 128^3 96 / 72 (launches, not bytes), 160^3 86 / 101, 192^3 115 / 134, 256^3 191 / 205,
@@ -930,6 +932,28 @@ public:
         // march geometry: strips of 4 rows, all planes unless there are too few strips to fill the chip
         constexpr int WX = 64 * (16 / (int)sizeof(Real));
         pair_nw_ = pitch_ / WX;
+        pair_windows_ = 0;
+        if (pair_nw_ > wv::kPairMaxWaves) {
+            // windows of up to kPairMaxWaves waves, one halo wave on every interior side (pair_march_kernel<.., WIDE>)
+            const int row_waves = pair_nw_;
+            int at = 0, widest = 0;
+            while (at < row_waves && pair_windows_ < wv::kPairMaxWindows) {
+                const int lo_halo = at > 0 ? 1 : 0;
+                int end = at + wv::kPairMaxWaves - lo_halo;            // storing [at, end) with no halo above ...
+                if (end < row_waves) end -= 1;                          // ... or one wave less and a halo wave
+                end = std::min(end, row_waves);
+                const int first = at - lo_halo, count = end + (end < row_waves ? 1 : 0) - first;
+                pair_win_[0][pair_windows_] = (uint8_t)first;
+                pair_win_[1][pair_windows_] = (uint8_t)count;
+                pair_win_[2][pair_windows_] = (uint8_t)at;
+                pair_win_[3][pair_windows_] = (uint8_t)end;
+                widest = std::max(widest, count);
+                ++pair_windows_;
+                at = end;
+            }
+            if (at < row_waves) return fail(WV_E_STATE, "row too long for the two-step pass");  // (pair_eligible rules it out)
+            pair_nw_ = widest;  // waves per workgroup
+        }
         pair_strips_ = (ny_ + wv::kPairRows - 1) / wv::kPairRows;
         const int owned = pair_z1_ - pair_z0_;
         // Workgroups the chip holds at once: 256 CUs x (8 wave slots at 2 waves / SIMD) / waves per
@@ -966,7 +990,7 @@ public:
             pair_units_ = nullptr;
         }
         pair_sparse_ok_ = true;
-        if (env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0 || pair_strips_ >= (1 << 16)) return WV_OK;
+        if (env_int("WV_TILE_LISTS", opt_.all_tiles ? 0 : 1) == 0 || pair_strips_ >= (1 << 16) || pair_windows_) return WV_OK;
         // activity per (plane, strip)
         const int64_t n_cells = (int64_t)nz_ * pair_strips_;
         ScopedDevice act_mem;
@@ -1123,7 +1147,19 @@ public:
         // (a variant with the row length as a compile-time constant was worth 6 % until the divide sequence went
         // (div3); with the shorter loop the compiler hoists its address arithmetic into registers it does not have
         // and spills: tools/pair_tune.hip still prices it)
-        hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        if (pair_windows_) {
+            a.windows = pair_windows_;
+            for (int k = 0; k < pair_windows_; ++k) {
+                a.win_first |= (uint64_t)pair_win_[0][k] << (8 * k);
+                a.win_count |= (uint64_t)pair_win_[1][k] << (8 * k);
+                a.win_store_lo |= (uint64_t)pair_win_[2][k] << (8 * k);
+                a.win_store_hi |= (uint64_t)pair_win_[3][k] << (8 * k);
+            }
+            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0, true>), dim3(grid * (unsigned)pair_windows_),
+                               dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        } else {
+            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        }
         if (timed) {
             WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
             ev_used_ += 2;
@@ -1860,6 +1896,8 @@ private:
     bool io_plain_known_ = false, io_plain_ = false;
     bool io_unfaced_known_ = false, io_unfaced_ = false;
     bool pair_list_early_ok_ = false;             // ensure_pair
+    int pair_windows_ = 0;                        // WIDE march: workgroups side by side per row (0: one)
+    uint8_t pair_win_[4][wv::kPairMaxWindows] = {};  // first wave, waves, first storing wave, end of the storing waves
     bool pair_mid_done_ = false, pair_list_done_ = false;  // part A of the pass in flight has served t+1's source / receivers, the list
     int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
     uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position

@@ -34,6 +34,7 @@ namespace wv {
 
 constexpr int kPairRows = 4;      // RY: rows per strip = one row group of the class map
 constexpr int kPairMaxWaves = 8;  // waves side by side: rows of up to 8 * 64 * 16 B
+constexpr int kPairMaxWindows = 8;  // WIDE march: workgroups side by side on longer rows (up to 8 * 6 + 2 waves)
 
 template <typename Real>
 struct PairArgs {
@@ -53,6 +54,13 @@ struct PairArgs {
     // unit_list[list_start[k] + j] = strip | chunk << 16; units without a node to update are not listed
     const uint32_t* unit_list;
     uint32_t list_start[9];
+    // WIDE march only (rows of more than kPairMaxWaves waves): the row is covered by `windows` workgroups side by side.
+    // Window k runs waves [win_first_k, win_first_k + win_count_k) of the row and stores those in
+    // [win_store_lo_k, win_store_hi_k); the one wave it runs beyond either end of that range is there for its
+    // t+1 values only (pair_march_kernel).
+    // (byte k of each word belongs to window k: words, not arrays, so that the kernel reads them with shifts)
+    int windows;
+    uint64_t win_first, win_count, win_store_lo, win_store_hi;
 };
 
 template <typename Real>
@@ -142,7 +150,13 @@ enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 1
 
 // NWC > 0: the row length is a compile-time constant, NWC waves = NWC * 64 * 16 B per row (address
 // arithmetic folds; measured -6 % at 1024 doubles per row); 0: any row length up to kPairMaxWaves waves.
-template <typename Real, int X = 0, int NWC = 0>
+// WIDE: rows longer than one workgroup can hold (kPairMaxWaves waves).  Several workgroups share a row, each a window
+// of up to kPairMaxWaves waves that OVERLAP by two: a window's outermost wave on an interior side is a halo wave --
+// it loads, exchanges edges and computes like any other, but stores nothing.  That is all it takes: with nothing
+// to its outside, the halo wave's t+1 is wrong in its outermost column only (the missing neighbour counts as 0),
+// which reaches no further than its own t+2; its innermost column's t+1 -- what the first storing wave needs --
+// is right.  25 % (8 waves run for 6 stored) more arithmetic and L2 traffic for such rows, the same HBM bytes.
+template <typename Real, int X = 0, int NWC = 0, bool WIDE = false>
 __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const PairArgs<Real> a_in) {
     PairArgs<Real> a = a_in;
     if (NWC > 0) {
@@ -160,7 +174,19 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // XCD k (= blockIdx % 8, observed dispatch: used for locality only) takes a contiguous run of
     // strips, so that the ring rows two neighbouring strips both need meet in that XCD's L2
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    int win = 0;
+    int row_waves = a.nw;  // waves side by side in this workgroup
+    if (WIDE) {  // windows outermost: the workgroups of one window are the grid of a narrow mesh
+        const int per_window = (int)(gridDim.x >> 3) / a.windows;
+        win = j / per_window;
+        j -= win * per_window;
+        row_waves = (int)((a.win_count >> (8 * win)) & 0xFFu);
+        if (wave >= row_waves) return;  // (a finished wave does not hold up the barriers)
+    }
+    const int wave_abs = WIDE ? (int)((a.win_first >> (8 * win)) & 0xFFu) + wave : wave;
+    const bool stores = !WIDE || (wave_abs >= (int)((a.win_store_lo >> (8 * win)) & 0xFFu) && wave_abs < (int)((a.win_store_hi >> (8 * win)) & 0xFFu));
     int strip, chunk;
     if (a.unit_list) {
         const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
@@ -182,9 +208,9 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     t.nz = a.nz;
     t.pitch = a.pitch;
     t.plane = (int64_t)a.pitch * a.ny;
-    t.col = (wave * 64 + lane) * VX;
+    t.col = (wave_abs * 64 + lane) * VX;
 
-    const PairEdges<Real, K> edges{sl, sr, lane, wave, a.nw};
+    const PairEdges<Real, K> edges{sl, sr, lane, wave, row_waves};
     auto load_b = [&](V(&dst)[RY + 4], int z) {
 #pragma unroll
         for (int q = 0; q < RY + 4; ++q) dst[q] = t.load(a.cur, y0 - 2 + q, z);
@@ -263,7 +289,7 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
         const uint32_t keep = code_word | (code_word >> 1);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            if (y0 + r < a.ny) {
+            if (y0 + r < a.ny && stores) {
                 const V v2 = pair_step_row<Real>(t_cur[r + 1], t_cur[r], t_cur[r + 2], t_prev[r + 1], t_next[r + 1],
                                                  b_mid[r + 2], edges.left(set, RY + 2 + r), edges.right(set, RY + 2 + r));
                 V o1 = t_cur[r + 1], o2 = v2;
