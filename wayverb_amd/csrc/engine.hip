@@ -1144,9 +1144,8 @@ public:
         }
         const bool timed = time_this_launch();
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
-        // (a variant with the row length as a compile-time constant was worth 6 % until the divide sequence went
-        // (div3); with the shorter loop the compiler hoists its address arithmetic into registers it does not have
-        // and spills: tools/pair_tune.hip still prices it)
+        // (a variant with the row length as a compile-time constant, NWC, was worth 6 % until the divide sequence went
+        // (div3); at the memory ceiling it runs level with this one: tools/pair_tune.hip still prices it)
         if (pair_windows_) {
             a.windows = pair_windows_;
             for (int k = 0; k < pair_windows_; ++k) {

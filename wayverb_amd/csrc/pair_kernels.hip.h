@@ -149,7 +149,7 @@ struct PairEdges {
 enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 16 };
 
 // NWC > 0: the row length is a compile-time constant, NWC waves = NWC * 64 * 16 B per row (address
-// arithmetic folds; measured -6 % at 1024 doubles per row); 0: any row length up to kPairMaxWaves waves.
+// arithmetic folds; measured -6 % at 1024 doubles per row before div3, nothing since); 0: any row length.
 // WIDE: rows longer than one workgroup can hold (kPairMaxWaves waves).  Several workgroups share a row, each a window
 // of up to kPairMaxWaves waves that OVERLAP by two: a window's outermost wave on an interior side is a halo wave --
 // it loads, exchanges edges and computes like any other, but stores nothing.  That is all it takes: with nothing
@@ -157,13 +157,12 @@ enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 1
 // which reaches no further than its own t+2; its innermost column's t+1 -- what the first storing wave needs --
 // is right.  25 % (8 waves run for 6 stored) more arithmetic and L2 traffic for such rows, the same HBM bytes.
 template <typename Real, int X = 0, int NWC = 0, bool WIDE = false>
-__global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const PairArgs<Real> a_in) {
-    PairArgs<Real> a = a_in;
-    if (NWC > 0) {
-        a.nw = NWC;
-        a.pitch = NWC * 64 * Vec16<Real>::N;
-        a.cls_pitch = a.pitch / 4;
-    }
+__global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const PairArgs<Real> a) {
+    // (The arguments are never written to: a modified copy of the struct is no longer promoted to registers, its
+    // pointers are re-read from scratch and lose their address space -- flat loads, a wait after each, three
+    // times the run time.  That, not register pressure, was what made the NWC variant collapse in mid-round.)
+    const int pitch = NWC > 0 ? NWC * 64 * Vec16<Real>::N : a.pitch;
+    const int cls_pitch = NWC > 0 ? pitch / 4 : a.cls_pitch;
     using V = typename Vec16<Real>::type;
     constexpr int VX = Vec16<Real>::N;
     constexpr int RY = kPairRows;
@@ -177,7 +176,7 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
     int win = 0;
-    int row_waves = a.nw;  // waves side by side in this workgroup
+    int row_waves = NWC > 0 ? NWC : a.nw;  // waves side by side in this workgroup
     if (WIDE) {  // windows outermost: the workgroups of one window are the grid of a narrow mesh
         const int per_window = (int)(gridDim.x >> 3) / a.windows;
         win = j / per_window;
@@ -206,8 +205,8 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     PairTile<Real> t;
     t.ny = a.ny;
     t.nz = a.nz;
-    t.pitch = a.pitch;
-    t.plane = (int64_t)a.pitch * a.ny;
+    t.pitch = pitch;
+    t.plane = (int64_t)pitch * a.ny;
     t.col = (wave_abs * 64 + lane) * VX;
 
     const PairEdges<Real, K> edges{sl, sr, lane, wave, row_waves};
@@ -237,7 +236,7 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     };
     // 2-bit codes of this lane's VX nodes in the RY rows of the strip on plane z: one dword load
     auto codes_of = [&](int z) -> uint32_t {
-        return reinterpret_cast<const uint32_t*>(a.pair_map)[cls_word_index(t.col, y0, z, a.ny, a.cls_pitch)];
+        return reinterpret_cast<const uint32_t*>(a.pair_map)[cls_word_index(t.col, y0, z, a.ny, cls_pitch)];
     };
     auto row_codes = [&](uint32_t word, int r) -> uint32_t {
         const uint32_t byte = (word >> (r * 8)) & 0xFFu;
