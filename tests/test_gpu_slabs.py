@@ -134,7 +134,8 @@ def assert_same(got, want, gmesh):
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 @pytest.mark.parametrize("world,room,dims", [(2, "box", (16, 14, 24)), (3, "box", (40, 36, 25)), (8, "box", (16, 14, 24)),
-                                             (2, "L", (20, 18, 24)), (3, "blob", (24, 22, 26)), (8, "L", (36, 20, 48))])
+                                             (2, "L", (20, 18, 24)), (3, "blob", (24, 22, 26)), (8, "L", (36, 20, 48)),
+                                             (2, "box", (1200, 9, 14))])   # rows of 10 waves: several workgroups per row
 def test_slab_chain_equals_single_domain(built_library, world, room, dims, precision, _step_mode):
     rng = np.random.default_rng(2024 + world)
     gmesh = global_mesh(dims, room, rng)
