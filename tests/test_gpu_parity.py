@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _set_env(**kw):
     for k in ("WV_STREAM_RY", "WV_STREAM_NWX", "WV_STREAM_NWY", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS", "WV_GRAPH",
               "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS", "WV_PAIR", "WV_PAIR_CHUNKS",
-              "WV_PAIR_INNER_FIX", "WV_PAIR_UNIT_PLANES", "WV_PAIR_WIDE"):
+              "WV_PAIR_INNER_FIX", "WV_PAIR_UNIT_PLANES", "WV_PAIR_WIDE", "WV_PAIR_UNIT_WAVES"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)

@@ -1018,25 +1018,61 @@ public:
         // finer chunks than a full mesh would take: skipping works in whole units
         const int zc = std::max(8, std::min(pair_zc_, env_int("WV_PAIR_UNIT_PLANES", 32)));
         const int chunks = (owned + zc - 1) / zc;
-        if (chunks >= (1 << 16)) return WV_OK;
+        if (chunks >= (1 << 9)) return WV_OK;  // (9 bits of a list entry)
+        // Which waves of a row does a unit need?  Those between the first and the last column block that holds anything
+        // but `none` nodes in the unit's rows +- a strip and planes +- 2 (all it reads, produces or hands on): beyond
+        // them every field is zero, which is what a missing neighbour counts as (pair_march_kernel, unit lists).
+        std::vector<uint8_t> raw;
+        pair_unit_waves_ = false;
+        if (env_int("WV_PAIR_UNIT_WAVES", 1) != 0 && pair_nw_ > 1) {
+            ScopedDevice raw_mem;
+            WV_HIP(hipMalloc(&raw_mem.p, (size_t)n_cells));
+            wv::WaveActivityArgs w{};
+            w.cls = cls_;
+            w.raw = static_cast<uint8_t*>(raw_mem.p);
+            w.ny = ny_;
+            w.nz = nz_;
+            w.pitch = pitch_;
+            w.cls_pitch = cls_pitch_;
+            w.strips = pair_strips_;
+            w.nw = pair_nw_;
+            w.wave_cols = 64 * (16 / (int)sizeof(Real));
+            hipLaunchKernelGGL(wv::pair_wave_activity_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream_, w);
+            WV_HIP(hipGetLastError());
+            raw.resize((size_t)n_cells);
+            WV_HIP(hipMemcpyAsync(raw.data(), raw_mem.p, (size_t)n_cells, hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            pair_unit_waves_ = true;
+        }
         std::vector<std::vector<uint32_t>> of_strip((size_t)pair_strips_);
-        uint64_t total = 0;
+        uint64_t total = 0, live_waves = 0;
         for (int sidx = 0; sidx < pair_strips_; ++sidx)
             for (int c = 0; c < chunks; ++c) {
                 bool any = false;
-                for (int z = pair_z0_ + c * zc; z < std::min(pair_z0_ + (c + 1) * zc, pair_z1_) && !any; ++z)
-                    any = active[(size_t)z * pair_strips_ + sidx] != 0;
-                if (any) {
-                    of_strip[(size_t)sidx].push_back((uint32_t)sidx | ((uint32_t)c << 16));
-                    ++total;
+                const int zb = pair_z0_ + c * zc, ze = std::min(pair_z0_ + (c + 1) * zc, pair_z1_);
+                for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * pair_strips_ + sidx] != 0;
+                if (!any) continue;
+                uint32_t entry = (uint32_t)sidx | ((uint32_t)c << 16), span = (uint32_t)pair_nw_;
+                if (pair_unit_waves_) {
+                    uint32_t bits = 0;
+                    for (int z = std::max(0, zb - 2); z < std::min(nz_, ze + 2); ++z)
+                        for (int ss = std::max(0, sidx - 1); ss <= std::min(pair_strips_ - 1, sidx + 1); ++ss)
+                            bits |= raw[(size_t)z * pair_strips_ + ss];
+                    const uint32_t lo = (uint32_t)__builtin_ctz(bits | (1u << 31)), hi = 32u - (uint32_t)__builtin_clz(bits | 1u);
+                    span = hi > lo ? hi - lo : 1u;
+                    entry |= (std::min(lo, (uint32_t)pair_nw_ - 1) << 25) | ((span - 1) << 28);
                 }
+                of_strip[(size_t)sidx].push_back(entry);
+                live_waves += span;
+                ++total;
             }
         if (!total) return WV_OK;
         // Is the march still the better deal here?  It visits whole rows (strip x chunk units) and moves 32 B per
         // node for two steps; the sweep visits 128 x 16 x 1 tiles and moves 48 B.  Sphere inscribed in 768^3: 80 % of
         // the units against 55 % of the tiles are live, and the two run level (1.59-1.73 vs 1.63 ms per step).
         (void)build_tile_lists(z_begin_, z_end_);
-        const double unit_frac = (double)total / ((double)pair_strips_ * chunks);
+        // (with the live waves of a unit only, what the march moves goes by waves, not by units)
+        const double unit_frac = (double)live_waves / ((double)pair_strips_ * chunks * pair_nw_);
         pair_sparse_ok_ = unit_frac * 32.0 * 1.15 < tile_active_frac_ * 48.0;
         std::vector<uint32_t> list;
         list.reserve((size_t)total);
@@ -1146,7 +1182,9 @@ public:
         if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
         // (a variant with the row length as a compile-time constant, NWC, was worth 6 % until the divide sequence went
         // (div3); at the memory ceiling it runs level with this one: tools/pair_tune.hip still prices it)
-        if (pair_windows_) {
+        if (pair_units_ && pair_unit_waves_) {  // rooms narrower than their rows: the live waves of each unit only
+            hipLaunchKernelGGL((wv::pair_march_kernel<Real, 0, 0, true>), dim3(grid), dim3(64u * (unsigned)pair_nw_), 0, stream_, a);
+        } else if (pair_windows_) {
             a.windows = pair_windows_;
             for (int k = 0; k < pair_windows_; ++k) {
                 a.win_first |= (uint64_t)pair_win_[0][k] << (8 * k);
@@ -1895,6 +1933,7 @@ private:
     bool io_plain_known_ = false, io_plain_ = false;
     bool io_unfaced_known_ = false, io_unfaced_ = false;
     bool pair_list_early_ok_ = false;             // ensure_pair
+    bool pair_unit_waves_ = false;                // the unit list carries each unit's live waves (build_pair_units)
     int pair_windows_ = 0;                        // WIDE march: workgroups side by side per row (0: one)
     uint8_t pair_win_[4][wv::kPairMaxWindows] = {};  // first wave, waves, first storing wave, end of the storing waves
     bool pair_mid_done_ = false, pair_list_done_ = false;  // part A of the pass in flight has served t+1's source / receivers, the list

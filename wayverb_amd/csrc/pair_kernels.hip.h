@@ -51,7 +51,8 @@ struct PairArgs {
     int zc, chunks;      // planes per workgroup, workgroups along z
     int strips, strips_per_xcd;
     // optional work list (rooms that leave much of the mesh outside): workgroup j of XCD k takes unit
-    // unit_list[list_start[k] + j] = strip | chunk << 16; units without a node to update are not listed
+    // unit_list[list_start[k] + j] = strip | chunk << 16 (| first wave << 25 | waves - 1 << 28 for the march that runs
+    // only the live waves of a unit); units without a node to update are not listed
     const uint32_t* unit_list;
     uint32_t list_start[9];
     // WIDE march only (rows of more than kPairMaxWaves waves): the row is covered by `windows` workgroups side by side.
@@ -175,28 +176,39 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     // strips, so that the ring rows two neighbouring strips both need meet in that XCD's L2
     const int xcd = blockIdx.x & 7;
     int j = blockIdx.x >> 3;
-    int win = 0;
-    int row_waves = NWC > 0 ? NWC : a.nw;  // waves side by side in this workgroup
-    if (WIDE) {  // windows outermost: the workgroups of one window are the grid of a narrow mesh
+    int row_waves = NWC > 0 ? NWC : a.nw;  // waves side by side in this workgroup ...
+    int wave_first = 0;                      // ... the first of them counted along the row ...
+    int store_lo = 0, store_hi = 1 << 30;    // ... and which waves of the row this workgroup stores
+    if (WIDE && a.windows) {  // windows outermost: the workgroups of one window are the grid of a narrow mesh
         const int per_window = (int)(gridDim.x >> 3) / a.windows;
-        win = j / per_window;
+        const int win = j / per_window;
         j -= win * per_window;
         row_waves = (int)((a.win_count >> (8 * win)) & 0xFFu);
-        if (wave >= row_waves) return;  // (a finished wave does not hold up the barriers)
+        wave_first = (int)((a.win_first >> (8 * win)) & 0xFFu);
+        store_lo = (int)((a.win_store_lo >> (8 * win)) & 0xFFu);
+        store_hi = (int)((a.win_store_hi >> (8 * win)) & 0xFFu);
     }
-    const int wave_abs = WIDE ? (int)((a.win_first >> (8 * win)) & 0xFFu) + wave : wave;
-    const bool stores = !WIDE || (wave_abs >= (int)((a.win_store_lo >> (8 * win)) & 0xFFu) && wave_abs < (int)((a.win_store_hi >> (8 * win)) & 0xFFu));
     int strip, chunk;
     if (a.unit_list) {
         const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
         if ((uint32_t)j >= count) return;  // whole workgroup
         const uint32_t u = a.unit_list[first + (uint32_t)j];
         strip = (int)(u & 0xFFFFu);
-        chunk = (int)(u >> 16);
+        chunk = (int)((u >> 16) & 0x1FFu);
+        if (WIDE && !a.windows) {
+            // rooms narrower than their rows: only the waves of the row between the first and the last one that holds
+            // anything but `none` nodes for this unit (its rows +- a strip, its planes +- 2) -- what lies beyond is
+            // zeros in every field, which is what a missing neighbour counts as
+            wave_first = (int)((u >> 25) & 7u);
+            row_waves = (int)(u >> 28) + 1;
+        }
     } else {
         strip = xcd * a.strips_per_xcd + j % a.strips_per_xcd;
         chunk = j / a.strips_per_xcd;
     }
+    if (WIDE && wave >= row_waves) return;  // (a finished wave does not hold up the barriers)
+    const int wave_abs = wave_first + wave;
+    const bool stores = !WIDE || (wave_abs >= store_lo && wave_abs < store_hi);
     if (strip >= a.strips || chunk >= a.chunks) return;  // whole workgroup
     const int y0 = strip * RY;
     const int zb = a.z_begin + chunk * a.zc, ze = min(zb + a.zc, a.z_end);
@@ -491,6 +503,29 @@ __global__ void __launch_bounds__(256) pair_map_kernel(const PairMapArgs a) {
         out |= code << (2 * k);
     }
     a.pair_map[cls_byte_index(xb * 4, y, z, a.ny, a.cls_pitch)] = (uint8_t)out;
+}
+
+// ---- which waves of which strips hold anything but `none` nodes at which plane (rooms narrower than their rows) ---
+struct WaveActivityArgs {
+    const uint8_t* cls;
+    uint8_t* raw;  // [nz][strips]: bit w = wave w's column block (128 doubles / 256 floats) of the strip's rows at plane z
+    int ny, nz, pitch, cls_pitch, strips, nw, wave_cols;
+};
+
+__global__ void __launch_bounds__(256) pair_wave_activity_kernel(const WaveActivityArgs a) {
+    const int64_t n = (int64_t)a.nz * a.strips;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int s = (int)(t % a.strips), z = (int)(t / a.strips);
+    uint32_t bits = 0;
+    for (int y = s * kPairRows; y < min((s + 1) * kPairRows, a.ny); ++y)
+        for (int w = 0; w < a.nw; ++w) {
+            uint32_t any = 0;
+            for (int x = w * a.wave_cols; x < min((w + 1) * a.wave_cols, a.pitch); x += 4)
+                any |= a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)];  // any class but CLS_NONE
+            if (any) bits |= 1u << w;
+        }
+    a.raw[t] = (uint8_t)bits;
 }
 
 }  // namespace wv
