@@ -21,7 +21,8 @@ MODES = {"default": {}, "passes": dict(WV_PAIR=1), "passes-list-only": dict(WV_P
 def random_case(seed):
     rng = np.random.default_rng(seed)
     room = ["box", "L", "sphere", "blob"][seed % 4]
-    nx = int(rng.choice([rng.integers(7, 40), rng.integers(120, 140), rng.integers(250, 300)], p=[0.6, 0.25, 0.15]))
+    nx = int(rng.choice([rng.integers(7, 40), rng.integers(120, 140), rng.integers(250, 300), rng.integers(1030, 1320)],
+                        p=[0.55, 0.22, 0.15, 0.08]))   # rows of one wave .. of more than one workgroup
     ny, nz = int(rng.integers(7, 34)), int(rng.integers(7, 30))
     if room != "box":
         nx, ny, nz = max(nx, 14), max(ny, 14), max(nz, 14)
