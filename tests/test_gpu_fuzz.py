@@ -79,3 +79,53 @@ def test_random_case_equals_the_oracle_in_every_stepping_mode(oracle, built_libr
         assert got["previous"].tobytes() == want["previous"].tobytes(), where
         for d, (a, b) in enumerate(zip(got["bd"], want["bd"])):
             assert a.tobytes() == b.tobytes(), where + " D=%d" % (d + 1)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_speckled_rooms_in_degenerate_meshes(oracle, built_library, seed):
+    """Meshes one to three nodes thick along an axis, rows of a few nodes or of several thousand (more than a two-step
+    pass can take: 51 waves and up), rooms that are random speckle (every node type incl. re-entrant, isolated
+    inside nodes, inside nodes on the mesh's outer faces so that neighbours fall off the grid): whatever stepping the
+    engine picks or is forced into must give the oracle's bits, flags included."""
+    rng = np.random.default_rng(9000 + seed)
+    pick = lambda: int(rng.choice([1, 2, 3, 4, 5, 7, 9, 17, 33]))
+    nx = int(rng.choice([pick(), int(rng.integers(100, 300)), int(rng.integers(6500, 7000))], p=[0.6, 0.3, 0.1]))
+    ny, nz = pick(), pick()
+    mask = rng.random((nz, ny, nx)) < rng.choice([0.15, 0.5, 0.85])
+    nodes, counts = E.classify_nodes(mask)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2), np.array([M.flat_coefficients(0.4)], dtype=M.coefficients_dtype)])
+    mesh = M.mesh_from_nodes((nx, ny, nz), nodes, counts, coeffs, surface_of_port=[0, 1, 2, 0, 1, 2])
+    t = mesh.nodes["boundary_type"]
+    live = np.nonzero(t != 0)[0]
+    steps = int(rng.integers(2, 12))
+    if live.size == 0:
+        src, kind = 0, E.SOURCE_NONE
+    else:
+        src, kind = int(rng.choice(live)), int(rng.choice([E.SOURCE_HARD, E.SOURCE_SOFT]))
+    prev = np.where(t != 0, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    cur = np.where(t != 0, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
+    case = dict(mesh=mesh, steps=steps, source_kind=kind, source_node=src, signal=rng.uniform(-0.2, 0.2, steps),
+                recv=[int(rng.integers(0, mesh.num_nodes)) for _ in range(3)], init=(prev, cur))
+    dtype, tag = (np.float64, "f64") if seed % 2 else (np.float32, "f32")
+    prev_o, cur_o = prev.astype(dtype), cur.astype(dtype)
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    want_steps, want_flag, want_trace = oracle.run(prev_o, cur_o, mesh, bd, kind, src, case["signal"], steps, case["recv"], threads=2)
+    for env in ({}, dict(WV_PAIR=1), dict(WV_PAIR=0)):
+        _set_env(**env)
+        eng = E.Engine(mesh, precision=tag)
+        try:
+            eng.write_field(prev.astype(dtype), E.BUF_PREVIOUS)
+            eng.write_field(cur.astype(dtype), E.BUF_CURRENT)
+            if kind != E.SOURCE_NONE:
+                eng.set_source(kind, src, case["signal"])
+            eng.set_receivers(case["recv"])
+            done, flag = eng.run_steps(steps)
+            assert (done, flag) == (want_steps, want_flag), (env, (nx, ny, nz))
+            assert np.array_equal(eng.fetch_receivers(0, done).astype(dtype).view(np.uint8), want_trace[:done].view(np.uint8)), env
+            if flag == 0:
+                final_cur, final_prev = (cur_o, prev_o) if done % 2 == 0 else (prev_o, cur_o)
+                assert eng.read_field(E.BUF_CURRENT).tobytes() == final_cur.tobytes(), (env, (nx, ny, nz))
+                assert eng.read_field(E.BUF_PREVIOUS).tobytes() == final_prev.tobytes(), (env, (nx, ny, nz))
+        finally:
+            eng.close()
+            _set_env()
