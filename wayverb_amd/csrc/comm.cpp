@@ -205,7 +205,7 @@ void SlabComm::set_fields(void* const* fields, int n_fields, size_t plane_bytes,
 SlabComm::~SlabComm() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (comm_) (void)rccl().comm_destroy(comm_);
-    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_, pushed_hi_, step_done_})
+    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_, pushed_hi_, step_done_, reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
     // a local chain is torn down as a whole (wv_comm_destroy on every engine); unlink anyway
@@ -321,10 +321,18 @@ bool SlabComm::or_flags(hipStream_t stream, int* flags, int n, std::string* err)
         return false;
     }
     if (!spread_ && !hip_ok(hipMalloc((void**)&spread_, kMaxFlags * sizeof(uint64_t)), "hipMalloc", err)) return false;
+    for (hipEvent_t* e : {&reduce_in_, &reduce_out_})
+        if (!*e && !hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(flag_spread_kernel, dim3(grid), dim3(256), 0, stream, (const int*)flags, spread_, n);
-    if (!nccl_ok(rccl().all_reduce(spread_, spread_, (size_t)n, kNcclUint64, kNcclSum, comm_, stream), "ncclAllReduce", err))
+    // The all-reduce goes to the halo stream, behind the exchanges: every RCCL call of this communicator is then issued
+    // to ONE stream, in the same order on every rank -- no two of its operations can be in flight side by side.
+    if (!hip_ok(hipEventRecord(reduce_in_, stream), "hipEventRecord", err)) return false;
+    if (!hip_ok(hipStreamWaitEvent(stream_, reduce_in_, 0), "hipStreamWaitEvent", err)) return false;
+    if (!nccl_ok(rccl().all_reduce(spread_, spread_, (size_t)n, kNcclUint64, kNcclSum, comm_, stream_), "ncclAllReduce", err))
         return false;
+    if (!hip_ok(hipEventRecord(reduce_out_, stream_), "hipEventRecord", err)) return false;
+    if (!hip_ok(hipStreamWaitEvent(stream, reduce_out_, 0), "hipStreamWaitEvent", err)) return false;
     hipLaunchKernelGGL(flag_gather_kernel, dim3(grid), dim3(256), 0, stream, (const uint64_t*)spread_, flags, n);
     return hip_ok(hipGetLastError(), "flag OR kernels", err);
 }

@@ -69,6 +69,7 @@ private:
     hipStream_t stream_ = nullptr;
     hipEvent_t faces_ready_ = nullptr;
     hipEvent_t ghosts_ready_ = nullptr;
+    hipEvent_t reduce_in_ = nullptr, reduce_out_ = nullptr;  // or_flags: compute stream -> halo stream -> compute stream
     bool pending_ = false;
     // field geometry
     void* fields_[4] = {nullptr, nullptr, nullptr, nullptr};
