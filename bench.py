@@ -48,6 +48,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-small", action="store_true", help="skip the 256^3 side measurement")
+    p.add_argument("--tuning", default="", help="wv_tuning fields for measurement runs, e.g. pair=0,stream_ry=2 "
+                                                "(default: none -- the product's own choices)")
     p.add_argument("--no-reference-on-gpu", action="store_true",
                    help="skip running the reference's OpenCL kernel on this GPU (oracle/_ref/libwvref_cl.so)")
     return p.parse_args()
@@ -130,6 +132,8 @@ def main():
     from wayverb_amd import mesh as M
     from wayverb_amd.slab import SlabLayout, box_slab_mesh
 
+    if args.tuning:
+        E.default_tuning.update({k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

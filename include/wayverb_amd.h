@@ -95,6 +95,24 @@ typedef struct wv_mesh {
 enum { WV_PRECISION_F32 = 0, /* pressures as the reference stores them (cl_float) */
        WV_PRECISION_F64 = 1  /* pressures in double: BASELINE.json north star */ };
 
+typedef struct wv_tuning {
+    int32_t pair;             /* two-step passes (pair_kernels.hip.h): -1 the engine decides by mesh size, 1 / 0 force on / off */
+    int32_t pair_chunks;      /* workgroups along z of the march; 0 = fill whole rounds of workgroup slots */
+    int32_t pair_inner_fix;   /* 1: 1-D boundary entries finish the inside node they face; 0: all such nodes go to the fix-up list */
+    int32_t pair_wide;        /* 1: rows of more than 8 waves are shared by several workgroups; 0: such meshes keep single steps */
+    int32_t pair_unit_waves;  /* sparse rooms: 1 = a listed unit runs only the live waves of its row */
+    int32_t pair_unit_planes; /* sparse rooms: planes per work-list unit of the march (default 32) */
+    int32_t tile_lists;       /* 1: rooms that leave much of the mesh outside visit live tiles / units only (see all_tiles) */
+    int32_t fuse_pre_post;    /* 1: the next step's source / receiver work rides in this step's boundary launch where legal */
+    int32_t graph;            /* 1: batches of single steps on small meshes are replayed as a hipGraph */
+    int32_t boundary_lds;     /* 1: boundary workgroups stage the coefficient sets in LDS (<= 256 sets) */
+    int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
+    int32_t boundary_merge;   /* 1: one boundary launch per two-step pass does both time levels of the wall nodes it can */
+    int32_t slab_march_faces; /* 1: on a slab the march also produces the face planes' first level (fewer launches per pass) */
+    int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
+    int32_t reserved_[7];
+} wv_tuning;
+
 typedef struct wv_options {
     int32_t struct_size; /* = sizeof(wv_options); lets the struct grow */
     int32_t precision;   /* WV_PRECISION_* */
@@ -115,6 +133,11 @@ typedef struct wv_options {
      * the boundary index and coefficient arrays are host arrays either way */
     int32_t nodes_on_device;
     int32_t reserved_[7];
+    /* HOW the engine does its work -- never what it computes: every setting gives bit-identical results
+     * (tests/test_gpu_parity.py, test_gpu_pair.py run the golden cases under each).  wv_default_options
+     * fills in the product's choices; the fields exist for measurement and for the tests.  The library
+     * reads no environment variables (built with -DWV_DEBUG_ENV, WV_<FIELD> overrides a field: tools only). */
+    wv_tuning tuning;
 } wv_options;
 
 typedef struct wv_engine wv_engine;

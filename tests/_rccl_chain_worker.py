@@ -3,7 +3,7 @@ torch -- which carries the real RCCL -- must not be loaded).  K slabs of one mes
 communicator from wv_comm_init (the RCCL path of csrc/comm.cpp, NOT the in-process transport), each stepped by
 its own thread with wv_run, all on one GPU; the result is compared with the single-domain engine bit for bit.
 
-    python tests/_rccl_chain_worker.py <world> <room> <nx> <ny> <nz> <f32|f64> <steps> <seed> [<bad_step>]
+    python tests/_rccl_chain_worker.py <world> <room> <nx> <ny> <nz> <f32|f64> <steps> <seed> [<bad_step>] [--pair=0|1]
 """
 import sys
 import threading
@@ -27,6 +27,9 @@ def global_mesh(dims, room, rng):
 
 
 def main():
+    for a in [a for a in sys.argv if a.startswith("--pair=")]:   # stepping mode of every engine (wv_tuning::pair)
+        E.default_tuning["pair"] = int(a.split("=")[1])
+        sys.argv.remove(a)
     world, room = int(sys.argv[1]), sys.argv[2]
     dims = tuple(int(a) for a in sys.argv[3:6])
     precision, steps, seed = sys.argv[6], int(sys.argv[7]), int(sys.argv[8])

@@ -8,6 +8,14 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def set_tuning(**fields):
+    """Tuning (wv_tuning fields of include/wayverb_amd.h, plus stream_variant) of every engine created from now on, through
+    wayverb_amd.engine.default_tuning -> wv_options::tuning.  No arguments: the library's defaults."""
+    from wayverb_amd import engine as E
+    E.default_tuning.clear()
+    E.default_tuning.update({k: int(v) for k, v in fields.items()})
+
+
 def initial_fields(case, dtype):
     n = case["mesh"].num_nodes
     if case["init"] is None:

@@ -32,7 +32,24 @@ def test_struct_layouts_match_the_reference_contract():
     from wayverb_amd import engine as E
     assert M.condensed_node_dtype.itemsize == 8 and M.boundary_data_dtype.itemsize == 56
     assert M.coefficients_dtype.itemsize == 112
-    assert ctypes.sizeof(E.WvOptions) == 64
+    # the ctypes mirrors against the header itself, as a C compiler lays it out
+    import subprocess
+    import tempfile
+    fields = ["struct_size", "precision", "device", "ghost_lo", "ghost_hi", "flag_interval", "stream_variant", "all_tiles",
+              "nodes_on_device", "tuning"]
+    tfields = list(E.TUNING_FIELDS)
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"wayverb_amd.h\"\nint main(void){printf(\"%zu %zu\", sizeof(wv_options), sizeof(wv_tuning));" + \
+        "".join('printf(" %%zu", offsetof(wv_options, %s));' % f for f in fields) + \
+        "".join('printf(" %%zu", offsetof(wv_tuning, %s));' % f for f in tfields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, "layout.c"), os.path.join(tmp, "layout")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [ctypes.sizeof(E.WvOptions), ctypes.sizeof(E.WvTuning)] + [getattr(E.WvOptions, f).offset for f in fields] + \
+        [getattr(E.WvTuning, f).offset for f in tfields]
+    assert got == want
+    assert ctypes.sizeof(E.WvOptions) == 64 + ctypes.sizeof(E.WvTuning)  # (64: the struct before wv_tuning was appended)
 
 
 def test_box_mesh_counts_match_survey_table():
@@ -86,3 +103,21 @@ def test_box_boundary_row_arithmetic(built_library):
     for z in range(nz + 1):
         _, counts = E.make_box_nodes(nx, ny, nz, z_begin=0, z_count=max(z, 1), number_from=0, number_to=z)
         assert [box_boundary_rows_below(nx, ny, nz, z, d) for d in (1, 2, 3)] == list(counts)
+
+
+def test_the_library_reads_no_environment_variables():
+    """Product behaviour is steered through wv_options / wv_tuning only; the one getenv in the sources sits in the
+    WV_DEBUG_ENV block of engine.hip, which the product build does not define."""
+    csrc = os.path.join(ROOT, "wayverb_amd", "csrc")
+    hits = []
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            text = open(os.path.join(csrc, name)).read()
+            hits += [(name, m.start()) for m in re.finditer(r"\bgetenv\b", text)]
+    assert [h[0] for h in hits] == ["engine.hip"]
+    text = open(os.path.join(csrc, "engine.hip")).read()
+    block = text[text.index("#ifdef WV_DEBUG_ENV"):]
+    block = block[:block.index("#endif")]
+    assert hits[0][1] > text.index("#ifdef WV_DEBUG_ENV") and "getenv" in block
+    from wayverb_amd import build as B
+    assert not any("WV_DEBUG_ENV" in f for f in B.FLAGS)

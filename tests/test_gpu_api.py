@@ -144,11 +144,11 @@ def test_rccl_halo_exchange_loopback_on_one_gpu(built_library, pad_x, pair, monk
     """The RCCL path on real hardware, as far as one GPU allows: a communicator of one rank whose
     slab is its own neighbour on both sides (periodic in z).  Exercises dlopen'd RCCL, grouped
     ncclSend/ncclRecv on the halo stream, the faces-first / interior-overlapped step and its
-    events, and the all-reduce that ORs the flag words / agrees on the stepping mode.  With WV_PAIR=1
+    events, and the all-reduce that ORs the flag words / agrees on the stepping mode.  With pair = 1
     the slab takes two-step passes: two grouped exchanges per pass (t+1 faces, then t+2 faces).
     Reference: a second engine without a communicator (single steps) whose ghost planes are filled
     by host copies before every step."""
-    monkeypatch.setenv("WV_PAIR", str(pair))
+    monkeypatch.setitem(E.default_tuning, "pair", pair)
     nx, ny, nz = 160, 24, 12                     # planes 0 and nz-1 are ghosts
     rng = np.random.default_rng(8)
     nodes, counts = E.make_box_nodes(nx, ny, 64, z_begin=20, z_count=nz, number_from=21, number_to=20 + nz - 1)

@@ -8,7 +8,7 @@ knows about the outside nodes, source / receiver work already served, the pair m
 import numpy as np
 import pytest
 
-from test_gpu_parity import _set_env
+from helpers import set_tuning
 from wayverb_amd import engine as E
 from wayverb_amd import mesh as M
 
@@ -69,8 +69,8 @@ def random_room(rng, seed):
 @pytest.mark.parametrize("mode", ["default", "passes", "single-steps", "graph-replay"])
 @pytest.mark.parametrize("seed", range(40))
 def test_random_api_sequence(oracle, built_library, seed, mode):
-    _set_env(**{"default": {}, "passes": dict(WV_PAIR=1), "single-steps": dict(WV_PAIR=0),
-                "graph-replay": dict(WV_PAIR=0, WV_GRAPH=1)}[mode])
+    set_tuning(**{"default": {}, "passes": dict(pair=1), "single-steps": dict(pair=0),
+                "graph-replay": dict(pair=0, graph=1)}[mode])
     rng = np.random.default_rng(4000 + seed)
     mesh = random_room(rng, seed)
     tag, dtype = ("f64", np.float64) if seed % 4 else ("f32", np.float32)

@@ -93,7 +93,7 @@ def test_concert_hall_in_z_slabs(hall, world, pair, monkeypatch):
     """The hall cut into z-slabs and stepped as a chain == the single-domain run (fields, wall filter
     memories, receiver traces), source and receiver wherever they fall."""
     from test_gpu_slabs import assert_same, single_domain, slab_chain
-    monkeypatch.setenv("WV_PAIR", str(pair))
+    monkeypatch.setitem(E.default_tuning, "pair", pair)
     vm = hall["vm"]
     mesh = vm.mesh
     steps = 90

@@ -7,15 +7,14 @@ the oracle's bit for bit: receiver traces, both fields, every filter memory word
 import numpy as np
 import pytest
 
-from helpers import run_engine, run_oracle
-from test_gpu_parity import _set_env
+from helpers import run_engine, run_oracle, set_tuning
 from wayverb_amd import engine as E
 from wayverb_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"default": {}, "passes": dict(WV_PAIR=1), "passes-list-only": dict(WV_PAIR=1, WV_PAIR_INNER_FIX=0),
-         "passes-own-launches": dict(WV_PAIR=1, WV_FUSE_PRE_POST=0), "single-steps": dict(WV_PAIR=0)}
+MODES = {"default": {}, "passes": dict(pair=1), "passes-list-only": dict(pair=1, pair_inner_fix=0),
+         "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0)}
 
 
 def random_case(seed):
@@ -65,13 +64,13 @@ def test_random_case_equals_the_oracle_in_every_stepping_mode(oracle, built_libr
     want = run_oracle(oracle, case, dtype, threads=2)
     assert want["flag"] == 0, (room, dims)
     modes = dict(MODES)
-    modes["passes-in-z-chunks"] = dict(WV_PAIR=1, WV_PAIR_CHUNKS=2 + seed % 3)
+    modes["passes-in-z-chunks"] = dict(pair=1, pair_chunks=2 + seed % 3)
     for mode, env in modes.items():
-        _set_env(**env)
+        set_tuning(**env)
         try:
             got = run_engine(case, tag, all_tiles=bool(seed % 2))
         finally:
-            _set_env()
+            set_tuning()
         where = "%s %s %s seed %d" % (mode, room, dims, seed)
         assert got["steps"] == want["steps"], where
         assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8)), where
@@ -110,8 +109,8 @@ def test_speckled_rooms_in_degenerate_meshes(oracle, built_library, seed):
     prev_o, cur_o = prev.astype(dtype), cur.astype(dtype)
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
     want_steps, want_flag, want_trace = oracle.run(prev_o, cur_o, mesh, bd, kind, src, case["signal"], steps, case["recv"], threads=2)
-    for env in ({}, dict(WV_PAIR=1), dict(WV_PAIR=0)):
-        _set_env(**env)
+    for env in ({}, dict(pair=1), dict(pair=0)):
+        set_tuning(**env)
         eng = E.Engine(mesh, precision=tag)
         try:
             eng.write_field(prev.astype(dtype), E.BUF_PREVIOUS)
@@ -128,4 +127,4 @@ def test_speckled_rooms_in_degenerate_meshes(oracle, built_library, seed):
                 assert eng.read_field(E.BUF_PREVIOUS).tobytes() == final_prev.tobytes(), (env, (nx, ny, nz))
         finally:
             eng.close()
-            _set_env()
+            set_tuning()

@@ -1,5 +1,5 @@
 """Two time steps per pass over the fields (csrc/pair_kernels.hip.h, engine.hip::enqueue_pair): forced
-on with WV_PAIR=1 on meshes of every shape, it must reproduce exactly what single steps produce --
+on with pair=1 on meshes of every shape, it must reproduce exactly what single steps produce --
 golden vectors of the reference kernel, the oracle, fields AND wall filter memories AND receiver
 traces AND the step at which an error flag stops the run.  (By default the engine takes the pair
 path only on meshes big enough to be bound by HBM bytes; tests/test_gpu_parity.py's full-size
@@ -11,8 +11,8 @@ import pytest
 
 import cases
 from conftest import golden
-from helpers import run_engine, run_oracle
-from test_gpu_parity import RAGGED, _random_case, _set_env, assert_same_run
+from helpers import run_engine, run_oracle, set_tuning
+from test_gpu_parity import RAGGED, _random_case, assert_same_run
 from wayverb_amd import engine as E
 from wayverb_amd import mesh as M
 
@@ -21,9 +21,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _pair_on(built_library):
-    _set_env(WV_PAIR=1)
+    set_tuning(pair=1)
     yield
-    _set_env()
+    set_tuning()
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))
@@ -38,7 +38,7 @@ def test_pair_path_matches_golden(name, tag):
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 def test_pair_path_z_chunks_match_golden(chunks, tag):
     """Several workgroups along z: each recomputes the two t+1 planes below its first plane."""
-    _set_env(WV_PAIR=1, WV_PAIR_CHUNKS=chunks)
+    set_tuning(pair=1, pair_chunks=chunks)
     r = run_engine(cases.CASES["random"](), tag)
     assert_same_run(r, golden("random"), tag, "random")
 
@@ -119,7 +119,7 @@ def test_pair_path_stops_at_the_failing_step(bad_step):
     sig[0] = 1.0
     sig[bad_step] = np.inf
     for pair in (1, 0):
-        _set_env(WV_PAIR=pair)
+        set_tuning(pair=pair)
         eng = E.Engine(mesh, precision="f32")
         eng.set_source(E.SOURCE_HARD, mesh.compute_index(6, 6, 6), sig)
         eng.set_receivers([mesh.compute_index(7, 6, 6)])
@@ -193,9 +193,9 @@ def test_two_step_passes_equal_single_steps_on_bigger_meshes(dims, tag):
     different walls, two-step passes (several z-chunks, 3-8 waves per row, pad columns) vs single steps --
     fields, filter memories and traces bit for bit."""
     case = _random_case(dims, seed=sum(dims), steps=41)
-    _set_env(WV_PAIR=0)
+    set_tuning(pair=0)
     want = run_engine(case, tag)
-    _set_env(WV_PAIR=1)
+    set_tuning(pair=1)
     got = run_engine(case, tag)
     assert got["steps"] == want["steps"] == 41
     assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
@@ -217,8 +217,8 @@ def _same(got, want):
 @pytest.mark.parametrize("inner_fix", [1, 0], ids=["entries-finish-faced-nodes", "list-only"])
 def test_faced_nodes_with_and_without_the_entries_finishing_them(oracle, inner_fix):
     """In the second boundary launch of a pass a 1-D entry also finishes the inside node it faces
-    (boundary_kernel<.., FIX>); WV_PAIR_INNER_FIX=0 leaves all of them to the fix-up list.  Same bits."""
-    _set_env(WV_PAIR=1, WV_PAIR_INNER_FIX=inner_fix)
+    (boundary_kernel<.., FIX>); pair_inner_fix=0 leaves all of them to the fix-up list.  Same bits."""
+    set_tuning(pair=1, pair_inner_fix=inner_fix)
     case = _random_case((40, 22, 18), 31, steps=25)
     want = run_oracle(oracle, case, np.float64, threads=2)
     got = run_engine(case, "f64")
@@ -296,9 +296,9 @@ def test_configs1_at_full_length_two_step_passes_equal_single_steps():
     sig[0] = 1.0
     case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_HARD, source_node=ci(n // 2, n // 2, n // 2), signal=sig,
                 recv=[ci(n // 2 + 3, n // 2, n // 2), ci(2, 2, 2), ci(n - 3, 40, 70)], init=None)
-    _set_env(WV_PAIR=0)
+    set_tuning(pair=0)
     want = run_engine(case, "f64")
-    _set_env()                                           # the engine's own choice
+    set_tuning()                                           # the engine's own choice
     got = run_engine(case, "f64")
     assert np.isfinite(want["trace"]).all() and np.abs(want["trace"][-100:]).max() > 0
     _same(got, want)
@@ -324,7 +324,7 @@ def test_rooms_much_narrower_than_their_rows(oracle, room, dims, tag, dtype):
     case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_SOFT, source_node=int(inside[len(inside) // 2]),
                 signal=rng.uniform(-0.1, 0.1, steps), recv=[int(inside[5]), int(inside[-7]), 3], init=(prev, cur))
     want = run_oracle(oracle, case, dtype, threads=4)
-    _set_env(WV_PAIR=1)
+    set_tuning(pair=1)
     got = run_engine(case, tag)
     _same(got, want)
 
@@ -344,9 +344,9 @@ def test_passes_on_a_bigger_sparse_room_equal_single_steps():
     cur = np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0)
     case = dict(mesh=mesh, steps=41, source_kind=E.SOURCE_HARD, source_node=int(inside[len(inside) // 2]),
                 signal=rng.uniform(-0.1, 0.1, 41), recv=[int(inside[9]), int(inside[-3])], init=(prev, cur))
-    _set_env(WV_PAIR=0)
+    set_tuning(pair=0)
     want = run_engine(case, "f64")
-    _set_env(WV_PAIR=1)
+    set_tuning(pair=1)
     got = run_engine(case, "f64")
     _same(got, want)
 
@@ -366,5 +366,5 @@ def test_rows_longer_than_one_workgroup(oracle, dims, tag):
     want = run_oracle(oracle, case, dtype, threads=4)
     got = run_engine(case, tag)
     _same(got, want)
-    _set_env(WV_PAIR=1, WV_PAIR_WIDE=0)          # without the WIDE march such rows fall back to single steps: same bits
+    set_tuning(pair=1, pair_wide=0)          # without the WIDE march such rows fall back to single steps: same bits
     _same(run_engine(case, tag), want)

@@ -10,26 +10,17 @@ import pytest
 
 import cases
 from conftest import golden
-from helpers import box_boundary_rows_below, run_engine, run_oracle, sha
+from helpers import box_boundary_rows_below, run_engine, run_oracle, set_tuning, sha
 from wayverb_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
 
 
-def _set_env(**kw):
-    for k in ("WV_STREAM_RY", "WV_STREAM_NWX", "WV_STREAM_NWY", "WV_STREAM_VARIANT", "WV_STREAM_ZCHUNKS", "WV_GRAPH",
-              "WV_FUSE_PRE_POST", "WV_BOUNDARY_LDS", "WV_BOUNDARY_ORDER", "WV_TILE_LISTS", "WV_PAIR", "WV_PAIR_CHUNKS",
-              "WV_PAIR_INNER_FIX", "WV_PAIR_UNIT_PLANES", "WV_PAIR_WIDE", "WV_PAIR_UNIT_WAVES"):
-        os.environ.pop(k, None)
-    for k, v in kw.items():
-        os.environ[k] = str(v)
-
-
 @pytest.fixture(autouse=True)
 def _clean_env(built_library):
-    _set_env()
+    set_tuning()
     yield
-    _set_env()
+    set_tuning()
 
 
 def assert_same_run(r, g, tag, name):
@@ -51,30 +42,30 @@ def test_engine_matches_golden(name, tag):
     assert_same_run(r, golden(name), tag, name)
 
 
-VARIANTS = [dict(WV_STREAM_VARIANT=1)] + \
-    [dict(WV_STREAM_VARIANT=v, WV_STREAM_RY=ry, WV_STREAM_NWX=nwx, WV_STREAM_NWY=nwy, WV_STREAM_ZCHUNKS=knob)
+VARIANTS = [dict(stream_variant=1)] + \
+    [dict(stream_variant=v, stream_ry=ry, stream_nwx=nwx, stream_nwy=nwy, stream_zchunks=knob)
      for v in (0, 2, 3)
      for ry, nwx, nwy, knob in ((2, 1, 1, 1), (2, 1, 4, 3), (4, 2, 2, 5), (4, 1, 4, 0), (2, 8, 1, 2), (4, 4, 2, 28),
                                 (2, 4, 1, 8), (4, 1, 1, 16))]
 
 
-@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "-".join("%s%s" % (k[10:], v) for k, v in e.items()))
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "-".join("%s%s" % (k.replace("stream_", ""), v) for k, v in e.items()))
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 def test_every_stream_variant_matches_golden(env, tag):
-    _set_env(**env)
+    set_tuning(**env)
     r = run_engine(cases.CASES["random"](), tag)
     assert_same_run(r, golden("random"), tag, "random")
 
 
-@pytest.mark.parametrize("env", [dict(WV_GRAPH=1), dict(WV_FUSE_PRE_POST=0), dict(WV_BOUNDARY_LDS=0),
-                                 dict(WV_BOUNDARY_ORDER=0), dict(WV_GRAPH=1, WV_FUSE_PRE_POST=0)],
+@pytest.mark.parametrize("env", [dict(graph=1), dict(fuse_pre_post=0), dict(boundary_lds=0),
+                                 dict(boundary_order=0), dict(graph=1, fuse_pre_post=0)],
                          ids=lambda e: "-".join("%s%s" % (k[3:], v) for k, v in e.items()))
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 def test_engine_switches_do_not_change_results(env, tag):
     """Replaying a captured batch of steps as a hipGraph, the pre/post work riding in the boundary
     launch, LDS-staged coefficients, brick-ordered boundary entries: each switched the other way
     still reproduces the golden run bit for bit."""
-    _set_env(**env)
+    set_tuning(**env)
     for name in ("random", "impulse_flat"):
         r = run_engine(cases.CASES[name](), tag)
         assert_same_run(r, golden(name), tag, name)
@@ -308,7 +299,7 @@ def test_config2_1024cubed_long_run_two_step_passes_equal_single_steps(built_lib
     planes = [1, 2, 3, 255, 256, 510, 511, 512, 513, 700, 767, 768, 1020, 1021, 1022, 64]
     runs = {}
     for pair in (0, -1):
-        _set_env(**({"WV_PAIR": 0} if pair == 0 else {}))
+        set_tuning(**({"pair": 0} if pair == 0 else {}))
         mesh = box_slab_mesh(n, n, n, _Window((n, n, n), 0, n), coefficients=M.bench_materials())
         eng = E.Engine(mesh, precision="f64")
         mesh.nodes = None

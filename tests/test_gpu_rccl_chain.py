@@ -28,10 +28,8 @@ def run_worker(mock_dir, *args, pair=None, timeout=300):
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env["WV_NO_TORCH_PRELOAD"] = "1"   # torch would bring the real librccl (same soname) into the process
-    env.pop("WV_PAIR", None)
-    if pair is not None:
-        env["WV_PAIR"] = str(pair)
-    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py")] + [str(a) for a in args],
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py")] + [str(a) for a in args] +
+                         (["--pair=%d" % pair] if pair is not None else []),
                          capture_output=True, text=True, env=env, timeout=timeout)
     last = (out.stdout.strip().splitlines() or [""])[-1]
     assert out.returncode == 0 and last.startswith("OK"), (out.stdout[-1500:], out.stderr[-1500:])

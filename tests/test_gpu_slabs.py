@@ -17,20 +17,17 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["single-steps", "two-step-passes"])
 def _step_mode(request):
     """Every test of this file runs twice: with the engine's default choice (single steps on meshes this
-    small) and with two-step passes forced on (WV_PAIR=1), where a slab exchanges its face planes
+    small) and with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
     twice per pass -- t+1, then t+2 (engine.hip::enqueue_pair_a / _b).  Slabs with fewer than four
     planes cannot take two-step passes, and then the whole chain falls back together."""
-    import os
-    old = os.environ.get("WV_PAIR")
+    old = dict(E.default_tuning)
     if request.param == "two-step-passes":
-        os.environ["WV_PAIR"] = "1"
+        E.default_tuning["pair"] = 1
     else:
-        os.environ.pop("WV_PAIR", None)
+        E.default_tuning.pop("pair", None)
     yield request.param
-    if old is None:
-        os.environ.pop("WV_PAIR", None)
-    else:
-        os.environ["WV_PAIR"] = old
+    E.default_tuning.clear()
+    E.default_tuning.update(old)
 
 
 def materials(rng):

@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["default", "two-step-passes"])
 def _step_mode(request, monkeypatch):
-    """Everything here also runs with two-step passes forced on (WV_PAIR=1): their spare fields and the work
+    """Everything here also runs with two-step passes forced on (wv_tuning::pair = 1): their spare fields and the work
     lists of march units rely on outside nodes holding zeros exactly as the sweep's tile lists do."""
+    from wayverb_amd import engine as E
     if request.param == "two-step-passes":
-        monkeypatch.setenv("WV_PAIR", "1")
+        monkeypatch.setitem(E.default_tuning, "pair", 1)
     else:
-        monkeypatch.delenv("WV_PAIR", raising=False)
+        monkeypatch.delitem(E.default_tuning, "pair", raising=False)
     return request.param
 
 

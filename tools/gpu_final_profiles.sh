@@ -40,7 +40,7 @@ python bench.py --precision f32 --no-cpu-baseline --no-small > gpurun_out/$R/ben
 python bench.py --nx 256 --ny 256 --nz 256 --no-cpu-baseline --no-small --steps 10000 --warmup 500 > gpurun_out/$R/bench_256cubed_10k_steps.json 2>/dev/null; tail -1 gpurun_out/$R/bench_256cubed_10k_steps.json | cut -c1-200
 python bench.py --nx 1000 --ny 1000 --nz 1000 --no-cpu-baseline --no-small > gpurun_out/$R/bench_1000cubed.json 2>/dev/null
 
-WV_PAIR=0 python bench.py --no-cpu-baseline --no-small --no-reference-on-gpu > gpurun_out/$R/bench_n1_single_steps_only.json 2>/dev/null; tail -1 gpurun_out/$R/bench_n1_single_steps_only.json | cut -c1-200
-for n in 128 160 256 384 512 768; do for p in 0 1; do echo "n=$n WV_PAIR=$p: $(WV_PAIR=$p python bench.py --nx $n --ny $n --nz $n --no-cpu-baseline --no-small --no-reference-on-gpu --steps 400 --warmup 40 2>/dev/null | cut -c1-140)"; done; done > gpurun_out/$R/pair_vs_single_by_size.txt
+python bench.py --tuning pair=0 --no-cpu-baseline --no-small --no-reference-on-gpu > gpurun_out/$R/bench_n1_single_steps_only.json 2>/dev/null; tail -1 gpurun_out/$R/bench_n1_single_steps_only.json | cut -c1-200
+for n in 128 160 256 384 512 768; do for p in 0 1; do echo "n=$n WV_PAIR=$p: $(python bench.py --tuning pair=$p --nx $n --ny $n --nz $n --no-cpu-baseline --no-small --no-reference-on-gpu --steps 400 --warmup 40 2>/dev/null | cut -c1-140)"; done; done > gpurun_out/$R/pair_vs_single_by_size.txt
 tools/pair_tune 1024 6 > gpurun_out/$R/pair_tune.txt 2>&1
 ls gpurun_out/$R

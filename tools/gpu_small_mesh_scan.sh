@@ -15,11 +15,11 @@ PY
 }
 {
 for n in 64 96 128 160 192 224 256 288 320 352; do for p in 0 1; do
-  echo "n=$n WV_PAIR=$p: $(WV_PAIR=$p $B --nx $n --ny $n --nz $n --steps 3000 --warmup 100 | val)"; done; done
-for c in 8 16 32; do echo "n=256 WV_PAIR=1 WV_PAIR_CHUNKS=$c: $(WV_PAIR=1 WV_PAIR_CHUNKS=$c $B --nx 256 --ny 256 --nz 256 --steps 3000 --warmup 100 | val)"; done
+  echo "n=$n WV_PAIR=$p: $($B --tuning pair=$p --nx $n --ny $n --nz $n --steps 3000 --warmup 100 | val)"; done; done
+for c in 8 16 32; do echo "n=256 WV_PAIR=1 WV_PAIR_CHUNKS=$c: $($B --tuning pair=1,pair_chunks=$c --nx 256 --ny 256 --nz 256 --steps 3000 --warmup 100 | val)"; done
 for p in 1 0; do
 echo "256^3 kernels WV_PAIR=$p"
-WV_PAIR=$p rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -o s -- $B --nx 256 --ny 256 --nz 256 --steps 600 --warmup 20 > $O/tr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -o s -- $B --tuning pair=$p --nx 256 --ny 256 --nz 256 --steps 600 --warmup 20 > $O/tr.log 2>&1
 kstat $O/tr/s_kernel_stats.csv; rm -rf $O/tr
 done
 } > $O/mid.txt 2>&1

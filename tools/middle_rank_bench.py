@@ -35,8 +35,7 @@ def main():
     src = (nz // 2) * n * n + (n // 2) * n + n // 2
     out = {}
     for mode in ("single steps", "two-step passes"):
-        os.environ["WV_PAIR"] = "0" if mode == "single steps" else "1"
-        eng = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True)
+        eng = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True, tuning=dict(pair=0 if mode == "single steps" else 1))
         eng.comm_init(E.Engine.comm_unique_id(), 0, 1)
         eng.set_source(E.SOURCE_HARD, src, sig)
         assert eng.run_steps(20) == (20, 0)

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-step wall time on small box meshes (launch-bound regime), kernel timing off so that the
-graph replay path (WV_GRAPH=1) is eligible."""
+graph replay path (wv_tuning::graph; here from WV_GRAPH=1 in the environment, through engine.tuning_from_env) is eligible."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wayverb_amd import engine as E, mesh as M
+E.default_tuning.update(E.tuning_from_env())
 for n in (32, 64, 128, 256):
     mesh = M.box_mesh(n, n, n, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
     eng = E.Engine(mesh, precision="f64")

@@ -1,0 +1,208 @@
+// engine.hip.h -- `Engine<Real>`: one `waveguide::run` worth of device state and the host logic that steps it
+// (src/waveguide/include/waveguide/waveguide.h:36-126 is what it replaces).  Real = float (the reference's cl_float
+// fields) or double (BASELINE.json's fp64 engine).
+//
+// The member functions are defined in:
+//   engine_setup.hip.h   wv_create: buffers, class map, boundary entry lists and their processing order, sweep plan,
+//                        work lists for rooms that leave much of the mesh outside; release
+//   engine_single.hip.h  one time step per pass: sweep + boundary launches, source / receiver launch, the slab form
+//                        (faces first, exchange, interior), hipGraph replay for small meshes
+//   engine_pair.hip.h    two time steps per pass: eligibility, pair map + fix-up lists, march geometry, parts A / B
+//   engine_batch.hip.h   wv_step / wv_run: batches of steps, flag words, kernel timing
+//   engine_io.hip.h      everything a caller reads or writes: values, fields, planes, filter memories, source,
+//                        receivers
+//   engine_slab.hip.h    z-slab chains: communicators, the in-process group (wv_comm_init_local / wv_run_group)
+// There is no CPU path: without a HIP device every entry point fails.
+#pragma once
+#include "engine_base.h"
+
+#include "boundary_kernels.hip.h"
+#include "pair_kernels.hip.h"
+#include "stream_kernels.hip.h"
+
+namespace wv {
+
+template <typename Real>
+class Engine final : public wv_engine {
+public:
+    ~Engine() override { release(); }
+    // ---- engine_setup.hip.h
+    int init(const wv_mesh& m, const wv_options& opt) override;
+    int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) override;
+    int build_plane_order();
+    void plan_stream();
+    // ---- engine_single.hip.h
+    template <int RY, int NWX, int NWY>
+    void launch_shape(const wv::StreamArgs<Real>& a, unsigned grid);
+    template <int RY>
+    void launch_ry(const wv::StreamArgs<Real>& a, unsigned grid);
+    // ---- engine_setup.hip.h
+    int build_tile_lists(int z0, int z1);
+    // ---- engine_single.hip.h
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr);
+    wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const;
+    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false);
+    wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
+    int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
+    // ---- engine_pair.hip.h
+    bool pair_eligible();
+    int ensure_pair();
+    int build_pair_units(int owned);
+    static void parallel_sort(std::vector<uint64_t>& v);
+    int enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live, bool fuse_mid);
+    int launch_fixup(uint32_t first, uint32_t n, const Real* t1, const Real* cur, Real* out2, int* flag2);
+    int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
+    int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
+    int batch_pairs_ready(int* singles_first) override;
+    // ---- engine_batch.hip.h
+    bool time_this_launch();
+    int drain_timing();
+    int step(int32_t* flag) override;
+    int swap() override;
+    // ---- engine_single.hip.h
+    int replay_batch(uint64_t batch, bool source_live, bool can_fuse);
+    // ---- engine_batch.hip.h
+    uint64_t plan_batch(uint64_t remaining) override;
+    int enqueue_batch_step(uint64_t i, uint64_t batch, int next_kind) override;
+    int collect_batch(uint64_t batch) override;
+    const int* batch_flags() const override { return flags_host_; }
+    int commit_batch(uint64_t batch, const int* flags, uint64_t* good_out, int32_t* flag_out) override;
+    int run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) override;
+    // ---- engine_io.hip.h
+    int set_source(int kind, uint64_t node, const double* signal, uint64_t n) override;
+    int set_receivers(const uint64_t* nodes, uint32_t n) override;
+    bool io_nodes_plain();
+    bool io_nodes(std::vector<uint64_t>* stored);
+    bool io_nodes_unfaced();
+    int fetch_receivers(uint64_t first, uint64_t n, double* dst) override;
+    Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[prv_]; }
+    hipError_t class_of(uint64_t x, uint64_t row, uint32_t* cls);
+    uint64_t stored_index(uint64_t node) const;
+    int read_value(int buffer_id, uint64_t index, double* v) override;
+    int write_value(int buffer_id, uint64_t index, double v) override;
+    template <typename Other>
+    int copy_field(Real* stored, void* host, bool to_device, int z0, int planes);
+    int read_field(int buffer_id, void* dst, int elem_size) override { return read_planes(buffer_id, 0, nz_, dst, elem_size); }
+    int write_field(int buffer_id, const void* src, int elem_size) override {
+        return write_planes(buffer_id, 0, nz_, src, elem_size);
+    }
+    int read_planes(int buffer_id, int z0, int planes, void* dst, int elem_size) override;
+    int write_planes(int buffer_id, int z0, int planes, const void* src, int elem_size) override;
+    int boundary_data(int dim, wv_boundary_data* host, bool to_device) override;
+    int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) override;
+    int device_buffer(int buffer_id, void** p) override;
+    // ---- engine_batch.hip.h
+    int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) override;
+    int synchronize() override;
+    // ---- engine_slab.hip.h
+    int comm_init(const void* id, int rank, int nranks) override;
+    int comm_init_local(int rank, int nranks) override;
+    int adopt_comm(std::unique_ptr<wv::SlabComm> c);
+    wv::SlabComm* comm() override { return comm_.get(); }
+    uint64_t field_pitch() const override { return (uint64_t)pitch_; }
+    int comm_destroy() override;
+
+private:
+    void release();  // engine_setup.hip.h
+    // rooms that leave much of the mesh outside: visit live tiles / units only (wv_options::all_tiles, wv_tuning::tile_lists)
+    bool use_work_lists() const { return !opt_.all_tiles && opt_.tuning.tile_lists != 0; }
+
+    wv_options opt_{};
+    int nx_ = 0, ny_ = 0, nz_ = 0, z_begin_ = 0, z_end_ = 0, device_ = -1;
+    uint64_t n_nodes_ = 0, stored_nodes_ = 0, field_bytes_ = 0;
+    int pitch_ = 0;
+    Real* field_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cur_ = 1, prv_ = 0, spare_[2] = {2, 3};  // which field_ holds which role
+    uint8_t* cls_ = nullptr;
+    int cls_pitch_ = 0;
+    uint32_t n1_ = 0, n2_ = 0, n3_ = 0, n_entries_ = 0, n_slots_ = 0, n_coeffs_ = 0;
+    uint32_t* bnode_ = nullptr;
+    uint64_t* tile_list_ = nullptr;   // sweep work list (build_tile_lists), null = arithmetic mapping
+    uint32_t list_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t list_longest_ = 0;
+    bool lists_built_ = false;
+    int lists_z0_ = 0, lists_z1_ = 0;  // plane range the lists were built for
+    struct GraphKey {
+        uint64_t batch;
+        int cur;
+        bool source_live, can_fuse;
+        uint32_t n_recv;
+        uint64_t source_node;
+        int source_kind;
+        uint64_t signal_ptr, recv_ptr;
+        bool lists;
+        bool operator==(const GraphKey& o) const {
+            return batch == o.batch && cur == o.cur && source_live == o.source_live && can_fuse == o.can_fuse &&
+                   n_recv == o.n_recv && source_node == o.source_node && source_kind == o.source_kind &&
+                   signal_ptr == o.signal_ptr && recv_ptr == o.recv_ptr && lists == o.lists;
+        }
+    };
+    hipGraphExec_t graph_exec_ = nullptr;
+    GraphKey graph_key_{};
+    uint64_t* signal_base_dev_ = nullptr;
+    bool graph_capturing_ = false;
+    uint64_t graph_max_nodes_ = 64ull << 20;
+    bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
+    // two-step passes
+    int pair_inner_ok_ = -1;  // boundary entries finish the inside nodes they face (ensure_pair): -1 not checked yet
+    uint64_t pair_min_nodes_ = 4ull << 20;      // stored nodes: between 128^3 (single steps win) and 160^3 (passes win)
+    bool pair_failed_ = false;
+    uint8_t* pair_map_ = nullptr;
+    uint32_t* pair_list_ = nullptr;
+    uint32_t* pair_counter_ = nullptr;
+    uint32_t* pair_units_ = nullptr;               // march work list (build_pair_units), null = every unit
+    uint32_t pair_unit_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t pair_units_longest_ = 0;
+    bool pair_sparse_ok_ = true;                   // sparse room: the march's live units cost less than the sweep's live tiles
+    double tile_active_frac_ = 1.0;
+    uint32_t pair_list_n_ = 0, pair_face_n_ = 0;  // fix-up nodes of the marched planes / of a slab's face planes
+    int pair_z0_ = 0, pair_z1_ = 0;                // planes the march produces
+    uint64_t pair_source_ = 0;
+    int pair_nw_ = 1, pair_strips_ = 0, pair_zc_ = 0, pair_chunks_ = 1;
+    uint64_t timed_steps_ = 0;
+    bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
+    bool io_plain_known_ = false, io_plain_ = false;
+    bool io_unfaced_known_ = false, io_unfaced_ = false;
+    bool pair_list_early_ok_ = false;             // ensure_pair
+    bool pair_unit_waves_ = false;                // the unit list carries each unit's live waves (build_pair_units)
+    int pair_windows_ = 0;                        // WIDE march: workgroups side by side per row (0: one)
+    uint8_t pair_win_[4][wv::kPairMaxWindows] = {};  // first wave, waves, first storing wave, end of the storing waves
+    bool pair_mid_done_ = false, pair_list_done_ = false;  // part A of the pass in flight has served t+1's source / receivers, the list
+    int outside_dirty_ = 0;           // steps until the outside nodes are known to be 0 in both fields again
+    uint32_t* ref_to_pos_ = nullptr;  // [n_entries] caller's (class offset + boundary_index) -> processing position
+    uint8_t* btype_ = nullptr;
+    double* fmem_ = nullptr;
+    uint32_t* cidx_ = nullptr;
+    // boundary entries by plane (build_plane_order; slab path only)
+    uint32_t* zorder_ = nullptr;
+    std::vector<uint32_t> plane_start_;
+    int* status_ = nullptr;
+    int* static_flag_dev_ = nullptr;
+    int static_flag_ = 0;
+    double* coeffs_ = nullptr;
+    int* flags_ = nullptr;
+    int* flags_host_ = nullptr;
+    void* scratch_ = nullptr;
+    Real courant_ = 0, courant_sq_ = 0;
+    hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
+    StreamPlan plan_;
+    int tune_variant_ = -1, tune_ry_ = 0, tune_nwx_ = 0, tune_nwy_ = 0, tune_zchunks_ = 0;
+    std::vector<hipEvent_t> events_;
+    unsigned timing_launches_ = 0;
+    int ev_used_ = 0;
+    double time_ms_ = 0;
+    uint64_t time_n_ = 0;
+    // source / receivers
+    int source_kind_ = WV_SOURCE_NONE;
+    uint64_t source_node_ = 0, signal_len_ = 0, signal_pos_ = 0;
+    double* signal_ = nullptr;
+    uint64_t* recv_nodes_ = nullptr;
+    Real* recv_out_ = nullptr;
+    uint32_t n_recv_ = 0;
+    uint64_t recv_first_step_ = 0;
+    std::vector<Real> recv_stage_;
+    std::vector<double> recv_log_;
+    std::unique_ptr<wv::SlabComm> comm_;
+};
+
+}  // namespace wv

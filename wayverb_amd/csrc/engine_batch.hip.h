@@ -1,0 +1,211 @@
+// engine_batch.hip.h -- wv_step / wv_swap / wv_run: batches of steps, the flag protocol of waveguide.h:82-119, kernel timing.
+//
+// Part of the engine behind the C ABI of include/wayverb_amd.h (engine.hip is the translation unit; see engine.hip.h for
+// the class and the map of which file holds what).
+#pragma once
+#include "engine.hip.h"
+
+namespace wv {
+
+// Kernel timing (wv_enable_kernel_timing): a pair of events around the dominant kernel.  The two records cost
+// about 11 us of stream time (measured at 256^3: 6 % of a pass; the launches without them follow each other
+// within a microsecond), so below 512^3 only every eighth launch is timed.
+template <typename Real>
+bool Engine<Real>::time_this_launch() {
+    if (!timing || ev_used_ + 2 > (int)events_.size()) return false;
+    const unsigned stride = stored_nodes_ < (128ull << 20) ? 8u : 1u;
+    return (timing_launches_++ % stride) == 0;
+}
+
+template <typename Real>
+int Engine<Real>::drain_timing() {
+    for (int i = 0; i + 1 < ev_used_; i += 2) {
+        float ms = 0;
+        WV_HIP(hipEventElapsedTime(&ms, events_[i], events_[i + 1]));
+        time_ms_ += ms;
+        ++time_n_;
+    }
+    ev_used_ = 0;
+    return WV_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+template <typename Real>
+int Engine<Real>::step(int32_t* flag) {
+    DeviceGuard guard(device_);
+    pre_post_done_ = false;  // (a batch that failed while being enqueued may have left it set)
+    int rc = enqueue_step(0, false, 0, false);
+    if (rc) return rc;
+    WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    WV_HIP(hipStreamSynchronize(stream_));
+    if ((rc = drain_timing())) return rc;
+    if (flag) *flag = flags_host_[0];
+    return WV_OK;
+}
+
+template <typename Real>
+int Engine<Real>::swap() {
+    std::swap(cur_, prv_);
+    ++steps_done;
+    // a step driven from outside (wv_step / wv_swap) records no receiver samples: its row of the log is NaN,
+    // so that wv_fetch_receivers keeps addressing rows by step
+    if (n_recv_) recv_log_.insert(recv_log_.end(), n_recv_, std::numeric_limits<double>::quiet_NaN());
+    return WV_OK;
+}
+
+// ---- a batch of steps: plan / enqueue / collect / commit ---------------------------------------
+// How many of `remaining` steps the next batch may take (0: the source signal is exhausted, which
+// ends the run -- hard_source.h:18-20 returns false).
+template <typename Real>
+uint64_t Engine<Real>::plan_batch(uint64_t remaining) {
+    DeviceGuard guard(device_);
+    const uint64_t interval = opt_.flag_interval > 0 ? (uint64_t)opt_.flag_interval : (uint64_t)kRing;
+    uint64_t batch = std::min<uint64_t>(std::min<uint64_t>(interval, kRing), remaining);
+    if (source_kind_ != WV_SOURCE_NONE) {
+        const uint64_t left = signal_len_ - std::min(signal_len_, signal_pos_);
+        batch = std::min(batch, left);
+    }
+    batch_can_fuse_ = !comm_ && io_nodes_plain() && opt_.tuning.fuse_pre_post != 0;
+    batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
+    // nothing rides across batches: whatever a batch that failed half-way left behind does not count
+    pre_post_done_ = pair_mid_done_ = pair_list_done_ = false;
+    return batch;
+}
+
+// `next_kind`: what step i + 1 of the batch starts (its source / receiver work may ride in this step's
+// boundary launch)
+template <typename Real>
+int Engine<Real>::enqueue_batch_step(uint64_t i, uint64_t batch, int next_kind) {
+    DeviceGuard guard(device_);
+    const int rc = enqueue_step((int)i, true, signal_pos_ + i, batch_source_live_,
+                                batch_can_fuse_ && i + 1 < batch ? next_kind : 0);
+    if (rc) return rc;
+    std::swap(cur_, prv_);
+    return WV_OK;
+}
+
+// Flag words and receiver rows of the batch to the host.  On an RCCL slab chain the flag words are
+// OR-ed over the ranks first, so that every rank sees the same first failing step and none is left
+// waiting in a receive (waveguide.h:100-119 stops the one and only device; here all of them stop).
+template <typename Real>
+int Engine<Real>::collect_batch(uint64_t batch) {
+    DeviceGuard guard(device_);
+    std::string cerr;
+    if (comm_ && !comm_->or_flags(stream_, flags_, (int)batch, &cerr)) return fail(WV_E_COMM, cerr);
+    WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (n_recv_) {
+        recv_stage_.resize((size_t)batch * n_recv_);
+        WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real), hipMemcpyDeviceToHost,
+                              stream_));
+    }
+    WV_HIP(hipStreamSynchronize(stream_));
+    return drain_timing();
+}
+
+// `flags[batch]`: this engine's flag words, or their OR over a group of slabs.
+template <typename Real>
+int Engine<Real>::commit_batch(uint64_t batch, const int* flags, uint64_t* good_out, int32_t* flag_out) {
+    uint64_t good = batch;
+    int32_t flag = 0;
+    for (uint64_t i = 0; i < batch; ++i) {
+        if (flags[i]) {
+            good = i;
+            flag = flags[i];
+            break;
+        }
+    }
+    if (n_recv_)
+        for (size_t i = 0; i < (size_t)good * n_recv_; ++i) recv_log_.push_back((double)recv_stage_[i]);
+    steps_done += good;
+    signal_pos_ += good;
+    // fields have advanced past a failing step: like the reference after its throw, the state is
+    // no longer meaningful; keep the buffer roles consistent with `good` swaps
+    if (flag && good < batch && ((batch - good) & 1)) std::swap(cur_, prv_);
+    *good_out = good;
+    *flag_out = flag;
+    return WV_OK;
+}
+
+template <typename Real>
+int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
+    DeviceGuard guard(device_);
+    if (comm_ && comm_->is_local() && comm_->nranks() > 1)
+        return fail(WV_E_STATE, "slabs joined by wv_comm_init_local are stepped together: use wv_run_group");
+    uint64_t completed = 0;
+    int32_t flag = 0;
+    while (completed < n_steps && flag == 0) {
+        const uint64_t batch = plan_batch(n_steps - completed);
+        if (batch == 0) break;
+        // Small meshes are bound by launches, not bytes: a full batch of steps is captured once
+        // into a hipGraph and replayed (the only thing that differs between batches, the
+        // position in the source signal, comes from a device scalar).  Even batch lengths only,
+        // so that the two fields are back in their roles after every replay.
+        const bool use_graph = opt_.tuning.graph != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
+                               stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
+        if (use_graph) {
+            int rc = replay_batch(batch, batch_source_live_, batch_can_fuse_);
+            if (rc) return rc;
+        } else {
+            // big meshes: two steps per pass over the fields wherever a batch has two left
+            int singles_first = -1;
+            int rc = batch_pairs_ready(&singles_first);
+            if (rc) return rc;
+            if (comm_ && !comm_->is_local()) {
+                // every rank of the chain has to take the same path: one flag word, OR-ed over the
+                // ranks -- bit 3 "some rank cannot", bits 0-1 the largest number of single steps any
+                // rank needs first (thermometer code: OR = max)
+                int word = singles_first < 0 ? 8 : (singles_first >= 2 ? 3 : singles_first);
+                std::string cerr;
+                WV_HIP(hipMemcpyAsync(flags_ + kRing, &word, sizeof(int), hipMemcpyHostToDevice, stream_));
+                if (!comm_->or_flags(stream_, flags_ + kRing, 1, &cerr)) return fail(WV_E_COMM, cerr);
+                WV_HIP(hipMemcpyAsync(&word, flags_ + kRing, sizeof(int), hipMemcpyDeviceToHost, stream_));
+                WV_HIP(hipStreamSynchronize(stream_));
+                singles_first = (word & 8) ? -1 : ((word & 2) ? 2 : (word & 1));
+            }
+            const bool pairs = singles_first >= 0;
+            auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+            auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
+            for (uint64_t i = 0; i < batch;) {
+                if (pair_at(i)) {
+                    if ((rc = enqueue_batch_pair(i, 0, 0))) return rc;
+                    if ((rc = enqueue_batch_pair(i, 1, kind_at(i + 2)))) return rc;
+                    i += 2;
+                } else {
+                    if ((rc = enqueue_batch_step(i, batch, kind_at(i + 1)))) return rc;
+                    i += 1;
+                }
+            }
+        }
+        int rc = collect_batch(batch);
+        if (rc) return rc;
+        uint64_t good = 0;
+        if ((rc = commit_batch(batch, flags_host_, &good, &flag))) return rc;
+        completed += good;
+    }
+    if (done) *done = completed;
+    if (flag_out) *flag_out = flag;
+    return WV_OK;
+}
+
+template <typename Real>
+int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) {
+    DeviceGuard guard(device_);
+    if (mean_ms) *mean_ms = time_n_ ? time_ms_ / (double)time_n_ : 0.0;
+    if (launches) *launches = time_n_;
+    if (steps) *steps = timed_steps_;
+    time_ms_ = 0;
+    time_n_ = 0;
+    timed_steps_ = 0;
+    timing_launches_ = 0;  // the next launch is timed again
+    return WV_OK;
+}
+
+template <typename Real>
+int Engine<Real>::synchronize() {
+    DeviceGuard guard(device_);
+    WV_HIP(hipStreamSynchronize(stream_));
+    WV_HIP(hipStreamSynchronize(comm_stream_));
+    return WV_OK;
+}
+
+}  // namespace wv

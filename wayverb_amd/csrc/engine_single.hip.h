@@ -1,0 +1,282 @@
+// engine_single.hip.h -- one time step per pass over the fields (waveguide.h:80-123, one loop body).
+//
+// Part of the engine behind the C ABI of include/wayverb_amd.h (engine.hip is the translation unit; see engine.hip.h for
+// the class and the map of which file holds what).
+#pragma once
+#include "engine.hip.h"
+
+namespace wv {
+
+template <typename Real>
+template <int RY, int NWX, int NWY>
+void Engine<Real>::launch_shape(const wv::StreamArgs<Real>& a, unsigned grid) {
+    if (plan_.variant == 2) {
+        hipLaunchKernelGGL((wv::stream_sweep_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                           stream_, a);
+    } else if (plan_.variant == 3) {
+        hipLaunchKernelGGL((wv::stream_sweep_nolds_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                           stream_, a);
+    } else {
+        hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
+                           stream_, a);
+    }
+}
+
+template <typename Real>
+template <int RY>
+void Engine<Real>::launch_ry(const wv::StreamArgs<Real>& a, unsigned grid) {
+    switch (plan_.nwx * 10 + plan_.nwy) {
+        case 11: launch_shape<RY, 1, 1>(a, grid); break;
+        case 22: launch_shape<RY, 2, 2>(a, grid); break;
+        case 41: launch_shape<RY, 4, 1>(a, grid); break;
+        case 42: launch_shape<RY, 4, 2>(a, grid); break;
+        case 81: launch_shape<RY, 8, 1>(a, grid); break;
+        case 18: launch_shape<RY, 1, 8>(a, grid); break;
+        case 24: launch_shape<RY, 2, 4>(a, grid); break;
+        default: launch_shape<RY, 1, 4>(a, grid); break;
+    }
+}
+
+// `out`: where the new field goes (null: in place, over `prev`)
+template <typename Real>
+int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out) {
+    if (z0 >= z1) return WV_OK;
+    wv::StreamArgs<Real> a{};
+    a.prev = prev;
+    a.next = out ? out : prev;
+    a.cur = cur;
+    a.cls = cls_;
+    a.flag = flag;
+    a.nx = nx_;
+    a.ny = ny_;
+    a.nz = nz_;
+    a.pitch = pitch_;
+    a.cls_pitch = cls_pitch_;
+    a.z_begin = z0;
+    a.z_end = z1;
+    a.tiles_x = plan_.tiles_x;
+    a.tiles_y = plan_.tiles_y;
+    unsigned grid = plan_.grid;
+    if (plan_.variant == 2 || plan_.variant == 3) {
+        a.stripe_rows = plan_.stripe_rows;
+        a.tiles_y_stripe = plan_.tiles_y_stripe;
+        a.passes = plan_.passes;
+        grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+        // rooms that leave much of the mesh outside: visit only the tiles with something to
+        // update -- valid while the outside nodes hold zeros in both fields (outside_dirty_)
+        // (built for the engine's big launch: all owned planes, or the interior planes of a slab)
+        if ((int64_t)(z1 - z0) * 2 > (int64_t)(z_end_ - z_begin_) && outside_dirty_ == 0) {
+            int rc = build_tile_lists(z0, z1);
+            if (rc) return rc;
+            if (tile_list_ && z0 == lists_z0_ && z1 == lists_z1_) {
+                a.tile_list = tile_list_;
+                for (int k = 0; k < 9; ++k) a.list_start[k] = list_start_[k];
+                grid = 8u * list_longest_;
+            }
+        }
+    } else if (plan_.variant == 0) {
+        a.zc = std::min(plan_.zc, z1 - z0);
+        a.chunks_z = (z1 - z0 + a.zc - 1) / a.zc;
+        a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
+        a.tiles_per_xcd = (a.total_tiles + 7) / 8;
+        grid = (unsigned)a.tiles_per_xcd * 8u;
+    }
+    timed = timed && time_this_launch();
+    if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+    if (plan_.variant == 1) {
+        hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
+    } else if (plan_.ry == 2) {
+        launch_ry<2>(a, grid);
+    } else {
+        launch_ry<4>(a, grid);
+    }
+    if (timed) {
+        WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+        timed_steps_ += 1;
+    }
+    return WV_OK;
+}
+
+template <typename Real>
+wv::BoundaryArgs<Real> Engine<Real>::boundary_args(Real* prev, const Real* cur, int* flag) const {
+    wv::BoundaryArgs<Real> b{};
+    b.prev = prev;
+    b.next = prev;  // one step at a time: the next field replaces `previous` in place
+    b.cur = cur;
+    b.flag = flag;
+    b.bnode = bnode_;
+    b.btype = btype_;
+    b.fmem = fmem_;
+    b.cidx = cidx_;
+    b.coeffs = coeffs_;
+    b.n_coeffs = n_coeffs_;
+    b.n1 = n1_;
+    b.n2 = n2_;
+    b.n3 = n3_;
+    b.n_slots = n_slots_;
+    b.nx = nx_;
+    b.ny = ny_;
+    b.nz = nz_;
+    b.pitch = pitch_;
+    b.z_begin = z_begin_;
+    b.z_end = z_end_;
+    b.courant = courant_;
+    b.courant_sq = courant_sq_;
+    return b;
+}
+
+// Boundary nodes of planes [z0, z1).  MUST be enqueued after the streaming launch that covers
+// those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
+// `out` (two-step passes): the new values go to another field instead of replacing `prev`.
+template <typename Real>
+int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner) {
+    if (!n_entries_ || z0 >= z1) return WV_OK;
+    wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
+    if (out) b.next = out;
+    b.fix_z0 = z0;  // (fix_inner: second launch of a two-step pass over the marched planes)
+    b.fix_z1 = z1;
+    wv::PrePostArgs<Real> nx{};  // fused == 0: nothing rides in this launch
+    if (next) {
+        nx = *next;
+        nx.fused = 1;
+    }
+    uint32_t n = n_entries_;
+    if (z0 > z_begin_ || z1 < z_end_) {
+        const int rc = build_plane_order();
+        if (rc != WV_OK) return rc;
+        b.order = zorder_ + plane_start_[z0];
+        b.n_order = plane_start_[z1] - plane_start_[z0];
+        n = b.n_order;
+        if (!n) return WV_OK;
+    }
+    const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && opt_.tuning.boundary_lds != 0;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (lds && fix_inner)
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, stream_, b, nx);
+    else if (lds)
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false>), grid, block, 0, stream_, b, nx);
+    else if (fix_inner)
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, true>), grid, block, 0, stream_, b, nx);
+    else
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false>), grid, block, 0, stream_, b, nx);
+    return WV_OK;
+}
+
+// One loop body: [pre/post on device] + pressure update + boundary update; flag -> flags_[slot]
+// reset a step's flag word to the mesh-static bits (setup_validate_kernel), inject the source
+// sample into `cur`, gather the receivers from it
+template <typename Real>
+wv::PrePostArgs<Real> Engine<Real>::pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const {
+    const bool io = with_pre_post && (n_recv_ || source_live);
+    wv::PrePostArgs<Real> pp{};
+    pp.cur = cur;
+    pp.signal = signal_;
+    pp.signal_pos = signal_pos;
+    pp.signal_base = graph_capturing_ ? signal_base_dev_ : nullptr;
+    pp.source_node = source_node_;
+    pp.source_kind = io && source_live ? source_kind_ : 0;
+    pp.recv = recv_nodes_;
+    pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
+    pp.n_recv = io ? n_recv_ : 0;
+    pp.flag = flags_ + slot;
+    pp.flag_init = static_flag_;
+    return pp;
+}
+
+// `fuse_next` (1: a single step follows in this batch, 2: a two-step pass): what follows gets its pre/post
+// work done by this step's boundary launch instead of a launch of its own -- one launch less per
+// step, which is what small meshes are bound by.
+template <typename Real>
+int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next) {
+    Real* prev = field_[prv_];
+    Real* cur = field_[cur_];
+    int* flag = flags_ + slot;
+    int rc;
+    std::string cerr;
+    // ghost planes of `cur` come from the exchange issued at the end of the previous step
+    if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+    if (!pre_post_done_) {
+        const wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);
+        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    }
+    pre_post_done_ = false;
+    // Order on the one compute stream: a plane's sweep, then that plane's boundary nodes.
+    if (comm_) {
+        // slab faces first, so that their exchange overlaps the interior update
+        const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
+        const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+        if ((rc = launch_stream(prev, cur, flag, z_begin_, zi0, false))) return rc;
+        if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
+        if ((rc = launch_boundary(prev, cur, flag, z_begin_, zi0))) return rc;
+        if ((rc = launch_boundary(prev, cur, flag, zi1, z_end_))) return rc;
+        WV_HIP(hipGetLastError());
+        if (!comm_->exchange_faces(stream_, prv_, &cerr)) return fail(WV_E_COMM, cerr);
+        if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
+        if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
+    } else {
+        if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
+        if (fuse_next && n_entries_) {
+            // the next step's `current` is this step's `prev`
+            wv::PrePostArgs<Real> nx = pre_post_args(prev, slot + 1, true, signal_pos + 1, source_live);
+            if (fuse_next == 2) nx.flag2 = flags_ + slot + 2;  // a two-step pass follows: both its flag words
+            if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_, &nx))) return rc;
+            pre_post_done_ = true;
+        } else if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_))) {
+            return rc;
+        }
+    }
+    WV_HIP(hipGetLastError());
+    if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+    // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
+    if (outside_dirty_ > 0 && outside_dirty_ < (1 << 30)) --outside_dirty_;
+    return WV_OK;
+}
+
+// Capture (once per batch shape) and replay a batch of `batch` steps.
+template <typename Real>
+int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) {
+    const GraphKey key{batch, cur_, source_live, can_fuse, n_recv_, source_node_, source_kind_, (uint64_t)(uintptr_t)signal_,
+                       (uint64_t)(uintptr_t)recv_nodes_, lists_built_ && tile_list_ != nullptr};
+    if (!graph_exec_ || !(key == graph_key_)) {
+        if (graph_exec_) {
+            (void)hipGraphExecDestroy(graph_exec_);
+            graph_exec_ = nullptr;
+        }
+        if (!signal_base_dev_) WV_HIP(hipMalloc((void**)&signal_base_dev_, sizeof(uint64_t)));
+        // whatever synchronises must happen before the capture starts
+        if (plan_.variant == 2 || plan_.variant == 3) {
+            int rc = build_tile_lists(z_begin_, z_end_);
+            if (rc) return rc;
+        }
+        (void)io_nodes_plain();
+        const int cur_before = cur_, prv_before = prv_;
+        hipGraph_t graph = nullptr;
+        WV_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        graph_capturing_ = true;
+        int rc = WV_OK;
+        for (uint64_t i = 0; i < batch && rc == WV_OK; ++i) {
+            rc = enqueue_step((int)i, true, i, source_live, can_fuse && i + 1 < batch ? 1 : 0);
+            std::swap(cur_, prv_);
+        }
+        graph_capturing_ = false;
+        const hipError_t end = hipStreamEndCapture(stream_, &graph);
+        cur_ = cur_before;
+        prv_ = prv_before;
+        if (rc != WV_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        WV_HIP(end);
+        const hipError_t inst = hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        WV_HIP(inst);
+        graph_key_ = key;
+    }
+    WV_HIP(hipMemcpyAsync(signal_base_dev_, &signal_pos_, sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    WV_HIP(hipGraphLaunch(graph_exec_, stream_));
+    // batch is even: the fields are back in their roles
+    return WV_OK;
+}
+
+}  // namespace wv

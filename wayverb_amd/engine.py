@@ -45,10 +45,50 @@ class WvMesh(C.Structure):
                 ("num_boundary_1", C.c_uint64), ("num_boundary_2", C.c_uint64), ("num_boundary_3", C.c_uint64)]
 
 
+TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "tile_lists",
+                 "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_merge", "slab_march_faces",
+                 "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks")
+
+
+class WvTuning(C.Structure):
+    """wv_tuning (include/wayverb_amd.h): how the engine does its work, never what it computes."""
+    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 7)]
+
+
 class WvOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
-                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("reserved_", C.c_int32 * 7)]
+                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("reserved_", C.c_int32 * 7),
+                ("tuning", WvTuning)]
+
+
+# Tuning applied to every engine this module creates unless the call says otherwise: {field of wv_tuning: value}, plus
+# "stream_variant" (wv_options).  Empty = the library's defaults.  Tests and tools steer the engine through this (the
+# library itself reads no environment variables).
+default_tuning = {}
+
+
+def tuning_from_env(environ=None):
+    """For the scripts under tools/: WV_PAIR=0 WV_STREAM_RY=2 ... in the environment -> a tuning dict."""
+    environ = os.environ if environ is None else environ
+    out = {}
+    for name in TUNING_FIELDS + ("stream_variant",):
+        v = environ.get("WV_" + name.upper())
+        if v is not None:
+            out[name] = int(v)
+    return out
+
+
+def apply_tuning(opt, tuning=None):
+    merged = dict(default_tuning)
+    merged.update(tuning or {})
+    for name, value in merged.items():
+        if name == "stream_variant":
+            opt.stream_variant = int(value)
+        elif name in TUNING_FIELDS:
+            setattr(opt.tuning, name, int(value))
+        else:
+            raise ValueError("unknown tuning field %r" % name)
 
 
 class WaveguideError(RuntimeError):
@@ -257,7 +297,7 @@ class Engine:
     """One `run` worth of device state: the buffers of waveguide.h:43-76."""
 
     def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
-                 flag_interval=0, stream_variant=2, all_tiles=False):
+                 flag_interval=0, stream_variant=2, all_tiles=False, tuning=None):
         self.lib = load_library()
         self.mesh = mesh
         self.precision = precision
@@ -280,6 +320,7 @@ class Engine:
         opt.flag_interval = flag_interval
         opt.stream_variant = stream_variant
         opt.all_tiles = 1 if all_tiles else 0
+        apply_tuning(opt, tuning)
         handle = C.c_void_p()
         _check(self.lib.wv_create(C.byref(wm), C.byref(opt), C.byref(handle)))
         self.h = handle
@@ -494,7 +535,7 @@ def run_fast(engine, source_kind, source_node, signal, receivers, keep_going=lam
 
 
 def run_fast_slabs(mesh, slabs, source_kind, source_node, signal, receivers, precision="f64", devices=None,
-                   keep_going=lambda: True, chunk=1024):
+                   keep_going=lambda: True, chunk=1024, tuning=None):
     """`run_fast` on a mesh cut into `slabs` z-slabs that live in THIS process -- on the GPUs listed in `devices`
     (slab r on devices[r % len(devices)]; default: all on the current device) -- joined by the in-process transport
     and stepped together (wv_comm_init_local / wv_run_group: the step code of the one-rank-per-GPU RCCL chain,
@@ -507,7 +548,7 @@ def run_fast_slabs(mesh, slabs, source_kind, source_node, signal, receivers, pre
         for r in range(slabs):
             L = SlabLayout(mesh.dims, r, slabs)
             eng = Engine(slab_mesh(mesh, L), precision=precision, device=devices[r % len(devices)],
-                         ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi)
+                         ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi, tuning=tuning)
             engines.append(eng)
             src_local, mine = place_source_and_receivers(L, source_node, receivers)
             if src_local is not None:
@@ -598,6 +639,7 @@ class SceneMesh:
         opt.flag_interval = kw.get("flag_interval", 0)
         opt.stream_variant = kw.get("stream_variant", 2)
         opt.all_tiles = 1 if kw.get("all_tiles", False) else 0
+        apply_tuning(opt, kw.get("tuning"))
         handle = C.c_void_p()
         _check(self.lib.wv_scene_mesh_create_engine(self.h, coeffs.ctypes.data_as(C.c_void_p), coeffs.shape[0],
                                                     C.byref(opt), C.byref(handle)))
