@@ -10,8 +10,12 @@ update of every node, boundary-filter update.  Inputs (mesh, fields, filter stat
 in HBM before the timed region.
 
   N = 1 : 1024^3 fp64 box (BASELINE configs[2], the mesh the north-star target is quoted on).
-  N > 1 : weak scaling -- rank r owns planes [1024 r, 1024 (r+1)) of a 1024 x 1024 x (1024 N) box
-          (configs[3] at N = 8), ghost planes exchanged each step over RCCL inside the engine.
+  N > 1 : weak scaling (default) -- rank r owns planes [1024 r, 1024 (r+1)) of a 1024 x 1024 x (1024 N) box
+          (configs[3] at N = 8), ghost planes exchanged each step over RCCL inside the engine;
+          `--scaling strong`: the 1024^3 box of N = 1 cut into N slabs of 1024 / N planes (the north star's
+          ">= 6x at 8 GPUs" read as a speed-up of configs[2]).
+  More ranks than GPUs (tests on a one-GPU box): torch.distributed falls back to gloo for the bookkeeping and
+  `--rccl-library` must name a stand-in for librccl (tests/mock_rccl/mock_rccl_shm.cpp); never a measurement.
 
 Prints ONE JSON line on rank 0 (see the README of the driver contract); `roofline` is for the
 dominant kernel, timed with HIP events on the engine's stream: at N = 1 the two-step pass
@@ -48,6 +52,10 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-small", action="store_true", help="skip the 256^3 side measurement")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="N > 1: weak = --nz planes per GPU (default), strong = --nz planes in total")
+    p.add_argument("--rccl-library", default="", help="resolve the RCCL entry points in this shared library "
+                                                      "(wv_comm_use_library; tests with more ranks than GPUs)")
     p.add_argument("--tuning", default="", help="wv_tuning fields for measurement runs, e.g. pair=0,stream_ry=2 "
                                                 "(default: none -- the product's own choices)")
     p.add_argument("--no-reference-on-gpu", action="store_true",
@@ -143,10 +151,20 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    local_rank %= max(1, torch.cuda.device_count())  # a launcher may expose one device per rank
+    n_dev = max(1, torch.cuda.device_count())
+    shared_gpu = world > n_dev              # several ranks per GPU: RCCL itself cannot do that
+    local_rank %= n_dev                     # (a launcher may also expose one device per rank)
     torch.cuda.set_device(local_rank)
+    if shared_gpu and not args.rccl_library:
+        raise SystemExit("%d ranks on %d GPU(s): RCCL needs one GPU per rank (tests: --rccl-library <stand-in>)" % (world, n_dev))
+    if args.rccl_library:
+        E.Engine.comm_use_library(args.rccl_library)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_device = "cpu" if shared_gpu else "cuda"  # where the bookkeeping collectives' tensors live
     if rank == 0:
         build.build(verbose=False)
     if world > 1:
@@ -154,7 +172,9 @@ def main():
 
     elem = 4 if args.precision == "f32" else 8
     nx, ny = args.nx, args.ny
-    nz_global = args.nz * world
+    if args.scaling == "strong" and args.nz < 4 * world:
+        raise SystemExit("--scaling strong: %d planes are too few for %d slabs" % (args.nz, world))
+    nz_global = args.nz if args.scaling == "strong" else args.nz * world
     layout = SlabLayout((nx, ny, nz_global), rank, world)
     t_setup = time.perf_counter()
     mesh = box_slab_mesh(nx, ny, nz_global, layout, coefficients=M.bench_materials())
@@ -162,7 +182,7 @@ def main():
                    ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi)
     mesh.nodes = None  # host copy no longer needed
     if world > 1:
-        idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device=coll_device)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(E.Engine.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
@@ -201,7 +221,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches, timed_steps = eng.kernel_time_detail()
@@ -253,11 +273,11 @@ def main():
         "metric": "Gnode-updates/s, fp64 box mesh" if args.precision == "f64" else "Gnode-updates/s, fp32 box mesh",
         "value": round(value, 3), "unit": "Gnode-updates/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "%dx%dx%d box mesh, %s pressures, walls of 4 mixed materials (2 flat, 2 frequency-dependent order-6 IIR), hard-source impulse + 1 receiver"
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
-                   "per_gpu": "%dx%dx%d z-slab" % (nx, ny, args.nz), "decomposition": "z-slabs x%d" % world,
+                   "per_gpu": "%dx%dx%d z-slab" % (nx, ny, layout.z1 - layout.z0), "decomposition": "z-slabs x%d" % world,
                    "halo": "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass), overlapped with the interior" if world > 1 else "none",
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -227,13 +227,19 @@ int wv_set_stream_tuning(wv_engine* e, int variant, int rows_per_wave, int waves
 
 /* ---- z-slab halo exchange over RCCL (multi-GPU) ---------------------------- */
 #define WV_UNIQUE_ID_BYTES 128
+/* The shared library the RCCL entry points are resolved in (dlopen of exactly this path) instead of the librccl the
+ * process finds by name; NULL / "" = by name again.  Process-wide, before the first communicator call (WV_E_STATE
+ * afterwards).  For deployments with RCCL outside the loader's path -- and for the test stand-ins under tests/mock_rccl. */
+int wv_comm_use_library(const char* path);
 /* rank 0 creates the id; the caller distributes the bytes (e.g. torch.distributed broadcast) */
 int wv_comm_unique_id(void* id_bytes /* [WV_UNIQUE_ID_BYTES] */);
 /* Joins a communicator: this engine is slab `rank` of `nranks`, neighbours rank-1 / rank+1. */
 int wv_comm_init(wv_engine* e, const void* id_bytes, int rank, int nranks);
 int wv_comm_destroy(wv_engine* e);
-/* On a chain of nranks > 1 every rank must call wv_run with the same n_steps (a rank that holds no
- * source cannot know where the signal ends); at the end of every batch of steps the per-step flag
+/* On a chain of nranks > 1 every rank calls wv_run with the same n_steps.  Before each batch of steps the ranks
+ * agree (one small all-reduce) on its length -- the ranks that hold the source plane know where the signal ends, and
+ * the run ends there on every rank with the same *steps_done, as it does on one device (hard_source.h:18-20) -- and
+ * on the form of its steps (two-step passes need every rank's consent); at the end of every batch the per-step flag
  * words are OR-ed over the ranks (one small all-reduce), so a NaN / Inf / bad-boundary flag raised
  * on one slab stops all of them at the same step -- the multi-device form of waveguide.h:100-119.
  *

@@ -640,7 +640,8 @@ class handle_bridge final {
 public:
     // wv_run has swapped the fields by the time the callback fires: the step's pre-update `current`
     // (what waveguide.h:121 hands to `post`) is the engine's PREVIOUS buffer now
-    handle_bridge(wv_engine* e, size_t nodes) : queue_{e}, current_{e, WV_BUF_PREVIOUS, nodes} {}
+    // (the handle carries the ENGINE's pressure type: a callback may branch on buffer::precision(), as soft_source does)
+    handle_bridge(wv_engine* e, size_t nodes) : queue_{e}, current_{e, WV_BUF_PREVIOUS, nodes, default_precision()} {}
     bool per_step() const { return true; }  // the callback may read the field: it must be the step's field
     template <typename Callback>
     void invoke(Callback& callback, size_t step, size_t steps) {

@@ -4,6 +4,7 @@ communicator from wv_comm_init (the RCCL path of csrc/comm.cpp, NOT the in-proce
 its own thread with wv_run, all on one GPU; the result is compared with the single-domain engine bit for bit.
 
     python tests/_rccl_chain_worker.py <world> <room> <nx> <ny> <nz> <f32|f64> <steps> <seed> [<bad_step>] [--pair=0|1]
+                                       [--short-signal=K] [--rccl-library=PATH]
 """
 import sys
 import threading
@@ -27,14 +28,23 @@ def global_mesh(dims, room, rng):
 
 
 def main():
-    for a in [a for a in sys.argv if a.startswith("--pair=")]:   # stepping mode of every engine (wv_tuning::pair)
-        E.default_tuning["pair"] = int(a.split("=")[1])
+    short_signal, library = None, None
+    for a in [a for a in sys.argv if a.startswith("--")]:
+        key, value = a[2:].split("=", 1)
+        if key == "pair":             # stepping mode of every engine (wv_tuning::pair)
+            E.default_tuning["pair"] = int(value)
+        elif key == "short-signal":   # the source signal ends after this many steps, the ranks are asked for more
+            short_signal = int(value)
+        elif key == "rccl-library":   # wv_comm_use_library instead of LD_LIBRARY_PATH
+            library = value
         sys.argv.remove(a)
     world, room = int(sys.argv[1]), sys.argv[2]
     dims = tuple(int(a) for a in sys.argv[3:6])
     precision, steps, seed = sys.argv[6], int(sys.argv[7]), int(sys.argv[8])
     bad_step = int(sys.argv[9]) if len(sys.argv) > 9 else -1
     E.load_library()
+    if library:
+        E.Engine.comm_use_library(library)
     assert "torch" not in sys.modules, "torch (and with it the real librccl) must stay out of this process"
     rng = np.random.default_rng(seed)
     gmesh = global_mesh(dims, room, rng)
@@ -46,6 +56,8 @@ def main():
     signal = rng.uniform(-0.1, 0.1, steps)
     if bad_step >= 0:
         signal[bad_step] = np.inf
+    if short_signal is not None:
+        signal = signal[:short_signal]
     inside = np.nonzero(t & M.ID_INSIDE)[0]
     plane = dims[0] * dims[1]
     # the source on a slab face (top owned plane of slab 0), receivers on every slab and next to a cut

@@ -9,12 +9,13 @@
 //   ncclSend / ncclRecv (inside ncclGroupStart / End): the receive is ordered after the sender's stream at the
 //     time of the send, the sender's stream does not run on before the data has been taken; sends and receives
 //     between a pair of ranks match in issue order; a rank may send to itself;
-//   ncclAllReduce(ncclUint64, ncclSum, in place or not): every rank's stream sees the sum.
+//   ncclAllReduce(ncclUint64, ncclSum or ncclMin, in place or not): every rank's stream sees the result.
 // Calls block on the host until the peer has made the matching call -- as NCCL may.
 //
 //   hipcc -O2 -fPIC -shared tests/mock_rccl/mock_rccl.cpp -o <dir>/librccl.so.1
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -202,7 +203,7 @@ int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm, hipStream
 }
 
 int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) {
-    if (dtype != 5 || op != 0) return 4;  // only what comm.cpp asks for: ncclUint64, ncclSum
+    if (dtype != 5 || (op != 0 && op != 3)) return 4;  // only what comm.cpp asks for: ncclUint64 with ncclSum or ncclMin
     Comm* c = static_cast<Comm*>(comm);
     Group& g = *c->g;
     std::vector<unsigned long long> mine(count);
@@ -212,9 +213,9 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
     {
         std::unique_lock<std::mutex> lk(g.m);
         const unsigned long long gen = g.generation;
-        if (g.contributed == 0) g.sum.assign(count, 0ull);
+        if (g.contributed == 0) g.sum.assign(count, op == 0 ? 0ull : ~0ull);
         if (g.sum.size() != count) return 2;
-        for (size_t i = 0; i < count; ++i) g.sum[i] += mine[i];
+        for (size_t i = 0; i < count; ++i) g.sum[i] = op == 0 ? g.sum[i] + mine[i] : std::min(g.sum[i], mine[i]);
         if (++g.contributed == g.nranks) g.cv.notify_all();
         g.cv.wait(lk, [&] { return g.contributed == g.nranks || g.generation != gen; });
         total = g.sum;

@@ -1,0 +1,75 @@
+"""bench.py with world > 1, launched exactly as the driver launches it (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N ... bench.py --gpus N ...`), on a box with ONE GPU: torch.distributed falls back to gloo for the
+bookkeeping collectives and the engine's communicator resolves its RCCL entry points in tests/mock_rccl/mock_rccl_shm.cpp
+(ranks = processes sharing the GPU, host-synchronous).  Nothing here is a measurement; what it buys is that bench.py's
+world > 1 path -- RANK / LOCAL_RANK / WORLD_SIZE from the environment, SlabLayout per rank, the unique-id broadcast,
+wv_comm_init, the chain's per-batch agreements, max-over-ranks timing, the roofline bookkeeping of a slab and the one
+JSON line from rank 0 -- has executed before the first real multi-GPU run does it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def shm_mock(tmp_path_factory, built_library):
+    d = tmp_path_factory.mktemp("mock_rccl_shm")
+    out = subprocess.run([HIPCC, "-O2", "-fPIC", "-shared", "-std=c++17", os.path.join(HERE, "mock_rccl", "mock_rccl_shm.cpp"),
+                          "-o", str(d / "libwvmockrccl.so"), "-lrt"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return str(d / "libwvmockrccl.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_bench(world, shm_mock, *extra, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rccl-library", shm_mock,
+           "--no-cpu-baseline", "--no-reference-on-gpu"] + [str(a) for a in extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world,scaling,tuning,two_step", [(2, "weak", "pair=1", True), (3, "strong", "pair=0", False),
+                                                          (4, "weak", "", None)])
+def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_step):
+    nx, ny, nz, steps, warmup = 256, 96, (48 if scaling == "weak" else 96), 8, 4
+    extra = ["--steps", steps, "--warmup", warmup, "--nx", nx, "--ny", ny, "--nz", nz, "--scaling", scaling]
+    if tuning:
+        extra += ["--tuning", tuning]
+    r = run_bench(world, shm_mock, *extra)
+    nz_global = nz * world if scaling == "weak" else nz
+    assert r["n_gpus"] == world and r["steps"] == steps and r["warmup"] == warmup and r["scaling"] == scaling
+    assert r["unit"] == "Gnode-updates/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f64"
+    assert r["config"]["workload"].startswith("%dx%dx%d box mesh" % (nx, ny, nz_global))
+    assert r["config"]["decomposition"] == "z-slabs x%d" % world and "RCCL" in r["config"]["halo"]
+    # value is the whole job: all nodes of all ranks x steps / (max-over-ranks) time
+    assert r["value"] == pytest.approx(nx * ny * nz_global * steps / (r["ms_per_step"] * 1e-3 * steps) / 1e9, rel=1e-2)
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["launches"] > 0 and roof["kernel_ms"] > 0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3)
+    if two_step is not None:
+        assert roof["kernel"] == ("pair_march_kernel" if two_step else "stream_sweep_kernel")
+        assert roof["time_steps_per_launch"] == (2.0 if two_step else 1.0)
+    # rank 0's slab: the timed launch covers its owned planes but the face plane(s) next to a neighbour
+    owned0 = nz_global // world + (1 if 0 < nz_global % world else 0)
+    fields = 4 if roof["time_steps_per_launch"] > 1.5 else 3
+    assert roof["alg_bytes_per_launch"] == fields * 8 * nx * ny * (owned0 - 1)
+    assert r["cpu_baseline"] is None

@@ -81,8 +81,11 @@ def test_config3_1024x1024x8192_as_eight_slabs_on_one_gpu(oracle, built_library,
     dtype = np.float32 if precision == "f32" else np.float64
     dims = (N, N, NZG)
     plane = N * N
-    coeffs = M.bench_materials()
     rng = np.random.default_rng(8192)
+    # fp64: ONE order-6 material on every wall, so that x-mirror-symmetric bands must stay mirror symmetric bit for bit;
+    # fp32: the bench's four materials dealt over the wall filters (no symmetry to speak of: the oracle is the check)
+    coeffs = M.passive_peak_filter_coefficients(rng, 1) if precision == "f64" else M.bench_materials()
+    check_symmetry = coeffs.shape[0] == 1
     signal = rng.uniform(-0.5, 0.5, S)
     # hard source on the top owned plane of slab 2 (its copy lives in slab 3's ghost plane); directional receiver
     # centred on the top owned plane of slab 3, its +z node owned by slab 4.  Global indices need 34 bits.
@@ -179,7 +182,7 @@ def test_config3_1024x1024x8192_as_eight_slabs_on_one_gpu(oracle, built_library,
                     assert lo - S < 1 or np.any(got[0] != 0), "the wave has not reached plane %d" % z0
                     assert hi + S > NZG - 1 or np.any(got[-1] != 0), "the wave has not reached plane %d" % (z1 - 1)
                 assert got.tobytes() == want.tobytes(), "planes %d..%d differ from the oracle" % (z0, z1 - 1)
-                if sym:
+                if sym and check_symmetry:
                     assert np.array_equal(got, got[:, :, ::-1]), "mirror symmetry lost in planes %d..%d" % (z0, z1 - 1)
             # filter memories of every wall node in the compared planes, slab by slab
             for d in (1, 2, 3):

@@ -24,12 +24,23 @@ def mock_dir(tmp_path_factory, built_library):
     return str(d)
 
 
-def run_worker(mock_dir, *args, pair=None, timeout=300):
+@pytest.fixture(scope="module")
+def shm_mock(tmp_path_factory, built_library):
+    """tests/mock_rccl/mock_rccl_shm.cpp: ranks may be processes; host-synchronous; loaded by path (wv_comm_use_library)."""
+    d = tmp_path_factory.mktemp("mock_rccl_shm")
+    out = subprocess.run([HIPCC, "-O2", "-fPIC", "-shared", "-std=c++17", os.path.join(HERE, "mock_rccl", "mock_rccl_shm.cpp"),
+                          "-o", str(d / "libwvmockrccl.so"), "-lrt"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return str(d / "libwvmockrccl.so")
+
+
+def run_worker(mock_dir, *args, pair=None, timeout=300, extra=()):
     env = dict(os.environ)
-    env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    if mock_dir:
+        env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env["WV_NO_TORCH_PRELOAD"] = "1"   # torch would bring the real librccl (same soname) into the process
     out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py")] + [str(a) for a in args] +
-                         (["--pair=%d" % pair] if pair is not None else []),
+                         (["--pair=%d" % pair] if pair is not None else []) + list(extra),
                          capture_output=True, text=True, env=env, timeout=timeout)
     last = (out.stdout.strip().splitlines() or [""])[-1]
     assert out.returncode == 0 and last.startswith("OK"), (out.stdout[-1500:], out.stderr[-1500:])
@@ -52,3 +63,20 @@ def test_a_non_finite_value_on_one_rank_stops_every_rank_at_that_step(mock_dir, 
     single domain's -- the run ends on the step that produced the value (waveguide.h:100-119)."""
     last = run_worker(mock_dir, 3, "box", 18, 16, 27, "f64", 40, 7, 17, pair=pair)
     assert last.startswith("OK steps 17 ") and " flag 0 " not in last, last
+
+
+@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
+def test_a_source_signal_shorter_than_the_run_ends_every_rank_together(mock_dir, pair):
+    """Only the ranks that hold the source plane know where the signal ends (hard_source.h:18-20 returns false there and
+    `run` stops): the chain agrees on every batch's length before enqueueing it, so all four ranks return after 23 of the
+    40 steps asked for -- none is left waiting in a receive for a step its neighbour never takes."""
+    last = run_worker(mock_dir, 4, "box", 20, 18, 33, "f64", 40, 11, pair=pair, extra=["--short-signal=23"])
+    assert last.startswith("OK steps 23 flag 0 "), last
+
+
+@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
+def test_the_shared_memory_stand_in_carries_a_chain_too(shm_mock, pair):
+    """tests/mock_rccl/mock_rccl_shm.cpp (what lets bench.py run with world > 1 on one GPU, test_gpu_bench_world.py)
+    against the same chain test as the thread stand-in, loaded through wv_comm_use_library."""
+    last = run_worker(None, 3, "L", 28, 24, 30, "f64", 27, 103, pair=pair, extra=["--rccl-library=" + shm_mock])
+    assert last.startswith("OK steps 27 flag 0 "), last

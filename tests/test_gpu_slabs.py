@@ -246,3 +246,22 @@ def test_random_slab_chains_equal_the_single_domain(built_library, seed, _step_m
     got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps)
     assert want["done"] == steps and want["flag"] == 0
     assert_same(got, want, gmesh)
+
+
+def test_a_group_refuses_slabs_that_are_out_of_step():
+    """Exchanges address the neighbour's field buffers by role: a slab that was stepped on its own (wv_step + wv_swap)
+    before joining no longer has its buffers in the roles the others have, and wv_run_group says so instead of
+    pushing face planes into the wrong field."""
+    gmesh = global_mesh((20, 18, 24), "box", np.random.default_rng(3))
+    engines = []
+    for r in range(2):
+        L = SlabLayout(gmesh.dims, r, 2)
+        engines.append(E.Engine(slab_mesh(gmesh, L), precision="f64", ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi))
+    engines[1].step()
+    engines[1].swap()
+    group = E.LocalSlabGroup(engines)
+    try:
+        with pytest.raises(E.WaveguideError, match="same steps"):
+            group.run_steps(4)
+    finally:
+        group.close()

@@ -39,15 +39,27 @@ struct Rccl {
 constexpr int kNcclInt8 = 0;    // ncclInt8 / ncclChar
 constexpr int kNcclUint64 = 5;  // ncclUint64
 constexpr int kNcclSum = 0;     // ncclSum
+constexpr int kNcclMin = 3;     // ncclMin
+
+std::string& library_override() {
+    static std::string path;
+    return path;
+}
+bool g_library_loaded = false;
 
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char* n : names) {
-            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
+        g_library_loaded = true;
+        if (!library_override().empty()) {  // wv_comm_use_library: this file and nothing else
+            r.handle = dlopen(library_override().c_str(), RTLD_NOW | RTLD_LOCAL);
+        } else {
+            const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+            for (const char* n : names) {
+                r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) break;
+            }
         }
         if (!r.handle) {
             r.load_error = std::string("cannot load librccl: ") + dlerror();
@@ -105,6 +117,15 @@ __global__ void flag_gather_kernel(const uint64_t* in, int* flags, int n) {
 }
 
 }  // namespace
+
+bool SlabComm::use_library(const char* path, std::string* err) {
+    if (g_library_loaded) {
+        *err = "the collective library is already loaded: wv_comm_use_library must come before the first communicator call";
+        return false;
+    }
+    library_override() = path ? path : "";
+    return true;
+}
 
 bool SlabComm::unique_id(void* bytes128, std::string* err) {
     Rccl& r = rccl();
@@ -204,6 +225,15 @@ void SlabComm::set_fields(void* const* fields, int n_fields, size_t plane_bytes,
 
 SlabComm::~SlabComm() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    // local transport: a neighbour's push into this slab's ghost plane runs on the NEIGHBOUR's halo stream
+    for (SlabComm* peer : {lo_, hi_})
+        if (peer && peer->stream_) {
+            int before = 0;
+            (void)hipGetDevice(&before);
+            if (peer->device_ != before) (void)hipSetDevice(peer->device_);
+            (void)hipStreamSynchronize(peer->stream_);
+            if (peer->device_ != before) (void)hipSetDevice(before);
+        }
     if (comm_) (void)rccl().comm_destroy(comm_);
     for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_, pushed_hi_, step_done_, reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
@@ -253,6 +283,10 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
             if (lo_->step_done_set_ &&
                 !hip_ok(hipStreamWaitEvent(stream_, lo_->step_done_, 0), "hipStreamWaitEvent", err))
                 return false;
+            if (field >= lo_->n_fields_ || !lo_->fields_[field]) {
+                *err = "exchange_faces: the lower neighbour has no such field buffer (slabs of a chain must take the same steps)";
+                return false;
+            }
             char* dst = static_cast<char*>(lo_->fields_[field]) + (size_t)(lo_->nz_ - 1) * lo_->plane_bytes_;
             if (lo_->plane_bytes_ != plane_bytes) {
                 *err = "neighbouring slabs disagree about the plane size";
@@ -269,6 +303,10 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
                 return false;
             if (hi_->plane_bytes_ != plane_bytes) {
                 *err = "neighbouring slabs disagree about the plane size";
+                return false;
+            }
+            if (field >= hi_->n_fields_ || !hi_->fields_[field]) {
+                *err = "exchange_faces: the upper neighbour has no such field buffer (slabs of a chain must take the same steps)";
                 return false;
             }
             char* dst = static_cast<char*>(hi_->fields_[field]);
@@ -312,6 +350,31 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
     if (!hip_ok(hipEventRecord(ghosts_ready_, stream_), "hipEventRecord", err)) return false;
     pending_ = true;
     return true;
+}
+
+// words[i] <- min over the ranks, on the halo stream like every other RCCL call of this communicator; host-synchronous
+// (the caller needs the answer to decide what to enqueue next).
+bool SlabComm::agree_min(hipStream_t stream, uint64_t* words, int n, std::string* err) {
+    if (local_ || n <= 0) return true;
+    if (n > kMaxFlags) {
+        *err = "agree_min: too many words";
+        return false;
+    }
+    if (!spread_ && !hip_ok(hipMalloc((void**)&spread_, kMaxFlags * sizeof(uint64_t)), "hipMalloc", err)) return false;
+    for (hipEvent_t* e : {&reduce_in_, &reduce_out_})
+        if (!*e && !hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    // (`spread_` is also or_flags' scratch: both are issued from the engine's one host thread, in stream order)
+    if (!hip_ok(hipMemcpyAsync(spread_, words, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "hipMemcpyAsync", err))
+        return false;
+    if (!hip_ok(hipEventRecord(reduce_in_, stream), "hipEventRecord", err)) return false;
+    if (!hip_ok(hipStreamWaitEvent(stream_, reduce_in_, 0), "hipStreamWaitEvent", err)) return false;
+    if (!nccl_ok(rccl().all_reduce(spread_, spread_, (size_t)n, kNcclUint64, kNcclMin, comm_, stream_), "ncclAllReduce", err))
+        return false;
+    if (!hip_ok(hipEventRecord(reduce_out_, stream_), "hipEventRecord", err)) return false;
+    if (!hip_ok(hipStreamWaitEvent(stream, reduce_out_, 0), "hipStreamWaitEvent", err)) return false;
+    if (!hip_ok(hipMemcpyAsync(words, spread_, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync", err))
+        return false;
+    return hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize", err);
 }
 
 bool SlabComm::or_flags(hipStream_t stream, int* flags, int n, std::string* err) {

@@ -32,6 +32,9 @@ public:
     SlabComm& operator=(const SlabComm&) = delete;
 
     static bool unique_id(void* bytes128, std::string* err);
+    // The shared library the RCCL entry points are taken from, instead of the librccl the process finds by name
+    // (null / empty: back to that).  Process-wide; before the first communicator call.
+    static bool use_library(const char* path, std::string* err);
 
     bool init(const void* id_bytes128, int rank, int nranks, int device, hipStream_t comm_stream,
               bool has_lo, bool has_hi, std::string* err);
@@ -56,6 +59,11 @@ public:
     // "error-flag OR": one rank's NaN must stop every rank at the same step.
     static constexpr int kMaxFlags = 1024;
     bool or_flags(hipStream_t stream, int* flags, int n, std::string* err);
+    // words[i] <- minimum of words[i] over all ranks (host array; returns when the answer is there).  What a chain
+    // agrees on before it enqueues a batch: how many steps, and in which form (engine_batch.hip.h).
+    bool agree_min(hipStream_t stream, uint64_t* words, int n, std::string* err);
+    // local transport: everything this slab has pushed into its neighbours has landed
+    hipStream_t halo_stream() const { return stream_; }
 
     int rank() const { return rank_; }
     int nranks() const { return nranks_; }

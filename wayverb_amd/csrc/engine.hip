@@ -202,6 +202,11 @@ int wv_set_stream_tuning(wv_engine* e, int variant, int ry, int nwx, int nwy, in
     WV_NEED(e);
     return e->set_tuning(variant, ry, nwx, nwy, zchunks);
 }
+int wv_comm_use_library(const char* path) {
+    std::string err;
+    if (!wv::SlabComm::use_library(path, &err)) return fail(WV_E_STATE, err);
+    return WV_OK;
+}
 int wv_comm_unique_id(void* id_bytes) {
     std::string err;
     if (!wv::SlabComm::unique_id(id_bytes, &err)) return fail(WV_E_COMM, err);
@@ -234,6 +239,11 @@ int wv_comm_init_local(wv_engine* const* engines, int32_t n) {
 int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_t* steps_done, int32_t* flag_out) {
     if (!engines || n < 1) return fail(WV_E_INVALID_ARGUMENT, "no engines");
     for (int i = 0; i < n; ++i) WV_NEED(engines[i]);
+    // lockstep needs the slabs in the same state: the same field buffer in the same role after the same number of steps
+    // (exchanges address the neighbour's buffer by index)
+    for (int k = 1; k < n; ++k)
+        if (engines[k]->role_signature() != engines[0]->role_signature())
+            return fail(WV_E_STATE, "the slabs of a group must have taken the same steps (wv_step / wv_swap / wv_run on one of them alone?)");
     uint64_t completed = 0;
     int32_t flag = 0;
     std::vector<int> ored;
@@ -242,14 +252,33 @@ int wv_run_group(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_
         uint64_t batch = n_steps - completed;
         for (int k = 0; k < n; ++k) batch = std::min(batch, engines[k]->plan_batch(n_steps - completed));
         if (batch == 0) break;
-        // two-step passes only if every slab can take them, after the single steps any of them needs first
-        int singles_first = 0;
-        for (int k = 0; k < n && singles_first >= 0; ++k) {
-            int mine = -1;
-            const int rc = engines[k]->batch_pairs_ready(&mine);
+        // two-step passes only if every slab can take them (asked before anything is allocated for them), after the
+        // single steps any of them needs first
+        int singles_first = -1, all_eligible = 1;
+        for (int k = 0; k < n && all_eligible; ++k) {
+            int mine = 0;
+            const int rc = engines[k]->batch_pair_eligible(&mine);
             if (rc) return rc;
-            singles_first = mine < 0 ? -1 : std::max(singles_first, mine);
+            all_eligible = mine;
         }
+        if (all_eligible) {
+            singles_first = 0;
+            for (int k = 0; k < n; ++k) {
+                int ready = 0, mine = 0;
+                const int rc = engines[k]->batch_pair_prepare(&ready, &mine);
+                if (rc) return rc;
+                if (!ready) {
+                    singles_first = -1;
+                    break;
+                }
+                singles_first = std::max(singles_first, mine);
+            }
+        }
+        if (singles_first < 0)
+            for (int k = 0; k < n; ++k) {
+                const int rc = engines[k]->batch_pair_vetoed();
+                if (rc) return rc;
+            }
         const bool pairs = singles_first >= 0;
         // lockstep: step i of every slab is enqueued before step i + 1 of any, and the two parts of a
         // two-step pass likewise (comm.h, local transport)

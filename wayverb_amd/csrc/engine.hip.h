@@ -53,7 +53,12 @@ public:
     int launch_fixup(uint32_t first, uint32_t n, const Real* t1, const Real* cur, Real* out2, int* flag2);
     int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
     int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
-    int batch_pairs_ready(int* singles_first) override;
+    int batch_pair_eligible(int* eligible) override;
+    int batch_pair_prepare(int* ready, int* singles_first) override;
+    int batch_pair_vetoed() override;
+    uint64_t role_signature() const override {
+        return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
+    }
     // ---- engine_batch.hip.h
     bool time_this_launch();
     int drain_timing();

@@ -98,7 +98,14 @@ struct wv_engine {
     // next_kind: what follows in the same batch -- 0 nothing, 1 a single step, 2 a two-step pass
     virtual int enqueue_batch_step(uint64_t i, uint64_t batch, int next_kind) = 0;
     virtual int enqueue_batch_pair(uint64_t i, int part, int next_kind) = 0;
-    virtual int batch_pairs_ready(int* singles_first) = 0;
+    // Two-step passes for the batch being planned, decided by all slabs of a chain together (their exchanges must
+    // pair up): first the cheap question -- would this engine take them at all -- and only when every slab says
+    // yes the set-up that costs memory and time (two more fields, the pair map, the lists); *singles_first = the
+    // number of single full sweeps this engine needs first (0, 1 or 2: a caller wrote into outside nodes).
+    virtual int batch_pair_eligible(int* eligible) = 0;
+    virtual int batch_pair_prepare(int* ready, int* singles_first) = 0;
+    virtual int batch_pair_vetoed() = 0;  // the chain stays with single steps: the spare fields go back
+    virtual uint64_t role_signature() const = 0;  // which field buffer plays which role, and after how many steps
     virtual int collect_batch(uint64_t batch) = 0;
     virtual const int* batch_flags() const = 0;
     virtual int commit_batch(uint64_t batch, const int* flags, uint64_t* good, int32_t* flag) = 0;

@@ -99,6 +99,9 @@ int Engine<Real>::collect_batch(uint64_t batch) {
                               stream_));
     }
     WV_HIP(hipStreamSynchronize(stream_));
+    // in-process chain: the last step's face pushes run on the halo streams; wv_run_group collects every slab, so that on
+    // its return no copy into anybody's ghost plane is still in flight (a read-back or a wv_destroy may follow)
+    if (comm_ && comm_->is_local()) WV_HIP(hipStreamSynchronize(comm_stream_));
     return drain_timing();
 }
 
@@ -133,8 +136,22 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
         return fail(WV_E_STATE, "slabs joined by wv_comm_init_local are stepped together: use wv_run_group");
     uint64_t completed = 0;
     int32_t flag = 0;
+    const bool chain = comm_ && !comm_->is_local();  // (a one-rank communicator agrees with itself: the loopback test runs this)
+    std::string cerr;
     while (completed < n_steps && flag == 0) {
-        const uint64_t batch = plan_batch(n_steps - completed);
+        uint64_t batch = plan_batch(n_steps - completed);
+        int eligible = 0, rc = batch_pair_eligible(&eligible);
+        if (rc) return rc;
+        if (chain) {
+            // Every rank of the chain has to enqueue the same steps in the same form, or its exchanges and the flag
+            // all-reduce would not pair up with its neighbours': the batch is the shortest any rank allows (only the
+            // ranks that hold the source plane know where the signal ends -- hard_source.h:18-20 ends the run there, for
+            // all of them), and two-step passes need every rank's consent.
+            uint64_t words[2] = {batch, (uint64_t)eligible};
+            if (!comm_->agree_min(stream_, words, 2, &cerr)) return fail(WV_E_COMM, cerr);
+            batch = words[0];
+            eligible = (int)words[1];
+        }
         if (batch == 0) break;
         // Small meshes are bound by launches, not bytes: a full batch of steps is captured once
         // into a hipGraph and replayed (the only thing that differs between batches, the
@@ -143,25 +160,22 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
         const bool use_graph = opt_.tuning.graph != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
                                stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
         if (use_graph) {
-            int rc = replay_batch(batch, batch_source_live_, batch_can_fuse_);
-            if (rc) return rc;
+            if ((rc = replay_batch(batch, batch_source_live_, batch_can_fuse_))) return rc;
         } else {
             // big meshes: two steps per pass over the fields wherever a batch has two left
             int singles_first = -1;
-            int rc = batch_pairs_ready(&singles_first);
-            if (rc) return rc;
-            if (comm_ && !comm_->is_local()) {
-                // every rank of the chain has to take the same path: one flag word, OR-ed over the
-                // ranks -- bit 3 "some rank cannot", bits 0-1 the largest number of single steps any
-                // rank needs first (thermometer code: OR = max)
-                int word = singles_first < 0 ? 8 : (singles_first >= 2 ? 3 : singles_first);
-                std::string cerr;
-                WV_HIP(hipMemcpyAsync(flags_ + kRing, &word, sizeof(int), hipMemcpyHostToDevice, stream_));
-                if (!comm_->or_flags(stream_, flags_ + kRing, 1, &cerr)) return fail(WV_E_COMM, cerr);
-                WV_HIP(hipMemcpyAsync(&word, flags_ + kRing, sizeof(int), hipMemcpyDeviceToHost, stream_));
-                WV_HIP(hipStreamSynchronize(stream_));
-                singles_first = (word & 8) ? -1 : ((word & 2) ? 2 : (word & 1));
+            if (eligible) {
+                int ready = 0, mine = 0;
+                if ((rc = batch_pair_prepare(&ready, &mine))) return rc;
+                if (chain) {  // min of (2 - singles) = the most single sweeps any rank needs first
+                    uint64_t words[2] = {(uint64_t)ready, (uint64_t)(2 - mine)};
+                    if (!comm_->agree_min(stream_, words, 2, &cerr)) return fail(WV_E_COMM, cerr);
+                    ready = (int)words[0];
+                    mine = 2 - (int)words[1];
+                }
+                if (ready) singles_first = mine;
             }
+            if (singles_first < 0 && (rc = batch_pair_vetoed())) return rc;
             const bool pairs = singles_first >= 0;
             auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
             auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
@@ -176,8 +190,7 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
                 }
             }
         }
-        int rc = collect_batch(batch);
-        if (rc) return rc;
+        if ((rc = collect_batch(batch))) return rc;
         uint64_t good = 0;
         if ((rc = commit_batch(batch, flags_host_, &good, &flag))) return rc;
         completed += good;

@@ -525,18 +525,49 @@ int Engine<Real>::enqueue_batch_pair(uint64_t i, int part, int next_kind) {
                      : enqueue_pair_b((int)i, signal_pos_ + i, batch_source_live_, batch_can_fuse_ ? next_kind : 0);
 }
 
-// Would this engine take two-step passes in the batch being planned?  *singles_first = -1: no;
-// otherwise the number of single steps (full sweeps) that must come first because a caller wrote
-// into outside nodes (0, 1 or 2).  Decided per batch, and by all slabs of a chain together: they
-// must agree, or their exchanges would not pair up.
+// Would this engine take two-step passes in the batch being planned?  Costs nothing (no allocation, no device work).
 template <typename Real>
-int Engine<Real>::batch_pairs_ready(int* singles_first) {
+int Engine<Real>::batch_pair_eligible(int* eligible) {
     DeviceGuard guard(device_);
-    *singles_first = -1;
-    if (!pair_eligible()) return WV_OK;
+    *eligible = pair_eligible() ? 1 : 0;
+    return WV_OK;
+}
+
+// ... then, once every slab of the chain is eligible: spare fields, pair map, lists (ensure_pair).  *ready = 0 when that
+// did not work out here (no memory for four fields; a sparse room where the march's live units cost more than the
+// sweep's live tiles); *singles_first = single full sweeps needed first because a caller wrote into outside nodes.
+template <typename Real>
+int Engine<Real>::batch_pair_prepare(int* ready, int* singles_first) {
+    DeviceGuard guard(device_);
+    *ready = 0;
+    *singles_first = 0;
     const int rc = ensure_pair();
     if (rc) return rc;
-    if (!pair_failed_ && (opt_.tuning.pair > 0 || pair_sparse_ok_)) *singles_first = outside_dirty_;
+    if (!pair_failed_ && (opt_.tuning.pair > 0 || pair_sparse_ok_)) {
+        *ready = 1;
+        *singles_first = std::min(outside_dirty_, 2);
+    }
+    return WV_OK;
+}
+
+// The chain (or this engine alone) stays with single steps: two spare fields are a third of a slab's memory.
+template <typename Real>
+int Engine<Real>::batch_pair_vetoed() {
+    DeviceGuard guard(device_);
+    bool any = false;
+    for (int i = 0; i < 2; ++i) any = any || field_[spare_[i]] != nullptr;
+    if (!any) return WV_OK;
+    WV_HIP(hipStreamSynchronize(stream_));
+    WV_HIP(hipStreamSynchronize(comm_stream_));
+    for (int i = 0; i < 2; ++i) {
+        Real*& f = field_[spare_[i]];
+        if (f) (void)hipFree(f);
+        f = nullptr;
+    }
+    if (comm_) {
+        void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
+        comm_->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
+    }
     return WV_OK;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
     "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
-    "wv_comm_destroy", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
+    "wv_comm_destroy", "wv_comm_use_library", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
     "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_hrtf_attenuation", "wv_hrtf_ear_position",
@@ -473,6 +473,13 @@ class Engine:
         buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
         _check(load_library().wv_comm_unique_id(buf))
         return bytes(buf)
+
+    @staticmethod
+    def comm_use_library(path):
+        """wv_comm_use_library: resolve the RCCL entry points in exactly this shared library (before any communicator)."""
+        lib = load_library()
+        lib.wv_comm_use_library.argtypes = [C.c_char_p]
+        _check(lib.wv_comm_use_library(path.encode() if path else None))
 
     def comm_init(self, id_bytes, rank, nranks):
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(id_bytes)
