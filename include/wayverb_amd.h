@@ -107,7 +107,7 @@ typedef struct wv_tuning {
     int32_t graph;            /* 1: batches of single steps on small meshes are replayed as a hipGraph */
     int32_t boundary_lds;     /* 1: boundary workgroups stage the coefficient sets in LDS (<= 256 sets) */
     int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
-    int32_t boundary_merge;   /* 1: one boundary launch per two-step pass does both time levels of the wall nodes it can */
+    int32_t boundary_xwall;   /* 1: in two-step passes the wall nodes that face along x work on compact copies of what they would gather from the fields */
     int32_t slab_march_faces; /* 1: on a slab the march also produces the face planes' first level (fewer launches per pass) */
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
     int32_t reserved_[7];
@@ -218,6 +218,12 @@ int wv_enable_kernel_timing(wv_engine* e, int enable);
  * by HBM bytes the engine advances TWO steps per pass over the fields (pair_kernels.hip.h; results are
  * bit-identical to single steps), so a launch of the dominant kernel may stand for two steps. */
 int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uint64_t* steps);
+/* What the engine is doing, for tests and tools (never needed to use it): *value receives
+ *   WV_QUERY_PASSES          two-step passes taken since creation
+ *   WV_QUERY_XWALL_ENTRIES   wall nodes that work on compact copies in two-step passes right now (0: none / not in use)
+ *   WV_QUERY_FIELDS          pressure fields allocated (2, or 4 once two-step passes have been taken) */
+enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2 };
+int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);
 /* Tuning hook for the streaming kernel.  variant 2 = plane sweep, 0 = register z-march, 1 = naive.

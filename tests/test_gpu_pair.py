@@ -368,3 +368,61 @@ def test_rows_longer_than_one_workgroup(oracle, dims, tag):
     _same(got, want)
     set_tuning(pair=1, pair_wide=0)          # without the WIDE march such rows fall back to single steps: same bits
     _same(run_engine(case, tag), want)
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+@pytest.mark.parametrize("dims,src_x,expect_active", [((34, 19, 21), 12, True), ((34, 19, 21), 4, True), ((34, 19, 21), 3, False),
+                                                      ((6, 17, 18), 2, False), ((5, 12, 11), 2, False), ((140, 12, 14), 70, True)])
+def test_x_facing_walls_on_compact_copies(oracle, dims, src_x, expect_active, tag, dtype):
+    """Two-step passes keep the wall nodes that face along x on compact copies of what they would gather from the
+    fields (boundary_kernels.hip.h, xwall_node): same bits as the gathers (boundary_xwall = 0) and as the oracle --
+    fields from noise, all filter memories, receivers ON x-facing wall nodes, on the nodes they face and behind those;
+    a source two nodes from the wall switches the copies off (level 1 would capture the faced node's t+1 value before
+    the sample goes in), three nodes away they stay on; a room three nodes thick (the node behind the faced node is the
+    opposite wall) has no eligible entry; runs interleaved with single steps and a caller's writes rebuild the copies."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(nx * 1000 + src_x)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2), np.array([M.flat_coefficients(0.2)], dtype=M.coefficients_dtype)])
+    mesh = M.box_mesh(nx, ny, nz, coefficients=coeffs, surface_of_face=[0, 1, 2, 0, 1, 2])
+    ci = mesh.compute_index
+    live = mesh.nodes["boundary_type"] != 0
+    init = [np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0) for _ in range(2)]
+    steps = 37                                   # odd: the batch ends on a single step, the next run regathers
+    sig = rng.uniform(-0.2, 0.2, 2 * steps)
+    src = ci(src_x, ny // 2, nz // 2)
+    recv = [ci(1, 5, 6), ci(2, 5, 6), ci(min(3, nx - 2), 5, 6), ci(nx - 2, 7, 4), ci(nx - 3, 7, 4), ci(1, 2, 2), ci(1, ny - 3, nz - 3), src]
+    case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_SOFT, source_node=src, signal=sig[:steps], recv=recv, init=init)
+    want = run_oracle(oracle, case, dtype, threads=2)
+    runs = {}
+    for xwall in (1, 0):
+        set_tuning(pair=1, boundary_xwall=xwall)
+        eng = E.Engine(mesh, precision=tag)
+        try:
+            eng.write_field(init[0].astype(dtype), E.BUF_PREVIOUS)
+            eng.write_field(init[1].astype(dtype), E.BUF_CURRENT)
+            done, out = E.run_fast(eng, E.SOURCE_SOFT, src, sig[:steps], recv)
+            assert done == steps and eng.query(E.Engine.QUERY_PASSES) == (steps - 2) // 2
+            active = eng.query(E.Engine.QUERY_XWALL_ENTRIES)
+            assert (active > 0) == (expect_active and xwall == 1), active
+            if expect_active and xwall:
+                assert active == 2 * (ny - 4) * (nz - 4)
+            runs[xwall] = dict(trace=out.astype(dtype), current=eng.read_field(E.BUF_CURRENT), previous=eng.read_field(E.BUF_PREVIOUS),
+                               bd=[eng.read_boundary_data(d) for d in (1, 2, 3)])
+            # on from there: a value written next to a wall, a step driven from outside, more passes
+            eng.write_value(ci(2, 6, 6), 0.125)
+            eng.step()
+            eng.swap()
+            eng.set_source(E.SOURCE_HARD, src, sig[steps:])
+            done2, _ = eng.run_steps(steps)
+            runs[xwall]["later"] = (done2, eng.read_field(E.BUF_CURRENT), [eng.read_boundary_data(d) for d in (1, 2, 3)])
+        finally:
+            eng.close()
+    for got in runs.values():
+        assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8)), "receiver traces differ"
+        assert got["current"].tobytes() == want["current"].tobytes() and got["previous"].tobytes() == want["previous"].tobytes()
+        for a, b in zip(got["bd"], want["bd"]):
+            assert a.tobytes() == b.tobytes()
+    a, b = runs[1]["later"], runs[0]["later"]
+    assert a[0] == b[0] == steps and a[1].tobytes() == b[1].tobytes()
+    for x, y in zip(a[2], b[2]):
+        assert x.tobytes() == y.tobytes()

@@ -58,6 +58,78 @@ __global__ void __launch_bounds__(64) filter_test_2_kernel(const float* input, f
     for (int j = 0; j < 6; ++j) memory[(size_t)f * 6 + j] = m[j];
 }
 
+// The arithmetic of one boundary node (program.cpp:331-387 with ghost_point_pressure_update, :150-174), from values
+// already loaded: nb = `cur` at -/+ along x, y, z, off = which of those lie off the grid, prev = the node's own old
+// value, m / cf = its filters' memories and coefficient sets.  Returns the node's new value; the memories are
+// advanced in place.  Shared by every way of loading (boundary_node, xwall_node) so that they cannot differ by a bit.
+template <typename Real, int D>
+__device__ __forceinline__ Real boundary_value(Real courant, Real courant_sq, uint32_t dirs, const Real (&nb)[3][2],
+                                               const bool (&off)[3][2], Real prev, double (&m)[D][6],
+                                               const double* const (&cf)[D]) {
+    // 2 * inner pressures, x before y before z (program.cpp:19-87, :268-276)
+    Real sum = 0;
+    bool inner_axis[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
+        inner_axis[ax] = has_n || has_p;
+        const Real p = has_p ? (off[ax][1] ? Real(0) : nb[ax][1]) : (off[ax][0] ? Real(0) : nb[ax][0]);
+        const Real with = sum + 2 * p;
+        sum = inner_axis[ax] ? with : sum;
+    }
+    // un-doubled in-plane / along-edge neighbours, lower axis first, n before p
+    // (program.cpp:112-143, :178-227); off-grid ends the sum at 0 (statically flagged at create)
+    Real surr = 0;
+    if (D < 3) {
+        bool ok = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool take = !inner_axis[ax] && ok;
+                const Real with = surr + nb[ax][s];
+                surr = take ? (off[ax][s] ? Real(0) : with) : surr;
+                ok = ok && !(take && off[ax][s]);
+            }
+        }
+    }
+    const Real csw = courant_sq * (sum + surr);
+
+    Real facc = 0, cacc = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) facc = (Real)((double)facc + m[i][0] / cf[i][0]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) cacc = (Real)((double)cacc + cf[i][7] / cf[i][0]);
+    const Real fw = courant_sq * facc;
+    const Real cw = cacc * courant;
+    const Real pw = (cw - 1) * prev;
+    const Real next = (csw + fw + pw) / (1 + cw);
+
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double b0 = cf[i][0], a0 = cf[i][7];
+        const double diff = (a0 * (double)(Real)(prev - next)) / (b0 * (double)courant) + (m[i][0] / b0);
+        filter_step_6(-diff, m[i], cf[i], cf[i] + 7);
+    }
+    return next;
+}
+
+// The 7-point update of an inside node from six loaded neighbours (off-grid ones 0) and its own old value
+// (program.cpp:393-412), in the reference's order.
+template <typename Real>
+__device__ __forceinline__ Real faced_value(const Real (&fnb)[3][2], Real fprev) {
+    Real s = 0;
+    s += fnb[0][0];
+    s += fnb[0][1];
+    s += fnb[1][0];
+    s += fnb[1][1];
+    s += fnb[2][0];
+    s += fnb[2][1];
+    s = div3(s);
+    s -= fprev;
+    return s;
+}
+
 // One boundary node.  Everything it needs from memory is requested before anything is used: all six
 // neighbours of `cur` whatever the node's type (the type only decides which of them enter which sum), its
 // own old value, its filters' memories -- and, in the second launch of a two-step pass, what the inside
@@ -135,51 +207,10 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         fprev = a.prev[fn];
     }
 
-    // ---- the node's new value (program.cpp:331-387) ------------------------------------------------
-    // 2 * inner pressures, x before y before z (program.cpp:19-87, :268-276)
-    Real sum = 0;
-    bool inner_axis[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        const bool has_n = (dirs >> (2 * ax)) & 1u, has_p = (dirs >> (2 * ax + 1)) & 1u;
-        inner_axis[ax] = has_n || has_p;
-        const Real p = has_p ? (off[ax][1] ? Real(0) : nb[ax][1]) : (off[ax][0] ? Real(0) : nb[ax][0]);
-        const Real with = sum + 2 * p;
-        sum = inner_axis[ax] ? with : sum;
-    }
-    // un-doubled in-plane / along-edge neighbours, lower axis first, n before p
-    // (program.cpp:112-143, :178-227); off-grid ends the sum at 0 (statically flagged at create)
-    Real surr = 0;
-    if (D < 3) {
-        bool ok = true;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool take = !inner_axis[ax] && ok;
-                const Real with = surr + nb[ax][s];
-                surr = take ? (off[ax][s] ? Real(0) : with) : surr;
-                ok = ok && !(take && off[ax][s]);
-            }
-        }
-    }
-    const Real csw = a.courant_sq * (sum + surr);
-
-    Real facc = 0, cacc = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) facc = (Real)((double)facc + m[i][0] / cf[i][0]);
-#pragma unroll
-    for (int i = 0; i < D; ++i) cacc = (Real)((double)cacc + cf[i][7] / cf[i][0]);
-    const Real fw = a.courant_sq * facc;
-    const Real cw = cacc * a.courant;
-    const Real pw = (cw - 1) * prev;
-    const Real next = (csw + fw + pw) / (1 + cw);
-
+    // ---- the node's new value, its filters' new memories ---------------------------------------------
+    const Real next = boundary_value<Real, D>(a.courant, a.courant_sq, dirs, nb, off, prev, m, cf);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const double b0 = cf[i][0], a0 = cf[i][7];
-        const double diff = (a0 * (double)(Real)(prev - next)) / (b0 * (double)a.courant) + (m[i][0] / b0);
-        filter_step_6(-diff, m[i], cf[i], cf[i] + 7);
 #pragma unroll
         for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(m[i][j], a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
@@ -189,19 +220,130 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
     // the faced node: 7-point update from the complete t+1 field (program.cpp:393-412, as pair_fixup_kernel
     // does it for the nodes nobody faces)
     if (D == 1 && FIX) {
-        Real s = 0;
-        s += fnb[0][0];
-        s += fnb[0][1];
-        s += fnb[1][0];
-        s += fnb[1][1];
-        s += fnb[2][0];
-        s += fnb[2][1];
-        s = div3(s);
-        s -= fprev;
+        const Real s = faced_value<Real>(fnb, fprev);
         if (fix) {
             bad |= bad_bits(s);
             a.next[fn] = s;
         }
+    }
+}
+
+// ---- walls that face along x: compact copies instead of field gathers -----------------------------------
+// The mesh is x-fastest, so a wall node at (1, y, z) owns a 128-byte line of every field it touches and uses 8-24
+// bytes of it; its in-wall neighbours (1, y+-1, z), (1, y, z+-1) each sit in a line of their own.  boundary_node's
+// gathers cost such a node 2.4 whole lines in the first launch of a two-step pass and 6 in the second (PMC, round 2),
+// where a node of a y- or z-facing wall moves little more than its algorithmic 168 B.  So in two-step passes the
+// 1-D entries that face along x (in the marched planes; the first xw_n positions of the entry list, engine_setup)
+// keep what they would gather in compact arrays indexed by entry position -- neighbours are then +-1 / +-8 positions
+// away in brick order -- and touch the fields for exactly what must cross between wall and march:
+//   level 1 (t-1, t -> t+1)  reads one line of the t+1 field: the faced node's value (the march's output) and the node
+//                            behind it; writes its own t+1 value into that line
+//   level 2 (t, t+1 -> t+2)  reads no field at all; writes its own and the faced node's t+2 values (one line)
+// xw_a / xw_b: the wall node's own value at the odd / even time level (t-1 then t+1 / t then t+2, updated in
+// place); xw_f: the faced node at the even level; xw_f1 / xw_g: the faced node and the node behind it at t+1, captured
+// by level 1 for level 2.  xw_nbr[k][pos], k = y-, y+, z-, z+: position of that in-wall neighbour if it is one of these
+// entries (bit 31: it faces the same way, so ITS faced node is the lateral neighbour of mine), else XW_FIELD: read the
+// field as boundary_node would.  Same arithmetic (boundary_value / faced_value), same results.
+constexpr uint32_t XW_FIELD = 0xFFFFFFFFu, XW_SAME_FACING = 0x80000000u;
+
+template <typename Real, int LEVEL>
+__device__ __forceinline__ void xwall_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t pos_e, int& bad) {
+    const uint32_t idx = a.bnode[pos_e];
+    const uint32_t dirs = a.btype[pos_e];  // 1: inner node at x-1, 2: at x+1
+    const int x = (int)(idx % (uint32_t)a.pitch);
+    const uint32_t q = idx / (uint32_t)a.pitch;
+    const int y = (int)(q % (uint32_t)a.ny);
+    const int z = (int)(q / (uint32_t)a.ny);
+    const int64_t plane = (int64_t)a.pitch * a.ny;
+    const int64_t stride[3] = {1, a.pitch, plane};
+    const int pos[3] = {x, y, z};
+    const int lim[3] = {a.nx, a.ny, a.nz};
+    const int step = (dirs & 2u) ? 1 : -1;
+    const int64_t fn = (int64_t)idx + step;  // the faced node: in the grid (xwall_eligible_kernel)
+    const bool far_off = x + 2 * step < 0 || x + 2 * step >= a.nx;
+
+    // ---- loads -----------------------------------------------------------------------------------
+    uint32_t ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ref[k] = a.xw_nbr[(size_t)k * a.xw_n + pos_e];
+    const Real* level = LEVEL == 1 ? a.xw_b : a.xw_a;  // wall values at the time level the neighbours are read at
+    Real nb[3][2];
+    bool off[3][2];
+    off[0][0] = x - 1 < 0;
+    off[0][1] = x + 1 >= a.nx;
+    nb[0][0] = nb[0][1] = LEVEL == 1 ? a.xw_f[pos_e] : a.xw_f1[pos_e];  // (only the inner side enters the sums)
+    bool any_field = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ax = 1 + (k >> 1), s = k & 1;
+        const int c = pos[ax] + (s ? 1 : -1);
+        off[ax][s] = c < 0 || c >= lim[ax];
+        const bool mirrored = ref[k] != XW_FIELD;
+        nb[ax][s] = level[mirrored ? (ref[k] & ~XW_SAME_FACING) : pos_e];
+        any_field = any_field || !mirrored;
+    }
+    const Real prev = LEVEL == 1 ? a.xw_a[pos_e] : a.xw_b[pos_e];
+    double m[1][6];
+    const double* cf[1];
+    cf[0] = coeffs + (size_t)a.cidx[pos_e] * 14;  // (1-D entries: slot = position)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m[0][j] = __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + pos_e);
+    // level 1: what level 2 will want of the t+1 field (a.next), both in this node's line
+    Real f1 = 0, far1 = 0;
+    // level 2: the faced node's update
+    Real fnb[3][2], fprev = 0;
+    bool any_lateral_field = false;
+    if (LEVEL == 1) {
+        f1 = a.next[fn];
+        far1 = a.next[fn + (far_off ? 0 : step)];
+        far1 = far_off ? Real(0) : far1;
+    } else {
+        const Real own1 = a.xw_a[pos_e], far = a.xw_g[pos_e];
+        fnb[0][0] = step > 0 ? own1 : far;
+        fnb[0][1] = step > 0 ? far : own1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            const bool regular = ref[k] != XW_FIELD && (ref[k] & XW_SAME_FACING);
+            const Real v = a.xw_f1[regular ? (ref[k] & ~XW_SAME_FACING) : pos_e];
+            fnb[ax][s] = off[ax][s] ? Real(0) : v;  // (the faced node's y, z are this node's)
+            any_lateral_field = any_lateral_field || (!regular && !off[ax][s]);
+        }
+        fprev = a.xw_f[pos_e];
+    }
+    // the wall's rim, walls that meet other things than walls: those neighbours come from the fields
+    if (any_field) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            if (ref[k] == XW_FIELD) nb[ax][s] = a.cur[(int64_t)idx + (off[ax][s] ? 0 : (s ? stride[ax] : -stride[ax]))];
+        }
+    }
+    if (LEVEL == 2 && any_lateral_field) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            const bool regular = ref[k] != XW_FIELD && (ref[k] & XW_SAME_FACING);
+            if (!regular && !off[ax][s]) fnb[ax][s] = a.cur[fn + (s ? stride[ax] : -stride[ax])];
+        }
+    }
+
+    // ---- the node's new value, its filter's new memories; stores -----------------------------------------
+    const Real next = boundary_value<Real, 1>(a.courant, a.courant_sq, dirs, nb, off, prev, m, cf);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(m[0][j], a.fmem + (size_t)j * a.n_slots + pos_e);
+    bad |= bad_bits(next);
+    a.next[idx] = next;
+    if (LEVEL == 1) {
+        a.xw_a[pos_e] = next;
+        a.xw_f1[pos_e] = f1;
+        a.xw_g[pos_e] = far1;
+    } else {
+        const Real s2 = faced_value<Real>(fnb, fprev);
+        bad |= bad_bits(s2);
+        a.next[fn] = s2;
+        a.xw_b[pos_e] = next;
+        a.xw_f[pos_e] = s2;
     }
 }
 
@@ -240,13 +382,70 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
     const double* coeffs = LDSC ? s_coeffs : a.coeffs;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     int bad = 0;
-    if (a.order) {
+    if (a.xw_n) {
+        // two-step pass: the first xw_n entries (x-facing walls) by their compact copies, whole workgroups of them
+        // first; then everything else as ever (FIX = this is the pass's second launch = level 2)
+        if (t < a.xw_pad) {
+            if (t < a.xw_n) xwall_node<Real, FIX ? 2 : 1>(a, coeffs, t, bad);
+        } else if (a.order) {
+            if (t - a.xw_pad < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t - a.xw_pad], bad);
+        } else {
+            boundary_entry<Real, FIX>(a, coeffs, a.xw_n + (t - a.xw_pad), bad);
+        }
+    } else if (a.order) {
         if (t < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t], bad);
     } else {
         boundary_entry<Real, FIX>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
     if (next.fused && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
+}
+
+// Which 1-D entries may live on compact copies (xwall_node): facing along x, in the planes the march produces, the
+// faced node an inside node of the grid, and the node behind it not a boundary node (level 1 reads its t+1 value
+// while other lanes of the same launch are still writing theirs).  One thread per 1-D entry, before the engine
+// settles the entries' processing order (engine_setup.hip.h).
+struct XwEligibleArgs {
+    const uint32_t* bnode;
+    const uint8_t* btype;
+    const uint8_t* cls;
+    uint8_t* eligible;  // [n1]
+    uint32_t n1;
+    int nx, ny, nz, pitch, cls_pitch;
+    int march_begin, march_end;
+};
+
+__global__ void __launch_bounds__(256) xwall_eligible_kernel(const XwEligibleArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n1) return;
+    const uint32_t idx = a.bnode[e];
+    const uint32_t dirs = a.btype[e] & 0x3Fu;
+    bool ok = idx != INVALID_NODE && (dirs == 1u || dirs == 2u);
+    if (ok) {
+        const int x = (int)(idx % (uint32_t)a.pitch);
+        const uint32_t q = idx / (uint32_t)a.pitch;
+        const int y = (int)(q % (uint32_t)a.ny), z = (int)(q / (uint32_t)a.ny);
+        const int step = dirs == 2u ? 1 : -1;
+        auto cls_at = [&](int xx) -> uint32_t {
+            return (a.cls[cls_byte_index(xx, y, z, a.ny, a.cls_pitch)] >> ((xx & 3) * 2)) & 3u;
+        };
+        ok = z >= a.march_begin && z < a.march_end && x + step >= 0 && x + step < a.nx && cls_at(x + step) == CLS_INSIDE;
+        if (ok && x + 2 * step >= 0 && x + 2 * step < a.nx) ok = cls_at(x + 2 * step) != CLS_BOUNDARY;
+    }
+    a.eligible[e] = ok ? 1 : 0;
+}
+
+// (Re)fill the compact copies from the fields: a.prev / a.cur = fields t-1 / t.  After anything but a two-step pass has
+// touched the fields (a caller's write, single steps), before the next pass.
+template <typename Real>
+__global__ void __launch_bounds__(256) xwall_gather_kernel(const BoundaryArgs<Real> a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.xw_n) return;
+    const uint32_t idx = a.bnode[p];
+    const int64_t fn = (int64_t)idx + ((a.btype[p] & 2u) ? 1 : -1);
+    a.xw_a[p] = a.prev[idx];
+    a.xw_b[p] = a.cur[idx];
+    a.xw_f[p] = a.cur[fn];
 }
 
 // ---- source injection + receiver gather: the pre/post callbacks, device resident -------------

@@ -134,6 +134,11 @@ struct BoundaryArgs {
     // Its cache lines are the ones the entry touches anyway (boundary_kernel<.., FIX = true>; pair_kernels.hip.h,
     // pair_map_kernel).
     int fix_z0, fix_z1;
+    // Two-step passes, x-facing walls on compact copies (boundary_kernels.hip.h, xwall_node): the first xw_n entries;
+    // xw_pad = xw_n rounded up to whole workgroups; 0 = every entry gathers from the fields.
+    uint32_t xw_n, xw_pad;
+    const uint32_t* xw_nbr;                  // [4][xw_n]
+    Real *xw_a, *xw_b, *xw_f, *xw_f1, *xw_g;  // [xw_n] each
 };
 
 template <typename Real>

@@ -54,7 +54,7 @@ void wv_default_options(wv_options* o) {
     t.graph = 0;
     t.boundary_lds = 1;
     t.boundary_order = 1;
-    t.boundary_merge = 1;
+    t.boundary_xwall = 1;
     t.slab_march_faces = 1;
 }
 
@@ -71,7 +71,7 @@ static void tuning_from_environment(wv_options* o) {
                           {"WV_PAIR_WIDE", &t.pair_wide}, {"WV_PAIR_UNIT_WAVES", &t.pair_unit_waves},
                           {"WV_PAIR_UNIT_PLANES", &t.pair_unit_planes}, {"WV_TILE_LISTS", &t.tile_lists},
                           {"WV_FUSE_PRE_POST", &t.fuse_pre_post}, {"WV_GRAPH", &t.graph}, {"WV_BOUNDARY_LDS", &t.boundary_lds},
-                          {"WV_BOUNDARY_ORDER", &t.boundary_order}, {"WV_BOUNDARY_MERGE", &t.boundary_merge},
+                          {"WV_BOUNDARY_ORDER", &t.boundary_order}, {"WV_BOUNDARY_XWALL", &t.boundary_xwall},
                           {"WV_SLAB_MARCH_FACES", &t.slab_march_faces}, {"WV_STREAM_VARIANT", &o->stream_variant},
                           {"WV_STREAM_RY", &t.stream_ry}, {"WV_STREAM_NWX", &t.stream_nwx}, {"WV_STREAM_NWY", &t.stream_nwy},
                           {"WV_STREAM_ZCHUNKS", &t.stream_zchunks}};
@@ -193,6 +193,10 @@ int wv_enable_kernel_timing(wv_engine* e, int enable) {
     WV_NEED(e);
     e->timing = enable != 0;
     return WV_OK;
+}
+int wv_query(wv_engine* e, int what, uint64_t* value) {
+    WV_NEED(e);
+    return e->query(what, value);
 }
 int wv_synchronize(wv_engine* e) {
     WV_NEED(e);

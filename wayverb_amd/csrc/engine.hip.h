@@ -51,6 +51,8 @@ public:
     static void parallel_sort(std::vector<uint64_t>& v);
     int enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live, bool fuse_mid);
     int launch_fixup(uint32_t first, uint32_t n, const Real* t1, const Real* cur, Real* out2, int* flag2);
+    int build_xwall();
+    void xwall_args(wv::BoundaryArgs<Real>& b) const;
     int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
     int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
     int batch_pair_eligible(int* eligible) override;
@@ -99,6 +101,7 @@ public:
     // ---- engine_batch.hip.h
     int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) override;
     int synchronize() override;
+    int query(int what, uint64_t* value) override;
     // ---- engine_slab.hip.h
     int comm_init(const void* id, int rank, int nranks) override;
     int comm_init_local(int rank, int nranks) override;
@@ -178,9 +181,18 @@ private:
     uint8_t* btype_ = nullptr;
     double* fmem_ = nullptr;
     uint32_t* cidx_ = nullptr;
-    // boundary entries by plane (build_plane_order; slab path only)
+    // boundary entries by plane (build_plane_order; slab path only); `_rest`: without the first n_xw_ entries
     uint32_t* zorder_ = nullptr;
-    std::vector<uint32_t> plane_start_;
+    uint32_t* zorder_rest_ = nullptr;  // (same allocation as zorder_)
+    std::vector<uint32_t> plane_start_, plane_start_rest_;
+    // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
+    uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)
+    uint32_t* xw_nbr_ = nullptr;   // [4][n_xw_] in-wall neighbours by entry position
+    Real* xw_val_ = nullptr;       // [5][n_xw_]: own value at the odd / even level, faced node, and level 1's captures
+    bool xw_built_ = false;        // table and copies allocated (first ensure_pair that may use them)
+    bool xw_active_ = false;       // this (mesh, source) runs its passes on them
+    bool xw_valid_ = false;        // the copies hold what the fields hold
+    uint64_t passes_taken_ = 0;
     int* status_ = nullptr;
     int* static_flag_dev_ = nullptr;
     int static_flag_ = 0;

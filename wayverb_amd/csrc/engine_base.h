@@ -88,6 +88,7 @@ struct wv_engine {
     virtual int fetch_receivers(uint64_t first, uint64_t n, double* dst) = 0;
     virtual int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) = 0;
     virtual int synchronize() = 0;
+    virtual int query(int what, uint64_t* value) = 0;
     virtual int set_tuning(int variant, int ry, int nwx, int nwy, int zchunks) = 0;
     virtual int comm_init(const void* id, int rank, int nranks) = 0;
     virtual int comm_init_local(int rank, int nranks) = 0;

@@ -46,6 +46,7 @@ int Engine<Real>::step(int32_t* flag) {
 template <typename Real>
 int Engine<Real>::swap() {
     std::swap(cur_, prv_);
+    xw_valid_ = false;
     ++steps_done;
     // a step driven from outside (wv_step / wv_swap) records no receiver samples: its row of the log is NaN,
     // so that wv_fetch_receivers keeps addressing rows by step
@@ -124,6 +125,7 @@ int Engine<Real>::commit_batch(uint64_t batch, const int* flags, uint64_t* good_
     // fields have advanced past a failing step: like the reference after its throw, the state is
     // no longer meaningful; keep the buffer roles consistent with `good` swaps
     if (flag && good < batch && ((batch - good) & 1)) std::swap(cur_, prv_);
+    if (flag) xw_valid_ = false;
     *good_out = good;
     *flag_out = flag;
     return WV_OK;
@@ -211,6 +213,22 @@ int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* ste
     timed_steps_ = 0;
     timing_launches_ = 0;  // the next launch is timed again
     return WV_OK;
+}
+
+template <typename Real>
+int Engine<Real>::query(int what, uint64_t* value) {
+    if (!value) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+    switch (what) {
+        case WV_QUERY_PASSES: *value = passes_taken_; return WV_OK;
+        case WV_QUERY_XWALL_ENTRIES: *value = xw_active_ ? n_xw_ : 0; return WV_OK;
+        case WV_QUERY_FIELDS: {
+            uint64_t n = 0;
+            for (int i = 0; i < 4; ++i) n += field_[i] != nullptr;
+            *value = n;
+            return WV_OK;
+        }
+        default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
+    }
 }
 
 template <typename Real>

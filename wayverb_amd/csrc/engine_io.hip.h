@@ -180,6 +180,7 @@ int Engine<Real>::write_value(int buffer_id, uint64_t index, double v) {
         WV_HIP(class_of(index % (uint64_t)nx_, index / (uint64_t)nx_, &cls));
         if (cls == wv::CLS_NONE) outside_dirty_ = 2;
     }
+    xw_valid_ = false;
     WV_HIP(hipMemcpyAsync(buffer(buffer_id) + stored_index(index), &tmp, sizeof(Real), hipMemcpyHostToDevice, stream_));
     WV_HIP(hipStreamSynchronize(stream_));
     return WV_OK;
@@ -233,6 +234,7 @@ int Engine<Real>::write_planes(int buffer_id, int z0, int planes, const void* sr
     if (!planes) return WV_OK;
     if (!src) return fail(WV_E_INVALID_ARGUMENT, "null argument");
     outside_dirty_ = std::max(outside_dirty_, 2);  // the caller may have put anything in the outside nodes
+    xw_valid_ = false;
     if (elem_size == 4) return copy_field<float>(buffer(buffer_id), const_cast<void*>(src), true, z0, planes);
     if (elem_size == 8) return copy_field<double>(buffer(buffer_id), const_cast<void*>(src), true, z0, planes);
     return fail(WV_E_INVALID_ARGUMENT, "elem_size must be 4 or 8");
@@ -290,6 +292,7 @@ int Engine<Real>::set_coefficients(const wv_coefficients_canonical* c, uint32_t 
 template <typename Real>
 int Engine<Real>::device_buffer(int buffer_id, void** p) {
     outside_dirty_ = 1 << 30;  // raw access: stop assuming anything about the outside nodes
+    xw_valid_ = false;
     *p = buffer(buffer_id);
     return WV_OK;
 }

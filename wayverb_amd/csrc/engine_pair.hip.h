@@ -21,6 +21,10 @@ bool Engine<Real>::pair_eligible() {
     // (rows of more than kPairMaxWaves waves are shared by several workgroups: the WIDE march, up to 50 waves)
     const int max_waves = opt_.tuning.pair_wide ? wv::kPairMaxWindows * (wv::kPairMaxWaves - 2) + 2 : wv::kPairMaxWaves;
     if (plan_.variant != 2 || pitch_ > max_waves * WX || outside_dirty_ > 2) return false;
+    // a sparse room in which the march's live units cost more than the sweep's live tiles (found by ensure_pair for
+    // this very source): asked once, not before every batch
+    const uint64_t src = source_kind_ != WV_SOURCE_NONE ? source_node_ : ~0ull;
+    if (opt_.tuning.pair < 0 && pair_map_ && pair_source_ == src && !pair_sparse_ok_) return false;
     if (opt_.tuning.pair < 0) {
         // Measured (profiles/r02/pair_vs_single_small_meshes.txt), fp64, Gnode-updates/s single / two-step:
         // 96^3 55 / 35, 128^3 96 / 72 (launches, not bytes), 160^3 86 / 101, 192^3 115 / 134, 256^3 191 / 205,
@@ -37,7 +41,7 @@ bool Engine<Real>::pair_eligible() {
 template <typename Real>
 int Engine<Real>::ensure_pair() {
     const uint64_t src = source_kind_ != WV_SOURCE_NONE ? source_node_ : ~0ull;
-    if (pair_map_ && pair_source_ == src) return WV_OK;
+    // (the spare fields first: a veto may have given them back -- batch_pair_vetoed -- while the map stayed)
     for (int i = 0; i < 2; ++i) {
         Real*& f = field_[spare_[i]];
         if (!f) {
@@ -54,6 +58,7 @@ int Engine<Real>::ensure_pair() {
         void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
         comm_->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
     }
+    if (pair_map_ && pair_source_ == src) return WV_OK;
     const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
     if (!pair_map_) {
         WV_HIP(hipMalloc((void**)&pair_map_, cls_bytes + 16));
@@ -148,6 +153,28 @@ int Engine<Real>::ensure_pair() {
         WV_HIP(hipMemcpy(pair_list_, list.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     pair_source_ = src;
+    // x-facing walls on compact copies: needs entries that finish the nodes they face, and a source that is neither a
+    // boundary node nor within two nodes of a wall along x -- level 1 captures the t+1 values of the faced node and
+    // of the node behind it before step t+1's sample goes in (boundary_kernels.hip.h, xwall_node)
+    xw_active_ = false;
+    if (n_xw_ && pair_inner_ok_ > 0) {
+        bool source_clear = true;
+        if (source_kind_ != WV_SOURCE_NONE) {
+            const int64_t sx = (int64_t)(source_node_ % (uint64_t)pitch_), row = (int64_t)(source_node_ / (uint64_t)pitch_);
+            for (int64_t dx = -2; dx <= 2 && source_clear; ++dx) {
+                if (sx + dx < 0 || sx + dx >= pitch_) continue;
+                uint32_t cls = 0;
+                WV_HIP(class_of((uint64_t)(sx + dx), (uint64_t)row, &cls));
+                source_clear = cls != wv::CLS_BOUNDARY;
+            }
+        }
+        if (source_clear) {
+            const int rc = build_xwall();
+            if (rc) return rc;
+            xw_active_ = xw_built_;
+        }
+    }
+    if (!xw_active_) xw_valid_ = false;  // passes that do not maintain the copies leave them behind
     // march geometry: strips of 4 rows, all planes unless there are too few strips to fill the chip
     constexpr int WX = 64 * (16 / (int)sizeof(Real));
     pair_nw_ = pitch_ / WX;
@@ -320,6 +347,67 @@ int Engine<Real>::build_pair_units(int owned) {
     return WV_OK;
 }
 
+// In-wall neighbours of the first n_xw_ entries by entry position, and the compact copies themselves.  Once per mesh.
+template <typename Real>
+int Engine<Real>::build_xwall() {
+    if (xw_built_) return WV_OK;
+    const uint32_t n = n_xw_;
+    std::vector<uint32_t> bnode(n);
+    std::vector<uint8_t> btype(n);
+    WV_HIP(hipMemcpy(bnode.data(), bnode_, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    WV_HIP(hipMemcpy(btype.data(), btype_, (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> by_node(n);  // (stored node index, position), sorted: who lives where
+    for (uint32_t p = 0; p < n; ++p) by_node[p] = ((uint64_t)bnode[p] << 32) | p;
+    parallel_sort(by_node);
+    std::vector<uint32_t> nbr((size_t)4 * n, wv::XW_FIELD);
+    const int64_t stride[2] = {pitch_, (int64_t)pitch_ * ny_};
+    const int lim[2] = {ny_, nz_};
+    auto fill = [&](uint32_t first, uint32_t last) {
+        for (uint32_t p = first; p < last; ++p) {
+            const uint32_t idx = bnode[p];
+            const uint32_t q = idx / (uint32_t)pitch_;
+            const int at[2] = {(int)(q % (uint32_t)ny_), (int)(q / (uint32_t)ny_)};
+            for (int k = 0; k < 4; ++k) {
+                const int ax = k >> 1, c = at[ax] + ((k & 1) ? 1 : -1);
+                if (c < 0 || c >= lim[ax]) continue;
+                const uint64_t want = (uint64_t)((int64_t)idx + ((k & 1) ? stride[ax] : -stride[ax])) << 32;
+                const auto it = std::lower_bound(by_node.begin(), by_node.end(), want);
+                if (it == by_node.end() || (*it >> 32) != (want >> 32)) continue;  // not one of these entries: from the field
+                const uint32_t other = (uint32_t)*it;
+                nbr[(size_t)k * n + p] = other | (btype[other] == btype[p] ? wv::XW_SAME_FACING : 0u);
+            }
+        }
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < (1u << 16) || hw < 2) {
+        fill(0, n);
+    } else {
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < hw; ++t)
+            workers.emplace_back(fill, (uint32_t)((uint64_t)n * t / hw), (uint32_t)((uint64_t)n * (t + 1) / hw));
+        for (auto& w : workers) w.join();
+    }
+    WV_HIP(hipMalloc((void**)&xw_nbr_, nbr.size() * sizeof(uint32_t)));
+    WV_HIP(hipMemcpy(xw_nbr_, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    WV_HIP(hipMalloc((void**)&xw_val_, (size_t)5 * n * sizeof(Real)));
+    WV_HIP(hipMemsetAsync(xw_val_, 0, (size_t)5 * n * sizeof(Real), stream_));
+    xw_built_ = true;
+    xw_valid_ = false;
+    return WV_OK;
+}
+
+template <typename Real>
+void Engine<Real>::xwall_args(wv::BoundaryArgs<Real>& b) const {
+    b.xw_n = n_xw_;
+    b.xw_pad = (n_xw_ + 255u) / 256u * 256u;
+    b.xw_nbr = xw_nbr_;
+    b.xw_a = xw_val_;
+    b.xw_b = xw_val_ + (size_t)n_xw_;
+    b.xw_f = xw_val_ + (size_t)2 * n_xw_;
+    b.xw_f1 = xw_val_ + (size_t)3 * n_xw_;
+    b.xw_g = xw_val_ + (size_t)4 * n_xw_;
+}
+
 template <typename Real>
 void Engine<Real>::parallel_sort(std::vector<uint64_t>& v) {
     const size_t n = v.size();
@@ -426,6 +514,12 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     }
     // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
     pair_mid_done_ = pair_list_done_ = false;
+    if (xw_active_ && !xw_valid_) {  // the x-facing walls' compact copies, from fields t-1 and t
+        wv::BoundaryArgs<Real> g = boundary_args(A, B, flag1);
+        xwall_args(g);
+        hipLaunchKernelGGL(wv::xwall_gather_kernel<Real>, dim3(g.xw_pad / 256), dim3(256), 0, stream_, g);
+        xw_valid_ = true;
+    }
     if (fuse_mid && n_entries_ && (n_recv_ || source_live)) {
         // ... and, by its last workgroup, step t+1's source sample / receivers (none of those nodes is a
         // boundary node: they have been final since the march) and then the few listed nodes
@@ -508,6 +602,7 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     }
     WV_HIP(hipGetLastError());
     if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+    ++passes_taken_;
     // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
     const int a_idx = prv_, b_idx = cur_;
     prv_ = spare_[0];

@@ -150,6 +150,32 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
         WV_HIP(hipMemcpy(bnode.data(), bnode_, (size_t)n_entries_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
         WV_HIP(hipMemcpy(btype.data(), btype_, (size_t)n_entries_, hipMemcpyDeviceToHost));
         const uint32_t nd[3] = {n1_, n2_, n3_};
+        // 1-D entries that face along x, in the planes a two-step pass marches, go first: in such passes they work on
+        // compact copies indexed by position instead of gathering from the fields (boundary_kernels.hip.h, xwall_node)
+        std::vector<uint8_t> eligible(std::max<uint32_t>(n1_, 1), 0);
+        if (n1_ && opt_.tuning.boundary_xwall != 0) {
+            ScopedDevice flags_mem;
+            WV_HIP(hipMalloc(&flags_mem.p, n1_));
+            wv::XwEligibleArgs x{};
+            x.bnode = bnode_;
+            x.btype = btype_;
+            x.cls = cls_;
+            x.eligible = static_cast<uint8_t*>(flags_mem.p);
+            x.n1 = n1_;
+            x.nx = nx_;
+            x.ny = ny_;
+            x.nz = nz_;
+            x.pitch = pitch_;
+            x.cls_pitch = cls_pitch_;
+            x.march_begin = z_begin_ + (opt_.ghost_lo ? 1 : 0);
+            x.march_end = z_end_ - (opt_.ghost_hi ? 1 : 0);
+            hipLaunchKernelGGL(wv::xwall_eligible_kernel, dim3((n1_ + 255) / 256), dim3(256), 0, stream_, x);
+            WV_HIP(hipGetLastError());
+            WV_HIP(hipMemcpyAsync(eligible.data(), flags_mem.p, n1_, hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            for (uint32_t k = 0; k < n1_; ++k) n_xw_ += eligible[k];
+            if (n_xw_ >= 0x7FFFFFFFu) n_xw_ = 0;  // (bit 31 of a neighbour reference is a flag)
+        }
         const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
         std::vector<std::pair<uint64_t, uint32_t>> keyed(n_entries_);  // (sort key, entry): ties keep list order
         std::vector<uint32_t> by_pos(n_entries_);
@@ -164,6 +190,7 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
                     const uint64_t brick = ((z >> 3) * bricks_y + (y >> 3)) * bricks_x + (x >> 6);
                     kk = (brick << 12) | ((z & 7) << 9) | ((y & 7) << 6) | (x & 63);
                 }
+                if (!(d == 0 && n_xw_ && eligible[k])) kk |= 1ull << 57;
                 keyed[off + k] = {kk, off + k};
             }
             std::sort(keyed.begin() + off, keyed.begin() + off + nd[d]);
@@ -254,13 +281,24 @@ int Engine<Real>::build_plane_order() {
     std::vector<uint32_t> order(std::max<uint32_t>(plane_start_[nz_], 1)), cursor(plane_start_.begin(), plane_start_.end() - 1);
     for (uint32_t e = 0; e < n_entries_; ++e)
         if (bnode[e] != wv::INVALID_NODE) order[cursor[bnode[e] / plane]++] = e;
+    // the same without the first n_xw_ entries (two-step passes take those by position: launch_boundary)
+    plane_start_rest_.assign((size_t)nz_ + 1, 0);
+    for (uint32_t e = n_xw_; e < n_entries_; ++e)
+        if (bnode[e] != wv::INVALID_NODE) ++plane_start_rest_[bnode[e] / plane + 1];
+    for (int z = 0; z < nz_; ++z) plane_start_rest_[z + 1] += plane_start_rest_[z];
+    std::vector<uint32_t> rest(std::max<uint32_t>(plane_start_rest_[nz_], 1));
+    cursor.assign(plane_start_rest_.begin(), plane_start_rest_.end() - 1);
+    for (uint32_t e = n_xw_; e < n_entries_; ++e)
+        if (bnode[e] != wv::INVALID_NODE) rest[cursor[bnode[e] / plane]++] = e;
     uint32_t* staged = nullptr;
-    WV_HIP(hipMalloc((void**)&staged, order.size() * sizeof(uint32_t)));
-    if (hipMemcpy(staged, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    WV_HIP(hipMalloc((void**)&staged, (order.size() + rest.size()) * sizeof(uint32_t)));
+    if (hipMemcpy(staged, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(staged + order.size(), rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(staged);
         return fail(WV_E_HIP, "copying the plane order of the boundary entries to the device failed");
     }
     zorder_ = staged;
+    zorder_rest_ = staged + order.size();
     return WV_OK;
 }
 
@@ -455,7 +493,7 @@ void Engine<Real>::release() {
     for (int i = 0; i < 4; ++i)
         if (field_[i]) (void)hipFree(field_[i]);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-    void* ptrs[] = {pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+    void* ptrs[] = {pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, xw_nbr_, xw_val_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                     status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -141,14 +141,22 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
         nx = *next;
         nx.fused = 1;
     }
-    uint32_t n = n_entries_;
+    // a two-step pass's launches over the marched planes: the x-facing walls by position, on their compact copies
+    const bool xw = out && xw_active_ && z0 == pair_z0_ && z1 == pair_z1_;
+    uint32_t n = n_entries_ - (xw ? n_xw_ : 0u);
     if (z0 > z_begin_ || z1 < z_end_) {
         const int rc = build_plane_order();
         if (rc != WV_OK) return rc;
-        b.order = zorder_ + plane_start_[z0];
-        b.n_order = plane_start_[z1] - plane_start_[z0];
+        const uint32_t* order = xw ? zorder_rest_ : zorder_;
+        const std::vector<uint32_t>& start = xw ? plane_start_rest_ : plane_start_;
+        b.order = order + start[z0];
+        b.n_order = start[z1] - start[z0];
         n = b.n_order;
-        if (!n) return WV_OK;
+        if (!n && !xw) return WV_OK;
+    }
+    if (xw) {
+        xwall_args(b);
+        n += b.xw_pad;
     }
     const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && opt_.tuning.boundary_lds != 0;
     const dim3 grid((n + 255) / 256), block(256);
@@ -230,6 +238,7 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
     if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     // every plane has been through a full sweep once more: outside nodes of `prev` are 0 now
     if (outside_dirty_ > 0 && outside_dirty_ < (1 << 30)) --outside_dirty_;
+    xw_valid_ = false;  // (a single step moves the fields on without the x-facing walls' compact copies)
     return WV_OK;
 }
 

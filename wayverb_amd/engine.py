@@ -27,7 +27,7 @@ EXPORTS = [
     "wv_read_field", "wv_write_field", "wv_read_planes", "wv_write_planes", "wv_read_boundary_data", "wv_write_boundary_data",
     "wv_set_coefficients", "wv_device_buffer", "wv_step", "wv_swap", "wv_set_source",
     "wv_set_receivers", "wv_run", "wv_fetch_receivers", "wv_step_count", "wv_kernel_time_ms",
-    "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
+    "wv_enable_kernel_timing", "wv_kernel_time_detail", "wv_query", "wv_measure_triad", "wv_synchronize", "wv_comm_unique_id", "wv_comm_init",
     "wv_comm_destroy", "wv_comm_use_library", "wv_comm_init_local", "wv_run_group", "wv_make_box_nodes", "wv_set_stream_tuning", "wv_filter_test_2", "wv_field_pitch", "wv_classify_nodes", "wv_voxelise", "wv_nodes_inside",
     "wv_boundary_index_data", "wv_arbitrary_magnitude_filter", "wv_is_stable", "wv_band_centres",
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
@@ -46,7 +46,7 @@ class WvMesh(C.Structure):
 
 
 TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "tile_lists",
-                 "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_merge", "slab_march_faces",
+                 "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_xwall", "slab_march_faces",
                  "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks")
 
 
@@ -460,6 +460,15 @@ class Engine:
         steps = C.c_uint64()
         _check(self.lib.wv_kernel_time_detail(self.h, C.byref(ms), C.byref(n), C.byref(steps)))
         return ms.value, n.value, steps.value
+
+    QUERY_PASSES, QUERY_XWALL_ENTRIES, QUERY_FIELDS = 0, 1, 2
+
+    def query(self, what):
+        """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
+        self.lib.wv_query.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        v = C.c_uint64()
+        _check(self.lib.wv_query(self.h, what, C.byref(v)))
+        return v.value
 
     def synchronize(self):
         _check(self.lib.wv_synchronize(self.h))
