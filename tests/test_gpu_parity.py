@@ -283,6 +283,91 @@ def test_config2_1024cubed_full_size(oracle, built_library):
                 assert np.any(got_rows != 0) or hi == lo
 
 
+def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library):
+    """BASELINE configs[2] for 64 steps in the engine's own stepping (two single sweeps after the caller's writes, then
+    31 two-step passes with the x-facing walls on their compact copies) against the oracle, bit for bit, without the
+    oracle having to step 2^30 nodes: the start fields are noise inside two thin bands of planes -- against the bottom wall
+    and in mid-mesh -- and zero elsewhere, so after S steps everything further than S planes from a band is still exactly
+    zero and the oracle, run on the window [band - S - 1, band + S + 1) with its cut planes held at zero, IS the solution
+    there (tests/test_gpu_config3.py).  Compared: every plane the bands have reached (both fields), the filter memories
+    of every wall node in those planes, 64 samples of a soft source's neighbourhood (a 7-point directional receiver and a
+    node next to the x = 1 wall); far from both bands the field must still be zero."""
+    from wayverb_amd import engine as E
+    from wayverb_amd.slab import box_slab_mesh
+    n, S = 1024, 64
+    dims = (n, n, n)
+    plane = n * n
+    coeffs = M.bench_materials()
+    bands = [(1, 4), (510, 516)]
+    rng = np.random.default_rng(64)
+    signal = rng.uniform(-0.5, 0.5, S)
+    g = lambda z, y, x: (z * n + y) * n + x   # noqa: E731
+    src = g(512, 500, 333)
+    rc = (513, 501, 340)
+    recv = [g(*rc), g(rc[0], rc[1], rc[2] - 1), g(rc[0], rc[1], rc[2] + 1), g(rc[0], rc[1] - 1, rc[2]), g(rc[0], rc[1] + 1, rc[2]),
+            g(rc[0] - 1, rc[1], rc[2]), g(rc[0] + 1, rc[1], rc[2]), g(512, 300, 2), g(2, 700, 700)]
+
+    def start_planes(a, b):
+        prev, cur = np.zeros((b - a, n, n)), np.zeros((b - a, n, n))
+        for lo, hi in bands:
+            for z in range(max(lo, a), min(hi, b)):
+                r = np.random.default_rng([6464, z])
+                for f in (prev, cur):
+                    f[z - a, 1:n - 1, 1:n - 1] = r.uniform(-0.25, 0.25, (n - 2, n - 2))
+        return prev, cur
+
+    mesh = box_slab_mesh(n, n, n, _Window(dims, 0, n), coefficients=coeffs)
+    eng = E.Engine(mesh, precision="f64")
+    mesh.nodes = None
+    try:
+        for lo, hi in bands:
+            p, c = start_planes(lo, hi)
+            eng.write_planes(lo, p, E.BUF_PREVIOUS)
+            eng.write_planes(lo, c, E.BUF_CURRENT)
+        done, trace = E.run_fast(eng, E.SOURCE_SOFT, src, signal, recv)
+        assert done == S and eng.query(E.Engine.QUERY_PASSES) == (S - 2) // 2 and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
+        for z in (200, 800, 516 + S + 1):
+            for buf in (E.BUF_CURRENT, E.BUF_PREVIOUS):
+                assert not eng.read_planes(z, 1, buf).any(), "plane %d should still be zero" % z
+        bd = [eng.read_boundary_data(d) for d in (1, 2, 3)]
+        threads = os.cpu_count() or 8
+        checked = set()
+        for lo, hi in bands:
+            a, b = max(0, lo - S - 1), min(n, hi + S + 1)
+            w = _Window(dims, a, b)
+            wmesh = box_slab_mesh(n, n, n, w, coefficients=coeffs)
+            o_prev, o_cur = (f.reshape(-1).copy() for f in start_planes(a, b))
+            obd = [wmesh.boundary_data(d) for d in (1, 2, 3)]
+            here = [(pos, node - a * plane) for pos, node in enumerate(recv) if a < node // plane < b - 1]
+            want_trace = np.zeros((S, len(here)))
+            for step in range(S):
+                if a <= src // plane < b:
+                    o_cur[src - a * plane] += signal[step]
+                for col, (_, idx) in enumerate(here):
+                    want_trace[step, col] = o_cur[idx]
+                assert oracle.step_range(o_prev, o_cur, wmesh, obd, w.z0 - a, w.z1 - a, threads=threads) == 0
+                o_prev, o_cur = o_cur, o_prev
+            for col, (pos, _) in enumerate(here):
+                assert trace[:, pos].tobytes() == want_trace[:, col].tobytes(), "receiver %d differs from the oracle" % pos
+                checked.add(pos)
+            z0, z1 = max(w.z0, lo - S), min(w.z1, hi + S)
+            for buf, field in ((E.BUF_CURRENT, o_cur), (E.BUF_PREVIOUS, o_prev)):
+                got = eng.read_planes(z0, z1 - z0, buf)
+                assert np.any(got[-1] != 0) or buf == E.BUF_PREVIOUS
+                assert got.tobytes() == field.reshape(b - a, n, n)[z0 - a:z1 - a].tobytes(), "planes %d..%d differ from the oracle" % (z0, z1 - 1)
+            for d in (1, 2, 3):
+                first = box_boundary_rows_below(n, n, n, w.z0, d)
+                lo_row, hi_row = (box_boundary_rows_below(n, n, n, zz, d) for zz in (z0, z1))
+                got_rows = bd[d - 1][lo_row:hi_row]["filter_memory"]
+                want_rows = obd[d - 1][lo_row - first:hi_row - first]["filter_memory"]
+                assert np.ascontiguousarray(got_rows).tobytes() == np.ascontiguousarray(want_rows).tobytes(), \
+                    "filter memories of planes %d..%d differ (D=%d)" % (z0, z1 - 1, d)
+                assert np.any(got_rows != 0) or hi_row == lo_row
+        assert checked == set(range(len(recv))) and np.abs(trace).max() > 0
+    finally:
+        eng.close()
+
+
 def test_config2_1024cubed_long_run_two_step_passes_equal_single_steps(built_library):
     """BASELINE configs[2] beyond the few steps an oracle window can follow: 1024^3 fp64 with the bench's four wall
     materials, an impulse at the centre, 1 200 steps (the wave front has crossed the room and come back) -- the

@@ -76,6 +76,33 @@ def test_engine_against_the_reference_as_its_device_compiler_builds_it(ref_cl, b
     assert np.abs(got["trace"].astype(np.float64) - want["trace"].astype(np.float64)).max() / scale <= bound
 
 
+@pytest.mark.parametrize("tag,dtype,bound", [("f64", np.float64, 1e-12), ("f32", np.float32, 5e-3)])
+def test_engine_against_the_reference_as_built_on_a_bigger_mesh_for_500_steps(ref_cl, built_library, tag, dtype, bound):
+    """The same comparison at a size and length where rounding differences have had time to grow: 128^3 box, the bench's
+    four wall materials (two of them order-6 IIR), both fields seeded with noise, a soft source, 500 steps -- the
+    reference's program as ROCm's OpenCL compiler builds it (free to fuse a*b+c) against the engine (never fuses).
+    BASELINE.json's bound for double, 1e-12 of the field's magnitude, must hold for fields and receiver traces."""
+    n, steps = 128, 500
+    from wayverb_amd import mesh as M
+    rng = np.random.default_rng(128500)
+    mesh = M.box_mesh(n, n, n, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
+    live = mesh.nodes["boundary_type"] != 0
+    init = [np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0) for _ in range(2)]
+    ci = mesh.compute_index
+    case = dict(mesh=mesh, steps=steps, source_kind=2, source_node=ci(64, 64, 64), signal=rng.uniform(-0.05, 0.05, steps),
+                recv=[ci(67, 64, 64), ci(2, 2, 2), ci(1, 60, 70), ci(100, 30, 125)], init=init)
+    want = run_reference(ref_cl, case, dtype, contract_off=False)
+    got = run_engine(case, tag)
+    assert want["flag"] == 0 and got["steps"] == want["steps"] == steps
+    worst = 0.0
+    for key in ("current", "previous", "trace"):
+        scale = np.abs(want[key]).max()
+        assert scale > 1e-3
+        worst = max(worst, float(np.abs(got[key].astype(np.float64) - want[key].astype(np.float64)).max() / scale))
+    print("engine vs the reference as built, %s, 128^3 x %d steps: max |difference| / max |field| = %.3e" % (tag, steps, worst))
+    assert worst <= bound, worst
+
+
 # ---- the reference's SET-UP programs on this device (SURVEY.md 8(f) rank 1) ---------------------------------------
 # set_node_inside / set_node_boundary_type (mesh_setup_program.cpp) and the three boundary_coefficient_finder
 # kernels, as program text handed to ROCm's OpenCL: dot / cross / normalize / length / distance are now the DEVICE's

@@ -85,6 +85,16 @@ __device__ __forceinline__ double read_lane(double v, int src) {
 // for which the scheme can miss, an all-ones significand, is not 3's); v_div_fixup then supplies IEEE's
 // answers for inf / nan / signed zero.  Checked against the hardware division on every one of the 2^32
 // floats and on 2^34 doubles incl. all exponents and subnormals (tests/test_gpu_div3.py).
+// The LOW RANGE, where Markstein's relative-error argument does not apply (quotient subnormal or in the lowest normal
+// binade, |x| < 3 * 2^-1021): there x, q0 and q1 are all integer multiples of u = 2^-1074, say x = X u with
+// X < 3 * 2^53.  q0 = Q u with Q = round(X c) (gradual underflow rounds to whole units), and X c = X/3 (1 - 2^-54)
+// lies within X/3 * 2^-54 < 1/2 of X/3, so |Q - X/3| < 1 and the integer X - 3 Q is one of -2 .. 2: r is exact (an FMA
+// rounds once, and a handful of units is representable).  q1 = round(Q + (X - 3 Q) c), again ONE rounding of the exact
+// value by the FMA: the fraction added is 0, +-0.333.. or +-0.666.. (each shrunk by 2^-54, never near a half), so q1 =
+// Q, Q or Q +- 1 -- in each case the integer nearest X/3 = Q + (X - 3 Q)/3, whose fractional part is 0, 1/3 or 2/3 and
+// therefore never a tie.  That is the correctly rounded quotient.  (f64 denormals are never flushed on gfx9.)
+// tests/hip/div3_check.hip runs the whole bottom of that range (every pattern below 2^32, both signs) and 2^32 more
+// patterns under the exponent fields 0..3, with windows where x / 3 crosses a binade.
 __device__ __forceinline__ double div3(double x) {
     constexpr double c = 0x1.5555555555555p-2;
     const double q0 = x * c;
@@ -153,6 +163,9 @@ struct StreamArgs {
     int pitch;           // elements per stored row: nx rounded up to 64 lanes x 16 B
     int cls_pitch;
     int z_begin, z_end;  // planes this engine updates (ghost planes excluded)
+    // plane sweep only: the launch covers z_end - z_begin planes, of which those from z_skip_from on lie z_skip planes
+    // further up (two plane ranges in one launch: a slab's two faces).  z_skip = 0: one range.
+    int z_skip_from, z_skip;
     int zc;              // planes marched by one workgroup
     int tiles_x, tiles_y, chunks_z;
     int total_tiles, tiles_per_xcd;

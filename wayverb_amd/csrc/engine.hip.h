@@ -39,8 +39,10 @@ public:
     // ---- engine_setup.hip.h
     int build_tile_lists(int z0, int z1);
     // ---- engine_single.hip.h
-    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr);
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr, int zb0 = 0, int zb1 = 0);
+    int launch_faces(Real* prev, const Real* cur, int* flag, Real* out);
     wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const;
+    // (z0 = z1 = -1: the boundary nodes of a slab's face planes)
     int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false);
     wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
@@ -150,6 +152,7 @@ private:
     uint64_t* signal_base_dev_ = nullptr;
     bool graph_capturing_ = false;
     uint64_t graph_max_nodes_ = 64ull << 20;
+    bool batch_flags_reset_ = false;  // the flag words of the batch being enqueued hold the mesh-static bits already
     bool pre_post_done_ = false;      // this step's pre/post work was done by the previous boundary launch
     // two-step passes
     int pair_inner_ok_ = -1;  // boundary entries finish the inside nodes they face (ensure_pair): -1 not checked yet
@@ -163,7 +166,7 @@ private:
     uint32_t pair_units_longest_ = 0;
     bool pair_sparse_ok_ = true;                   // sparse room: the march's live units cost less than the sweep's live tiles
     double tile_active_frac_ = 1.0;
-    uint32_t pair_list_n_ = 0, pair_face_n_ = 0;  // fix-up nodes of the marched planes / of a slab's face planes
+    uint32_t pair_list_n_ = 0;  // fix-up nodes of the marched planes
     int pair_z0_ = 0, pair_z1_ = 0;                // planes the march produces
     uint64_t pair_source_ = 0;
     int pair_nw_ = 1, pair_strips_ = 0, pair_zc_ = 0, pair_chunks_ = 1;
@@ -184,6 +187,8 @@ private:
     // boundary entries by plane (build_plane_order; slab path only); `_rest`: without the first n_xw_ entries
     uint32_t* zorder_ = nullptr;
     uint32_t* zorder_rest_ = nullptr;  // (same allocation as zorder_)
+    uint32_t* face_order_ = nullptr;   // (same allocation) the entries of a slab's face plane(s)
+    uint32_t face_n_ = 0;
     std::vector<uint32_t> plane_start_, plane_start_rest_;
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)

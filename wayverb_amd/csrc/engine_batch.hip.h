@@ -34,6 +34,7 @@ template <typename Real>
 int Engine<Real>::step(int32_t* flag) {
     DeviceGuard guard(device_);
     pre_post_done_ = false;  // (a batch that failed while being enqueued may have left it set)
+    batch_flags_reset_ = false;
     int rc = enqueue_step(0, false, 0, false);
     if (rc) return rc;
     WV_HIP(hipMemcpyAsync(flags_host_, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -70,6 +71,13 @@ uint64_t Engine<Real>::plan_batch(uint64_t remaining) {
     batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
     // nothing rides across batches: whatever a batch that failed half-way left behind does not count
     pre_post_done_ = pair_mid_done_ = pair_list_done_ = false;
+    // A slab resets the flag words of the whole batch here (waveguide.h:82 does it per step; the source / receiver
+    // launch does it elsewhere) -- most slabs of a chain hold neither source nor receivers and then have no such launch.
+    batch_flags_reset_ = false;
+    if (comm_ && batch) {
+        static_assert(sizeof(int) == 4, "flag words are 32 bit");
+        if (hipMemsetD32Async((hipDeviceptr_t)flags_, static_flag_, (size_t)batch, stream_) == hipSuccess) batch_flags_reset_ = true;
+    }
     return batch;
 }
 

@@ -121,13 +121,13 @@ int Engine<Real>::ensure_pair() {
         pair_list_ = nullptr;
     }
     pair_list_n_ = count[0];
-    pair_face_n_ = count[1];
-    const uint32_t total = count[0] + count[1];
+    // (a slab's face planes get their t+2 from a plain sweep once the neighbours' t+1 faces are in -- launch_faces in
+    // enqueue_pair_b -- not from a list: the map marks them unfinished, that is all)
+    const uint32_t total = count[0];
     if (total) {
-        // one allocation: [marched planes' nodes][face planes' nodes]
         WV_HIP(hipMalloc((void**)&pair_list_, (size_t)total * sizeof(uint32_t)));
         m.list = pair_list_;
-        m.list_face = pair_list_ + count[0];
+        m.list_face = nullptr;
         WV_HIP(hipMemsetAsync(pair_counter_, 0, 3 * sizeof(uint32_t), stream_));
         hipLaunchKernelGGL(wv::pair_map_kernel, dim3(grid), dim3(256), 0, stream_, m);  // fill
         WV_HIP(hipGetLastError());
@@ -137,8 +137,8 @@ int Engine<Real>::ensure_pair() {
         WV_HIP(hipMemcpyAsync(list.data(), pair_list_, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
         WV_HIP(hipStreamSynchronize(stream_));
         const uint64_t bricks_x = ((uint64_t)pitch_ + 63) / 64, bricks_y = ((uint64_t)ny_ + 7) / 8;
-        for (int part = 0; part < 2; ++part) {
-            const uint32_t first = part ? count[0] : 0u, n = count[part];
+        {
+            const uint32_t first = 0u, n = count[0];
             std::vector<uint64_t> keyed(n);
             for (uint32_t i = 0; i < n; ++i) {
                 const uint64_t idx = list[first + i];
@@ -449,17 +449,14 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     int rc;
     std::string cerr;
     if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-    if (!pre_post_done_) {  // step t: flag words of both steps, source sample into t, receivers from t
+    if (!pre_post_done_ && !(batch_flags_reset_ && !n_recv_ && !source_live)) {  // step t: flag words of both steps, source sample into t, receivers from t
         wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
         pp.flag2 = flag2;
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
     pre_post_done_ = false;  // (else: the boundary launch before this pass has done it)
     if (comm_) {
-        if ((rc = launch_stream(A, B, flag1, z_begin_, pair_z0_, false, O1))) return rc;
-        if ((rc = launch_stream(A, B, flag1, pair_z1_, z_end_, false, O1))) return rc;
-        if ((rc = launch_boundary(A, B, flag1, z_begin_, pair_z0_, nullptr, O1))) return rc;
-        if ((rc = launch_boundary(A, B, flag1, pair_z1_, z_end_, nullptr, O1))) return rc;
+        if ((rc = launch_faces(A, B, flag1, O1))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
     }
@@ -581,9 +578,8 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
     if (comm_) {
-        if ((rc = launch_fixup(pair_list_n_, pair_face_n_, O1, B, O2, flag2))) return rc;
-        if ((rc = launch_boundary(B, O1, flag2, z_begin_, pair_z0_, nullptr, O2))) return rc;
-        if ((rc = launch_boundary(B, O1, flag2, pair_z1_, z_end_, nullptr, O2))) return rc;
+        // the face planes to t+2: one more plain step of theirs, from the t+1 field with its ghost planes in place
+        if ((rc = launch_faces(B, O1, flag2, O2))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
     }

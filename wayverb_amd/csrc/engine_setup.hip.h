@@ -290,15 +290,27 @@ int Engine<Real>::build_plane_order() {
     cursor.assign(plane_start_rest_.begin(), plane_start_rest_.end() - 1);
     for (uint32_t e = n_xw_; e < n_entries_; ++e)
         if (bnode[e] != wv::INVALID_NODE) rest[cursor[bnode[e] / plane]++] = e;
+    // the entries of a slab's face plane(s) as one list (launch_faces)
+    std::vector<uint32_t> face;
+    {
+        const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
+        const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+        face.assign(order.begin() + plane_start_[z_begin_], order.begin() + plane_start_[zi0]);
+        face.insert(face.end(), order.begin() + plane_start_[zi1], order.begin() + plane_start_[z_end_]);
+        face_n_ = (uint32_t)face.size();
+        if (face.empty()) face.push_back(0);
+    }
     uint32_t* staged = nullptr;
-    WV_HIP(hipMalloc((void**)&staged, (order.size() + rest.size()) * sizeof(uint32_t)));
+    WV_HIP(hipMalloc((void**)&staged, (order.size() + rest.size() + face.size()) * sizeof(uint32_t)));
     if (hipMemcpy(staged, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(staged + order.size(), rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(staged + order.size(), rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(staged + order.size() + rest.size(), face.data(), face.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(staged);
         return fail(WV_E_HIP, "copying the plane order of the boundary entries to the device failed");
     }
     zorder_ = staged;
     zorder_rest_ = staged + order.size();
+    face_order_ = zorder_rest_ + rest.size();
     return WV_OK;
 }
 

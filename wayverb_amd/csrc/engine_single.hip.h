@@ -37,10 +37,17 @@ void Engine<Real>::launch_ry(const wv::StreamArgs<Real>& a, unsigned grid) {
     }
 }
 
-// `out`: where the new field goes (null: in place, over `prev`)
+// `out`: where the new field goes (null: in place, over `prev`).  Planes [z0, z1) and, in the same launch, [zb0, zb1)
+// further up (a slab's two face planes).
 template <typename Real>
-int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out) {
+int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out, int zb0, int zb1) {
+    if (zb0 < zb1 && z0 >= z1) return launch_stream(prev, cur, flag, zb0, zb1, timed, out);
+    if (zb0 < zb1 && plan_.variant != 2 && plan_.variant != 3) {  // (the measurement variants take one range at a time)
+        const int rc = launch_stream(prev, cur, flag, z0, z1, timed, out);
+        return rc ? rc : launch_stream(prev, cur, flag, zb0, zb1, false, out);
+    }
     if (z0 >= z1) return WV_OK;
+    const int second = zb0 < zb1 ? zb1 - zb0 : 0;
     wv::StreamArgs<Real> a{};
     a.prev = prev;
     a.next = out ? out : prev;
@@ -53,7 +60,9 @@ int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, 
     a.pitch = pitch_;
     a.cls_pitch = cls_pitch_;
     a.z_begin = z0;
-    a.z_end = z1;
+    a.z_end = z1 + second;
+    a.z_skip_from = second ? z1 : std::numeric_limits<int>::max();
+    a.z_skip = second ? zb0 - z1 : 0;
     a.tiles_x = plan_.tiles_x;
     a.tiles_y = plan_.tiles_y;
     unsigned grid = plan_.grid;
@@ -61,11 +70,11 @@ int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, 
         a.stripe_rows = plan_.stripe_rows;
         a.tiles_y_stripe = plan_.tiles_y_stripe;
         a.passes = plan_.passes;
-        grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
+        grid = 8u * (unsigned)plan_.passes * (unsigned)(z1 - z0 + second) * (unsigned)(a.tiles_x * a.tiles_y_stripe);
         // rooms that leave much of the mesh outside: visit only the tiles with something to
         // update -- valid while the outside nodes hold zeros in both fields (outside_dirty_)
         // (built for the engine's big launch: all owned planes, or the interior planes of a slab)
-        if ((int64_t)(z1 - z0) * 2 > (int64_t)(z_end_ - z_begin_) && outside_dirty_ == 0) {
+        if (!second && (int64_t)(z1 - z0) * 2 > (int64_t)(z_end_ - z_begin_) && outside_dirty_ == 0) {
             int rc = build_tile_lists(z0, z1);
             if (rc) return rc;
             if (tile_list_ && z0 == lists_z0_ && z1 == lists_z1_) {
@@ -131,7 +140,8 @@ wv::BoundaryArgs<Real> Engine<Real>::boundary_args(Real* prev, const Real* cur, 
 // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
 template <typename Real>
 int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner) {
-    if (!n_entries_ || z0 >= z1) return WV_OK;
+    const bool faces = z0 == -1 && z1 == -1;
+    if (!n_entries_ || (z0 >= z1 && !faces)) return WV_OK;
     wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
     if (out) b.next = out;
     b.fix_z0 = z0;  // (fix_inner: second launch of a two-step pass over the marched planes)
@@ -144,7 +154,13 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
     // a two-step pass's launches over the marched planes: the x-facing walls by position, on their compact copies
     const bool xw = out && xw_active_ && z0 == pair_z0_ && z1 == pair_z1_;
     uint32_t n = n_entries_ - (xw ? n_xw_ : 0u);
-    if (z0 > z_begin_ || z1 < z_end_) {
+    if (faces) {
+        const int rc = build_plane_order();
+        if (rc != WV_OK) return rc;
+        b.order = face_order_;
+        b.n_order = n = face_n_;
+        if (!n) return WV_OK;
+    } else if (z0 > z_begin_ || z1 < z_end_) {
         const int rc = build_plane_order();
         if (rc != WV_OK) return rc;
         const uint32_t* order = xw ? zorder_rest_ : zorder_;
@@ -169,6 +185,17 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
     else
         hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false>), grid, block, 0, stream_, b, nx);
     return WV_OK;
+}
+
+// A slab's face plane(s) -- the first owned plane when there is a lower neighbour, the last when there is an upper one --
+// one step on: the sweep over both in ONE launch, then their boundary nodes in one.  `out`: as launch_stream.
+template <typename Real>
+int Engine<Real>::launch_faces(Real* prev, const Real* cur, int* flag, Real* out) {
+    const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
+    const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+    int rc = launch_stream(prev, cur, flag, z_begin_, zi0, false, out, zi1, z_end_);
+    if (rc) return rc;
+    return launch_boundary(prev, cur, flag, -1, -1, nullptr, out);
 }
 
 // One loop body: [pre/post on device] + pressure update + boundary update; flag -> flags_[slot]
@@ -204,7 +231,8 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
     std::string cerr;
     // ghost planes of `cur` come from the exchange issued at the end of the previous step
     if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
-    if (!pre_post_done_) {
+    // (the flag words of a batch are reset when it is planned: a slab without source or receivers has nothing to do here)
+    if (!pre_post_done_ && !(batch_flags_reset_ && !n_recv_ && !(with_pre_post && source_live))) {
         const wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
@@ -214,10 +242,7 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
         // slab faces first, so that their exchange overlaps the interior update
         const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
         const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
-        if ((rc = launch_stream(prev, cur, flag, z_begin_, zi0, false))) return rc;
-        if ((rc = launch_stream(prev, cur, flag, zi1, z_end_, false))) return rc;
-        if ((rc = launch_boundary(prev, cur, flag, z_begin_, zi0))) return rc;
-        if ((rc = launch_boundary(prev, cur, flag, zi1, z_end_))) return rc;
+        if ((rc = launch_faces(prev, cur, flag, nullptr))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, prv_, &cerr)) return fail(WV_E_COMM, cerr);
         if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;

@@ -349,6 +349,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_nolds_kernel(cons
         j /= per_plane;
         const int nzr = a.z_end - a.z_begin;
         z = a.z_begin + j % nzr;
+        if (z >= a.z_skip_from) z += a.z_skip;  // (a slab's two face planes in one launch)
         stripe = (j / nzr) * 8 + xcd;
     }
     const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
@@ -439,6 +440,7 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
         j /= per_plane;
         const int nzr = a.z_end - a.z_begin;
         z = a.z_begin + j % nzr;
+        if (z >= a.z_skip_from) z += a.z_skip;  // (a slab's two face planes in one launch)
         stripe = (j / nzr) * 8 + xcd;
     }
     const int tx = tl % a.tiles_x, tyl = tl / a.tiles_x;
