@@ -108,9 +108,8 @@ typedef struct wv_tuning {
     int32_t boundary_lds;     /* 1: boundary workgroups stage the coefficient sets in LDS (<= 256 sets) */
     int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
     int32_t boundary_xwall;   /* 1: in two-step passes the wall nodes that face along x work on compact copies of what they would gather from the fields */
-    int32_t slab_march_faces; /* 1: on a slab the march also produces the face planes' first level (fewer launches per pass) */
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
-    int32_t reserved_[7];
+    int32_t reserved_[8];
 } wv_tuning;
 
 typedef struct wv_options {

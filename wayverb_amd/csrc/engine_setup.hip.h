@@ -352,12 +352,21 @@ void Engine<Real>::plan_stream() {
         if (knob > 0) {
             rows = std::max<int64_t>(tile_rows, rows / tile_rows * tile_rows);  // explicit: any whole number of tiles
         } else {
-            int pow2 = tile_rows;
-            while (pow2 * 2 <= rows) pow2 *= 2;
-            rows = pow2;
+            // Stripes are dealt to the 8 XCDs in rounds, and a round takes as long as a full stripe: the height (whole
+            // tiles, within the L2 budget) that wastes the fewest stripe slots, the taller of equals.  (Until round 3 this
+            // was the largest power of two: 768 rows -> 12 stripes of 64 -> the second round ran on 4 XCDs of 8, which
+            // is what made single steps at 768^3 slower than at 512^3 and 1024^3 -- 48 rows make 16 stripes.)
+            const int64_t budget = std::max<int64_t>(rows, tile_rows);
+            double best = -1.0;
+            for (int64_t r = tile_rows; r <= budget; r += tile_rows) {
+                const int64_t stripes = (ny_ + r - 1) / r, rounds = (stripes + 7) / 8;
+                const double used = (double)ny_ / (double)(rounds * 8 * r);
+                if (used >= best - 1e-12) {
+                    best = used;
+                    rows = r;
+                }
+            }
         }
-        const int per_xcd = (((ny_ + 7) / 8) + tile_rows - 1) / tile_rows * tile_rows;
-        if (knob <= 0) rows = std::min<int64_t>(rows, per_xcd);
         rows = std::max<int64_t>(rows, 1);
         p.stripe_rows = (int)rows;
         p.tiles_y_stripe = (p.stripe_rows + tile_rows - 1) / tile_rows;

@@ -147,7 +147,9 @@ struct PairEdges {
 
 // Experiment switches (tools/pair_tune.hip only; the engine runs X = 0).  They change results or drop
 // checks and exist to price a piece of the kernel.
-enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 16 };
+// PX_NO_MEMORY: no global loads (values made up in registers) and no stores (behind a condition that never holds): what is
+// left is the kernel's instruction stream -- the time below which no amount of temporal blocking can push a pass.
+enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 16, PX_NO_MEMORY = 32 };
 
 // NWC > 0: the row length is a compile-time constant, NWC waves = NWC * 64 * 16 B per row (address
 // arithmetic folds; measured -6 % at 1024 doubles per row before div3, nothing since); 0: any row length.
@@ -222,9 +224,15 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     t.col = (wave_abs * 64 + lane) * VX;
 
     const PairEdges<Real, K> edges{sl, sr, lane, wave, row_waves};
+    auto made_up = [&](int y, int z) -> V {  // (PX_NO_MEMORY)
+        V v;
+#pragma unroll
+        for (int k = 0; k < VX; ++k) v[k] = Real(y) * Real(0.001) + Real(z + k + lane);
+        return v;
+    };
     auto load_b = [&](V(&dst)[RY + 4], int z) {
 #pragma unroll
-        for (int q = 0; q < RY + 4; ++q) dst[q] = t.load(a.cur, y0 - 2 + q, z);
+        for (int q = 0; q < RY + 4; ++q) dst[q] = (X & PX_NO_MEMORY) ? made_up(y0 - 2 + q, z) : t.load(a.cur, y0 - 2 + q, z);
     };
     // t+1 on plane z, rows y0-1 .. y0+RY, from current(z-1), current(z), current(z+1) and previous(z);
     // el / er: x edges of the current(z) rows y0-1 .. y0+RY.  Rows / planes off the grid are 0.
@@ -233,7 +241,8 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     auto load_p = [&](V(&dst)[RY + 2], int z) {
 #pragma unroll
         for (int q = 0; q < RY + 2; ++q)
-            dst[q] = (X & PX_PREV_NT) ? t.load_nt(a.prev, y0 - 1 + q, z) : t.load(a.prev, y0 - 1 + q, z);
+            dst[q] = (X & PX_NO_MEMORY) ? made_up(y0 - 1 + q, -z)
+                                        : ((X & PX_PREV_NT) ? t.load_nt(a.prev, y0 - 1 + q, z) : t.load(a.prev, y0 - 1 + q, z));
     };
     // (x edges of the current(z) rows: edge rows 0 .. RY+1 of LDS set `set`)
     auto level1 = [&](V(&dst)[RY + 2], const V(&bm)[RY + 4], const V(&b0)[RY + 4], const V(&bp)[RY + 4],
@@ -314,7 +323,12 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
                     // if anything non-finite was seen at all (never, in a healthy run)
                     if (!(X & PX_NO_FLAGS)) nonfinite |= (bool)((int)!is_finite(o1[k]) | (int)!is_finite(o2[k]));  // no short circuit: no branch
                 }
-                if (X & PX_STORE_CACHED) {
+                if (X & PX_NO_MEMORY) {
+                    if (nonfinite) {  // (never: the made-up values stay finite)
+                        t.store(a.out1, y0 + r, z, o1);
+                        t.store(a.out2, y0 + r, z, o2);
+                    }
+                } else if (X & PX_STORE_CACHED) {
                     t.store_cached(a.out1, y0 + r, z, o1);
                     t.store_cached(a.out2, y0 + r, z, o2);
                 } else {
