@@ -18,9 +18,11 @@ in HBM before the timed region.
   `--rccl-library` must name a stand-in for librccl (tests/mock_rccl/mock_rccl_shm.cpp); never a measurement.
 
 Prints ONE JSON line on rank 0 (see the README of the driver contract); `roofline` is for the
-dominant kernel, timed with HIP events on the engine's stream: at N = 1 the two-step pass
-(pair_march_kernel: one launch advances every node by TWO time steps, so its algorithmic bytes are
-2 x 24 B per node), at N > 1 the single-step plane sweep of a slab's interior planes.
+dominant kernel, timed with HIP events on the engine's stream: the two-step pass (pair_march_kernel:
+one launch advances every node by TWO time steps and moves 4 x 8 B per node, 16 B per node-update) --
+at N > 1 over a slab's planes between its face planes, which are stepped separately around the two
+halo exchanges of a pass -- or, where the engine keeps single steps (small meshes, `--tuning pair=0`),
+the plane sweep (3 x 8 B per node-update).
 `cpu_baseline` is the reference's own kernel compiled for the host (oracle/_ref, kind "reference";
 the C restatement, kind "port", when that is absent) on the host's cores, N = 1 only, on the SAME
 mesh for a few steps.

@@ -2,7 +2,7 @@
 # Round-end evidence: tests, rocprofv3 kernel stats + PMC traffic, bench (N=1), engine sweeps.
 R=${1:-r02}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
-python -m pytest tests -m gpu -q > gpurun_out/$R/pytest_gpu.txt 2>&1; grep -h "passed\|failed" gpurun_out/$R/pytest_gpu.txt | tail -1
+( time python -m pytest tests -m gpu -q --durations=15 ) > gpurun_out/$R/pytest_gpu.txt 2>&1; grep -h "passed\|failed" gpurun_out/$R/pytest_gpu.txt | tail -1
 python __graft_entry__.py --smoke > gpurun_out/$R/smoke.txt 2>&1; tail -1 gpurun_out/$R/smoke.txt
 CMD="python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-small --no-reference-on-gpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -o bench -- $CMD > gpurun_out/$R/trace.log 2>&1
@@ -44,3 +44,5 @@ python bench.py --tuning pair=0 --no-cpu-baseline --no-small --no-reference-on-g
 for n in 128 160 256 384 512 768; do for p in 0 1; do echo "n=$n WV_PAIR=$p: $(python bench.py --tuning pair=$p --nx $n --ny $n --nz $n --no-cpu-baseline --no-small --no-reference-on-gpu --steps 400 --warmup 40 2>/dev/null | cut -c1-140)"; done; done > gpurun_out/$R/pair_vs_single_by_size.txt
 tools/pair_tune 1024 6 > gpurun_out/$R/pair_tune.txt 2>&1
 ls gpurun_out/$R
+python tools/middle_rank_bench.py > gpurun_out/$R/middle_rank_bench.txt 2>&1; tail -2 gpurun_out/$R/middle_rank_bench.txt
+python tools/concert_bench.py > gpurun_out/$R/concert_hall_steps.txt 2>&1; tail -8 gpurun_out/$R/concert_hall_steps.txt
