@@ -121,3 +121,30 @@ def test_the_library_reads_no_environment_variables():
     assert hits[0][1] > text.index("#ifdef WV_DEBUG_ENV") and "getenv" in block
     from wayverb_amd import build as B
     assert not any("WV_DEBUG_ENV" in f for f in B.FLAGS)
+
+
+def test_tuning_reaches_the_options_struct_and_unknown_fields_are_refused(built_library):
+    """Engine tuning travels in wv_options::tuning: the Python side fills the struct from a dict (engine.default_tuning
+    merged with the call's own), refuses names the header does not have, and tools may read WV_* names from their own
+    environment -- the library never does."""
+    from wayverb_amd import engine as E
+    lib = E.load_library()
+    opt = E.WvOptions()
+    lib.wv_default_options(ctypes.byref(opt))
+    assert opt.struct_size == ctypes.sizeof(E.WvOptions) and opt.precision == E.PRECISION_F64 and opt.stream_variant == 2
+    t = opt.tuning
+    assert (t.pair, t.pair_inner_fix, t.pair_wide, t.pair_unit_planes, t.tile_lists, t.fuse_pre_post, t.graph, t.boundary_lds,
+            t.boundary_order, t.boundary_xwall) == (-1, 1, 1, 32, 1, 1, 0, 1, 1, 1)
+    old = dict(E.default_tuning)
+    try:
+        E.default_tuning.clear()
+        E.default_tuning.update(pair=0, stream_variant=3)
+        E.apply_tuning(opt, dict(boundary_xwall=0, pair=1))
+        assert (opt.tuning.pair, opt.tuning.boundary_xwall, opt.stream_variant) == (1, 0, 3)
+        with pytest.raises(ValueError):
+            E.apply_tuning(opt, dict(no_such_knob=1))
+    finally:
+        E.default_tuning.clear()
+        E.default_tuning.update(old)
+    assert E.tuning_from_env({"WV_PAIR": "0", "WV_STREAM_RY": "2", "WV_STREAM_VARIANT": "3", "HOME": "/"}) == \
+        dict(pair=0, stream_ry=2, stream_variant=3)
