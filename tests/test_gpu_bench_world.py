@@ -48,9 +48,9 @@ def run_bench(world, shm_mock, *extra, timeout=600):
 
 
 @pytest.mark.parametrize("world,scaling,tuning,two_step", [(2, "weak", "pair=1", True), (3, "strong", "pair=0", False),
-                                                          (4, "weak", "", None)])
+                                                          (4, "weak", "", None), (8, "strong", "pair=1", True)])
 def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_step):
-    nx, ny, nz, steps, warmup = 256, 96, (48 if scaling == "weak" else 96), 8, 4
+    nx, ny, nz, steps, warmup = 256, 96, (48 if scaling == "weak" else (96 if world < 8 else 128)), 8, 4
     extra = ["--steps", steps, "--warmup", warmup, "--nx", nx, "--ny", ny, "--nz", nz, "--scaling", scaling]
     if tuning:
         extra += ["--tuning", tuning]
