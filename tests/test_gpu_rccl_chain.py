@@ -80,3 +80,34 @@ def test_the_shared_memory_stand_in_carries_a_chain_too(shm_mock, pair):
     against the same chain test as the thread stand-in, loaded through wv_comm_use_library."""
     last = run_worker(None, 3, "L", 28, 24, 30, "f64", 27, 103, pair=pair, extra=["--rccl-library=" + shm_mock])
     assert last.startswith("OK steps 27 flag 0 "), last
+
+
+def test_the_collective_library_can_be_named_once_before_first_use(shm_mock, built_library):
+    """wv_comm_use_library: a path that does not load makes the first communicator call fail with the loader's message; after
+    the library has been loaded, renaming it is refused (WV_E_STATE) -- the entry points are resolved once per process."""
+    prog = r'''
+import sys
+sys.path.insert(0, %r)
+from wayverb_amd import engine as E
+E.load_library()
+mode, path = sys.argv[1], sys.argv[2]
+if mode == "missing":
+    E.Engine.comm_use_library("/nonexistent/librccl-nowhere.so")
+    try:
+        E.Engine.comm_unique_id()
+    except E.WaveguideError as ex:
+        assert "cannot load librccl" in str(ex), ex
+        print("OK missing")
+else:
+    E.Engine.comm_use_library(path)
+    assert len(E.Engine.comm_unique_id()) == E.UNIQUE_ID_BYTES
+    try:
+        E.Engine.comm_use_library("/somewhere/else.so")
+    except E.WaveguideError as ex:
+        assert "already loaded" in str(ex), ex
+        print("OK late")
+''' % os.path.dirname(HERE)
+    env = dict(os.environ, WV_NO_TORCH_PRELOAD="1")
+    for mode in ("missing", "late"):
+        out = subprocess.run([sys.executable, "-c", prog, mode, shm_mock], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0 and ("OK " + mode) in out.stdout, (out.stdout[-800:], out.stderr[-1500:])
