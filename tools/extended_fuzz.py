@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--first", type=int, default=200)
     ap.add_argument("--count", type=int, default=1500)
     ap.add_argument("--seconds", type=float, default=240.0, help="stop a family after this long")
+    ap.add_argument("--only", default="", help="substring of the family title to run alone")
     args = ap.parse_args()
     from oracle.oracle import Oracle
     from wayverb_amd import build
@@ -38,8 +39,27 @@ def main():
                 families.append(("random API sequences: " + name, fn))
     except Exception:  # noqa: BLE001
         traceback.print_exc()
+    try:
+        import test_gpu_slabs as S
+        from wayverb_amd import engine as E
+
+        def chains(seed, _fn=S.test_random_slab_chains_equal_the_single_domain):
+            for pair in (None, 1):  # the engine's choice of stepping, then two-step passes forced (the test's _step_mode fixture)
+                old = dict(E.default_tuning)
+                if pair is not None:
+                    E.default_tuning["pair"] = pair
+                try:
+                    _fn(None, seed, "two-step-passes" if pair else "single-steps")
+                finally:
+                    E.default_tuning.clear()
+                    E.default_tuning.update(old)
+        families.append(("random slab chains against the single domain, both stepping modes", chains))
+    except Exception:  # noqa: BLE001
+        traceback.print_exc()
     failed = False
     for title, fn in families:
+        if args.only and args.only not in title:
+            continue
         params = inspect.signature(fn).parameters
         t0 = time.perf_counter()
         done = 0
