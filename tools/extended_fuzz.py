@@ -66,6 +66,8 @@ def main():
         for seed in range(args.first, args.first + args.count):
             kw = {}
             for p in params:
+                if params[p].default is not inspect.Parameter.empty:
+                    continue
                 if p == "seed":
                     kw[p] = seed
                 elif p == "oracle":
