@@ -131,6 +131,8 @@ int main(int argc, char** argv) {
         }
         ms = time_variant<wv::PX_NO_MEMORY | wv::PX_NO_MAP>(a, grid, iters, e0, e1);
         printf("  no loads, no stores (instructions only) %.3f ms  %.1f\n", ms, gnodes / ms);
+        ms = time_variant<wv::PX_NO_COMPUTE | wv::PX_NO_MAP>(a, grid, iters, e0, e1);
+        printf("  loads and stores only (no arithmetic, no exchange) %.3f ms  %.1f\n", ms, gnodes / ms);
         ms = time_variant<wv::PX_PREV_NT>(a, grid, iters, e0, e1);
         printf("  previous loaded with nt hint     %.3f ms  %.1f\n", ms, gnodes / ms);
         ms = time_variant<wv::PX_STORE_CACHED>(a, grid, iters, e0, e1);

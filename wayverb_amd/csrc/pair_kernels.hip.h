@@ -149,7 +149,9 @@ struct PairEdges {
 // checks and exist to price a piece of the kernel.
 // PX_NO_MEMORY: no global loads (values made up in registers) and no stores (behind a condition that never holds): what is
 // left is the kernel's instruction stream -- the time below which no amount of temporal blocking can push a pass.
-enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 16, PX_NO_MEMORY = 32 };
+// PX_NO_COMPUTE: the loads and stores of the product, the arithmetic and the edge exchange replaced by a few additions that
+// consume every loaded row: the memory side alone, with the product's access pattern and occupancy.
+enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 16, PX_NO_MEMORY = 32, PX_NO_COMPUTE = 64 };
 
 // NWC > 0: the row length is a compile-time constant, NWC waves = NWC * 64 * 16 B per row (address
 // arithmetic folds; measured -6 % at 1024 doubles per row before div3, nothing since); 0: any row length.
@@ -296,6 +298,18 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
         load_b(b_nn, z + 2);
         load_p(pv, z + 1);
         const uint32_t code_word = (X & PX_NO_MAP) ? 0x55555555u : codes_of(z);
+        if (X & PX_NO_COMPUTE) {  // (tools/pair_tune only)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                if (y0 + r < a.ny && stores) {
+                    const V o1 = b_nn[r] + b_nn[r + RY] + pv[r] + (r < 2 ? pv[r + RY] : b_mid[r]);
+                    const V o2 = b_nn[r + RY] + b_hi[r + 1] + pv[(r + 2) % (RY + 2)];
+                    t.store(a.out1, y0 + r, z, o1);
+                    t.store(a.out2, y0 + r, z, o2);
+                }
+            }
+            return;
+        }
         // one exchange serves both levels: x edges of current(z+1) (for t+1 on z+1) and of t+1(z) (for t+2 on z)
 #pragma unroll
         for (int q = 0; q < RY + 2; ++q) edges.publish(set, q, b_hi[q + 1]);
