@@ -44,4 +44,110 @@ int Engine<Real>::comm_destroy() {
     return WV_OK;
 }
 
+// ---- a chain inside ONE process (wv_comm_init_local / wv_run_group): the slabs are engines driven by one host thread ----
+// Same step code as a rank of the RCCL chain; what the ranks of that chain settle by all-reduce (batch length, stepping
+// form, flag words) is settled here by looking at every engine.
+
+// engines[r] is slab r: communicators with the in-process transport, neighbours linked
+inline int group_init_local(wv_engine* const* engines, int32_t n) {
+    if (!engines || n < 1) return fail(WV_E_INVALID_ARGUMENT, "no engines");
+    for (int i = 0; i < n; ++i)
+        if (!engines[i]) return fail(WV_E_INVALID_ARGUMENT, "null engine");
+    for (int i = 0; i < n; ++i) {
+        const int rc = engines[i]->comm_init_local(i, n);
+        if (rc != WV_OK) {
+            for (int k = 0; k < i; ++k) (void)engines[k]->comm_destroy();
+            return rc;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        engines[i]->comm()->link_local(i > 0 ? engines[i - 1]->comm() : nullptr, i + 1 < n ? engines[i + 1]->comm() : nullptr);
+    return WV_OK;
+}
+
+// wv_run on the whole chain, in lockstep: step i of every slab is enqueued before step i + 1 of any, and the two parts of
+// a two-step pass likewise -- that is what makes every event a slab waits for refer to a record already enqueued (comm.h)
+inline int group_run(wv_engine* const* engines, int32_t n, uint64_t n_steps, uint64_t* steps_done, int32_t* flag_out) {
+    if (!engines || n < 1) return fail(WV_E_INVALID_ARGUMENT, "no engines");
+    for (int i = 0; i < n; ++i)
+        if (!engines[i]) return fail(WV_E_INVALID_ARGUMENT, "null engine");
+    // lockstep needs the slabs in the same state: the same field buffer in the same role after the same number of steps
+    // (exchanges address the neighbour's buffer by index)
+    for (int k = 1; k < n; ++k)
+        if (engines[k]->role_signature() != engines[0]->role_signature())
+            return fail(WV_E_STATE, "the slabs of a group must have taken the same steps (wv_step / wv_swap / wv_run on one of them alone?)");
+    uint64_t completed = 0;
+    int32_t flag = 0;
+    std::vector<int> ored;
+    while (completed < n_steps && flag == 0) {
+        // the shortest batch any slab allows (the slab that holds the source knows when it ends)
+        uint64_t batch = n_steps - completed;
+        for (int k = 0; k < n; ++k) batch = std::min(batch, engines[k]->plan_batch(n_steps - completed));
+        if (batch == 0) break;
+        // two-step passes only if every slab can take them (asked before anything is allocated for them), after the
+        // single steps any of them needs first
+        int singles_first = -1, all_eligible = 1;
+        for (int k = 0; k < n && all_eligible; ++k) {
+            int mine = 0;
+            const int rc = engines[k]->batch_pair_eligible(&mine);
+            if (rc) return rc;
+            all_eligible = mine;
+        }
+        if (all_eligible) {
+            singles_first = 0;
+            for (int k = 0; k < n; ++k) {
+                int ready = 0, mine = 0;
+                const int rc = engines[k]->batch_pair_prepare(&ready, &mine);
+                if (rc) return rc;
+                if (!ready) {
+                    singles_first = -1;
+                    break;
+                }
+                singles_first = std::max(singles_first, mine);
+            }
+        }
+        if (singles_first < 0)
+            for (int k = 0; k < n; ++k) {
+                const int rc = engines[k]->batch_pair_vetoed();
+                if (rc) return rc;
+            }
+        const bool pairs = singles_first >= 0;
+        // lockstep: step i of every slab is enqueued before step i + 1 of any, and the two parts of a
+        // two-step pass likewise (comm.h, local transport)
+        auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+        for (uint64_t i = 0; i < batch;) {
+            if (pair_at(i)) {
+                for (int part = 0; part < 2; ++part)
+                    for (int k = 0; k < n; ++k) {
+                        const int rc = engines[k]->enqueue_batch_pair(i, part, 0);
+                        if (rc) return rc;
+                    }
+                i += 2;
+            } else {
+                for (int k = 0; k < n; ++k) {
+                    const int rc = engines[k]->enqueue_batch_step(i, batch, 0);
+                    if (rc) return rc;
+                }
+                i += 1;
+            }
+        }
+        ored.assign((size_t)batch, 0);
+        for (int k = 0; k < n; ++k) {
+            const int rc = engines[k]->collect_batch(batch);
+            if (rc) return rc;
+            const int* f = engines[k]->batch_flags();
+            for (uint64_t i = 0; i < batch; ++i) ored[(size_t)i] |= f[i];
+        }
+        uint64_t good = 0;
+        for (int k = 0; k < n; ++k) {
+            const int rc = engines[k]->commit_batch(batch, ored.data(), &good, &flag);
+            if (rc) return rc;
+        }
+        completed += good;
+    }
+    if (steps_done) *steps_done = completed;
+    if (flag_out) *flag_out = flag;
+    return WV_OK;
+}
+
 }  // namespace wv
