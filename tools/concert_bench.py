@@ -45,11 +45,13 @@ def main():
             assert (done, flag) == (steps, 0)
             results[pair] = (dt, eng.read_field(E.BUF_CURRENT))
             _, launches, timed = eng.kernel_time_detail()
+            visited = (eng.query(E.Engine.QUERY_MARCH_LIVE_PERMILLE), eng.query(E.Engine.QUERY_SWEEP_LIVE_PERMILLE))
             eng.close()
             label = {0: "single steps", 1: "two-step passes", -1: "engine's choice (%s)" % ("two-step passes" if timed > launches else "single steps")}[pair]
             print("   %-34s %.3f ms/step = %.1f Gnode-updates/s over the mesh, %.1f over the room's nodes"
                   % (label, dt * 1e3, mesh.num_nodes / dt / 1e9, mesh.num_nodes * room / dt / 1e9), flush=True)
-        print("   fields after 220 steps identical: %s" % (results[0][1].tobytes() == results[1][1].tobytes()))
+        print("   fields after 220 steps identical: %s; the march visits %.1f %% of the mesh (in wave-sized pieces of rows), the sweep %.1f %% (in tiles)"
+              % (results[0][1].tobytes() == results[1][1].tobytes(), visited[0] / 10.0, visited[1] / 10.0))
 
 
 if __name__ == "__main__":

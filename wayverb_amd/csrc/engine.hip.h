@@ -166,6 +166,7 @@ private:
     uint32_t pair_units_longest_ = 0;
     bool pair_sparse_ok_ = true;                   // sparse room: the march's live units cost less than the sweep's live tiles
     double tile_active_frac_ = 1.0;
+    double pair_live_frac_ = 1.0;                  // live waves of listed units / all waves of all units (build_pair_units)
     uint32_t pair_list_n_ = 0;  // fix-up nodes of the marched planes
     int pair_z0_ = 0, pair_z1_ = 0;                // planes the march produces
     uint64_t pair_source_ = 0;

@@ -235,6 +235,8 @@ int Engine<Real>::query(int what, uint64_t* value) {
             *value = n;
             return WV_OK;
         }
+        case WV_QUERY_MARCH_LIVE_PERMILLE: *value = pair_units_ ? (uint64_t)(pair_live_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
+        case WV_QUERY_SWEEP_LIVE_PERMILLE: *value = tile_list_ ? (uint64_t)(tile_active_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

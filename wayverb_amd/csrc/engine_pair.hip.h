@@ -321,6 +321,7 @@ int Engine<Real>::build_pair_units(int owned) {
     // (with the live waves of a unit only, what the march moves goes by waves, not by units)
     const double unit_frac = (double)live_waves / ((double)pair_strips_ * chunks * pair_nw_);
     pair_sparse_ok_ = unit_frac * 32.0 * 1.15 < tile_active_frac_ * 48.0;
+    pair_live_frac_ = unit_frac;
     std::vector<uint32_t> list;
     list.reserve((size_t)total);
     pair_units_longest_ = 0;
