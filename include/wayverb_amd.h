@@ -102,6 +102,7 @@ typedef struct wv_tuning {
     int32_t pair_wide;        /* 1: rows of more than 8 waves are shared by several workgroups; 0: such meshes keep single steps */
     int32_t pair_unit_waves;  /* sparse rooms: 1 = a listed unit runs only the live waves of its row */
     int32_t pair_unit_planes; /* sparse rooms: planes per work-list unit of the march (default 32) */
+    int32_t pair_units_by_chunk; /* sparse rooms: 1 = an XCD takes its units chunk by chunk (neighbouring strips run together); 0 = strip by strip */
     int32_t tile_lists;       /* 1: rooms that leave much of the mesh outside visit live tiles / units only (see all_tiles) */
     int32_t fuse_pre_post;    /* 1: the next step's source / receiver work rides in this step's boundary launch where legal */
     int32_t graph;            /* 1: batches of single steps on small meshes are replayed as a hipGraph */
@@ -109,7 +110,7 @@ typedef struct wv_tuning {
     int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
     int32_t boundary_xwall;   /* 1: in two-step passes the wall nodes that face along x work on compact copies of what they would gather from the fields */
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
-    int32_t reserved_[8];
+    int32_t reserved_[7];
 } wv_tuning;
 
 typedef struct wv_options {

@@ -31,7 +31,7 @@ def main():
                  len(mesh.bidx[0]), len(mesh.bidx[1]), len(mesh.bidx[2]), setup), flush=True)
         results = {}
         for pair in (0, 1, -1):
-            eng = E.Engine(mesh, precision="f64", tuning=dict(pair=pair))
+            eng = E.Engine(mesh, precision="f64", tuning=dict(pair=pair, **E.tuning_from_env()))
             eng.enable_kernel_timing(True)
             sig = np.zeros(4096)
             sig[0] = 1.0

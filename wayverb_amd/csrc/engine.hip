@@ -49,6 +49,7 @@ void wv_default_options(wv_options* o) {
     t.pair_wide = 1;
     t.pair_unit_waves = 1;
     t.pair_unit_planes = 32;
+    t.pair_units_by_chunk = 1;
     t.tile_lists = 1;
     t.fuse_pre_post = 1;
     t.graph = 0;
@@ -68,7 +69,7 @@ static void tuning_from_environment(wv_options* o) {
     wv_tuning& t = o->tuning;
     const Knob knobs[] = {{"WV_PAIR", &t.pair}, {"WV_PAIR_CHUNKS", &t.pair_chunks}, {"WV_PAIR_INNER_FIX", &t.pair_inner_fix},
                           {"WV_PAIR_WIDE", &t.pair_wide}, {"WV_PAIR_UNIT_WAVES", &t.pair_unit_waves},
-                          {"WV_PAIR_UNIT_PLANES", &t.pair_unit_planes}, {"WV_TILE_LISTS", &t.tile_lists},
+                          {"WV_PAIR_UNIT_PLANES", &t.pair_unit_planes}, {"WV_PAIR_UNITS_BY_CHUNK", &t.pair_units_by_chunk}, {"WV_TILE_LISTS", &t.tile_lists},
                           {"WV_FUSE_PRE_POST", &t.fuse_pre_post}, {"WV_GRAPH", &t.graph}, {"WV_BOUNDARY_LDS", &t.boundary_lds},
                           {"WV_BOUNDARY_ORDER", &t.boundary_order}, {"WV_BOUNDARY_XWALL", &t.boundary_xwall},
                           {"WV_STREAM_VARIANT", &o->stream_variant},

@@ -262,8 +262,47 @@ int Engine<Real>::build_pair_units(int owned) {
     for (int z = pair_z0_; z < pair_z1_; ++z)
         for (int sidx = 0; sidx < pair_strips_; ++sidx) live += active[(size_t)z * pair_strips_ + sidx];
     if (live * 100 >= (uint64_t)owned * pair_strips_ * 92) return WV_OK;  // (nearly) all room
-    // finer chunks than a full mesh would take: skipping works in whole units
-    const int zc = std::max(8, std::min(pair_zc_, opt_.tuning.pair_unit_planes));
+    // finer chunks than a full mesh would take: skipping works in whole units.  How many planes to a unit?  About
+    // pair_unit_planes (32), and among the heights near it the one whose units fill the chip's workgroup slots in the
+    // fewest, fullest rounds: an XCD runs 32 x (8 / waves per workgroup) of its units at a time, a round of them takes
+    // (height + 3 prologue planes), and a last round with two units in it costs as much as a full one -- the concert
+    // hall at 1 600 Hz made 1 538 units of 32 planes for 256 slots: six rounds and one nearly empty.
+    const int64_t slots_per_xcd = 32ll * std::max(1, wv::kPairMaxWaves / pair_nw_);
+    auto rounds_cost = [&](int height) -> double {
+        const int n_chunks = (owned + height - 1) / height;
+        std::vector<uint32_t> per_strip((size_t)pair_strips_, 0u);
+        uint64_t units = 0;
+        for (int sidx = 0; sidx < pair_strips_; ++sidx)
+            for (int c = 0; c < n_chunks; ++c) {
+                const int zb = pair_z0_ + c * height, ze = std::min(zb + height, pair_z1_);
+                bool any = false;
+                for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * pair_strips_ + sidx] != 0;
+                per_strip[(size_t)sidx] += any;
+                units += any;
+            }
+        if (!units) return 0.0;
+        uint64_t longest = 0, so_far = 0, start = 0;  // the same partition into eight runs of strips as below
+        int sidx = 0;
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t want = units * (uint64_t)(k + 1) / 8;
+            while (sidx < pair_strips_ && (so_far < want || k == 7)) so_far += per_strip[(size_t)sidx++];
+            longest = std::max(longest, so_far - start);
+            start = so_far;
+        }
+        return (double)((longest + slots_per_xcd - 1) / slots_per_xcd) * (double)(height + 3);
+    };
+    int zc = std::max(8, std::min(pair_zc_, opt_.tuning.pair_unit_planes));
+    if (zc == opt_.tuning.pair_unit_planes && opt_.tuning.pair_units_by_chunk != 0) {
+        double best = rounds_cost(zc);
+        for (int height = zc * 3 / 4; height <= zc * 5 / 4; ++height) {
+            if (height < 8 || height > owned || (owned + height - 1) / height >= (1 << 9)) continue;
+            const double cost = rounds_cost(height);
+            if (cost > 0 && cost < best * 0.97) {  // (only a clear win moves the height)
+                best = cost;
+                zc = height;
+            }
+        }
+    }
     const int chunks = (owned + zc - 1) / zc;
     if (chunks >= (1 << 9)) return WV_OK;  // (9 bits of a list entry)
     // Which waves of a row does a unit need?  Those between the first and the last column block that holds anything
@@ -329,10 +368,19 @@ int Engine<Real>::build_pair_units(int owned) {
     for (int k = 0; k < 8; ++k) {
         pair_unit_start_[k] = (uint32_t)list.size();
         const uint64_t want = total * (uint64_t)(k + 1) / 8;  // cumulative share of XCDs 0 .. k
+        const size_t first = list.size();
         while (sidx < pair_strips_ && (list.size() < want || k == 7)) {
             list.insert(list.end(), of_strip[(size_t)sidx].begin(), of_strip[(size_t)sidx].end());
             ++sidx;
         }
+        // An XCD takes its units chunk by chunk, the strips of a chunk side by side -- as the arithmetic mapping of a
+        // full mesh does -- so that the workgroups it runs at one time are NEIGHBOURING strips at the same planes and
+        // the ring rows two of them both load meet in its L2.  (Until round 3 the order was strip by strip: the 32
+        // workgroups of an XCD were 29 chunks of one strip and shared nothing; every ring row came from HBM -- the
+        // concert hall's march ran at 3.3 TB/s where a box's runs at 5.85.)
+        if (opt_.tuning.pair_units_by_chunk != 0)
+            std::stable_sort(list.begin() + (std::ptrdiff_t)first, list.end(),
+                             [](uint32_t a, uint32_t b) { return ((a >> 16) & 0x1FFu) < ((b >> 16) & 0x1FFu); });
         pair_units_longest_ = std::max<uint32_t>(pair_units_longest_, (uint32_t)list.size() - pair_unit_start_[k]);
     }
     pair_unit_start_[8] = (uint32_t)list.size();

@@ -45,14 +45,14 @@ class WvMesh(C.Structure):
                 ("num_boundary_1", C.c_uint64), ("num_boundary_2", C.c_uint64), ("num_boundary_3", C.c_uint64)]
 
 
-TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "tile_lists",
+TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "pair_units_by_chunk", "tile_lists",
                  "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_xwall",
                  "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks")
 
 
 class WvTuning(C.Structure):
     """wv_tuning (include/wayverb_amd.h): how the engine does its work, never what it computes."""
-    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 8)]
+    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 7)]
 
 
 class WvOptions(C.Structure):
