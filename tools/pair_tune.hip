@@ -54,6 +54,16 @@ __global__ void box_map_kernel(uint8_t* map, int n, int cls_pitch) {
     map[wv::cls_byte_index(xb * 4, y, z, n, cls_pitch)] = (uint8_t)out;
 }
 
+// strips of TWO rows, three waves per SIMD asked of the compiler (rows of 5-7 waves leave wave slots empty at two)
+template <int X>
+__global__ void __launch_bounds__(64 * wv::kPairMaxWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) pair_march_ry2_kernel(const wv::PairArgs<double> a) {
+    wv::pair_march_body<double, X, 0, false, 2>(a);
+}
+template <int X>
+__global__ void __launch_bounds__(64 * wv::kPairMaxWaves) pair_march_ry2_free_kernel(const wv::PairArgs<double> a) {
+    wv::pair_march_body<double, X, 0, false, 2>(a);
+}
+
 template <int X, int NWC = 0>
 float time_variant(const wv::PairArgs<double>& a, unsigned grid, int iters, hipEvent_t e0, hipEvent_t e1) {
     for (int it = 0; it < iters + 2; ++it) {
@@ -133,6 +143,28 @@ int main(int argc, char** argv) {
         printf("  no loads, no stores (instructions only) %.3f ms  %.1f\n", ms, gnodes / ms);
         ms = time_variant<wv::PX_NO_COMPUTE | wv::PX_NO_MAP>(a, grid, iters, e0, e1);
         printf("  loads and stores only (no arithmetic, no exchange) %.3f ms  %.1f\n", ms, gnodes / ms);
+        {   // the same march in strips of two rows (no pair map: its row groups are four rows)
+            wv::PairArgs<double> b = a;
+            b.strips = (n + 1) / 2;
+            b.strips_per_xcd = (b.strips + 7) / 8;
+            const unsigned g2 = 8u * (unsigned)b.strips_per_xcd * (unsigned)b.chunks;
+            for (int which = 0; which < 2; ++which) {
+                for (int it = 0; it < iters + 2; ++it) {
+                    if (it == 2) CK(hipEventRecord(e0));
+                    if (which == 0)
+                        hipLaunchKernelGGL((pair_march_ry2_kernel<wv::PX_NO_MAP>), dim3(g2), dim3(64u * (unsigned)b.nw), 0, 0, b);
+                    else
+                        hipLaunchKernelGGL((pair_march_ry2_free_kernel<wv::PX_NO_MAP>), dim3(g2), dim3(64u * (unsigned)b.nw), 0, 0, b);
+                }
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipGetLastError());
+                float m2 = 0;
+                CK(hipEventElapsedTime(&m2, e0, e1));
+                m2 /= iters;
+                printf("  strips of 2 rows, no map, %s  %.3f ms  %.1f\n", which == 0 ? "3 waves per SIMD asked:" : "registers as they come:", m2, gnodes / m2);
+            }
+        }
         ms = time_variant<wv::PX_PREV_NT>(a, grid, iters, e0, e1);
         printf("  previous loaded with nt hint     %.3f ms  %.1f\n", ms, gnodes / ms);
         ms = time_variant<wv::PX_STORE_CACHED>(a, grid, iters, e0, e1);

@@ -161,8 +161,10 @@ enum : int { PX_NO_MAP = 1, PX_NO_FLAGS = 2, PX_PREV_NT = 8, PX_STORE_CACHED = 1
 // to its outside, the halo wave's t+1 is wrong in its outermost column only (the missing neighbour counts as 0),
 // which reaches no further than its own t+2; its innermost column's t+1 -- what the first storing wave needs --
 // is right.  25 % (8 waves run for 6 stored) more arithmetic and L2 traffic for such rows, the same HBM bytes.
-template <typename Real, int X = 0, int NWC = 0, bool WIDE = false>
-__global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const PairArgs<Real> a) {
+// (The body is a device function so that tools/pair_tune.hip can price it at other strip heights and occupancies; the
+// product is pair_march_kernel below, RYT = kPairRows.)
+template <typename Real, int X, int NWC, bool WIDE, int RYT>
+__device__ __forceinline__ void pair_march_body(const PairArgs<Real>& a) {
     // (The arguments are never written to: a modified copy of the struct is no longer promoted to registers, its
     // pointers are re-read from scratch and lose their address space -- flat loads, a wait after each, three
     // times the run time.  That, not register pressure, was what made the NWC variant collapse in mid-round.)
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
     const int cls_pitch = NWC > 0 ? pitch / 4 : a.cls_pitch;
     using V = typename Vec16<Real>::type;
     constexpr int VX = Vec16<Real>::N;
-    constexpr int RY = kPairRows;
+    constexpr int RY = RYT;
     constexpr int K = 2 * RY + 2;  // edge rows per plane: RY+2 of `current`, RY of t+1
     __shared__ Real sl[2][K][kPairMaxWaves], sr[2][K][kPairMaxWaves];
 
@@ -383,6 +385,11 @@ __global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const Pa
         if (bad1) atomicOr(a.flag1, bad1);
         if (bad2) atomicOr(a.flag2, bad2);
     }
+}
+
+template <typename Real, int X = 0, int NWC = 0, bool WIDE = false>
+__global__ void __launch_bounds__(64 * kPairMaxWaves) pair_march_kernel(const PairArgs<Real> a) {
+    pair_march_body<Real, X, NWC, WIDE, kPairRows>(a);
 }
 
 // ---- t+2 of the nodes the march could not finish (code 3): plain 7-point update from the complete t+1
