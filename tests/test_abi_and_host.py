@@ -148,3 +148,26 @@ def test_tuning_reaches_the_options_struct_and_unknown_fields_are_refused(built_
         E.default_tuning.update(old)
     assert E.tuning_from_env({"WV_PAIR": "0", "WV_STREAM_RY": "2", "WV_STREAM_VARIANT": "3", "HOME": "/"}) == \
         dict(pair=0, stream_ry=2, stream_variant=3)
+
+
+def test_no_kernel_of_the_engine_spills(built_library):
+    """The march runs on 255 of 256 VGPRs and used to carry 44 B of scratch per lane, worth 7 % of its time:
+    the compiler's own account of engine.hip's kernels, written beside the library by wayverb_amd.build, must show no
+    scratch in any of them, two waves per SIMD for the march and at least four for the boundary kernels."""
+    from wayverb_amd import build as B
+    text = open(B.RESOURCES).read()
+    blocks = re.split(r"remark: Function Name: ", text)[1:]
+    assert len(blocks) > 50
+    seen = set()
+    for b in blocks:
+        name = b.split()[0]
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        waves = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert scratch == 0, (name, scratch)
+        if "pair_march_kernel" in name:
+            assert waves >= 2, (name, waves)
+            seen.add("march")
+        if "boundary_kernel" in name:
+            assert waves >= 3, (name, waves)
+            seen.add("boundary")
+    assert seen == {"march", "boundary"}

@@ -23,8 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+RESOURCES = os.path.join(CSRC, "engine.resources.txt")  # the compiler's per-kernel register / scratch report for engine.hip
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(RESOURCES):
         return True
     t = os.path.getmtime(LIB)
     files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -40,7 +43,22 @@ def build(force=False, verbose=True):
         cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[wayverb_amd.build]", " ".join(cmd))
-        subprocess.check_call(cmd)
+        if src == "engine.hip":
+            # the hot kernels live at the edge of the register file (the march: 255 of 256 VGPRs): keep the compiler's
+            # account of every kernel beside the library, tests/test_abi_and_host.py reads it (no kernel may spill)
+            out = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+            remarks = [l for l in out.stderr.splitlines() if "kernel-resource-usage" in l]
+            other = [l for l in out.stderr.splitlines() if "kernel-resource-usage" not in l and not l.lstrip().startswith(("|", "^"))
+                     and "__global__" not in l]
+            if out.returncode != 0:
+                sys.stderr.write(out.stderr)
+                raise subprocess.CalledProcessError(out.returncode, cmd)
+            if other and verbose:
+                sys.stderr.write("\n".join(other) + "\n")
+            with open(RESOURCES, "w") as f:
+                f.write("\n".join(remarks) + "\n")
+        else:
+            subprocess.check_call(cmd)
         objs.append(obj)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl", "-lpthread"]
     if verbose:
