@@ -8,12 +8,19 @@ both -- on ONE GPU the slabs run one after the other, so (b)/(a) - 1 is the work
 launches, second exchange, fix-up of the face planes), i.e. what a perfect interconnect would still leave of the
 scaling efficiency -- and compares sampled planes (slab faces, ghosts' owners, mid-slab) bit for bit.
 
-    python tools/slab_overhead.py [--world 8] [--nz 1024] [--steps 40]
+    python tools/slab_overhead.py [--world 8] [--nz 1024] [--steps 40] [--hw-queues 16]
+
+`--hw-queues N` sets GPU_MAX_HW_QUEUES for this process: the ROCm runtime spreads a process's streams over 4 hardware
+queues unless told otherwise, and 8 slabs x (compute + halo stream) on one GPU then share queues that 8 GPUs would
+not share.
 """
 import argparse
 import os
 import sys
 import time
+
+if "--hw-queues" in sys.argv:  # before the HIP runtime is loaded
+    os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[sys.argv.index("--hw-queues") + 1]
 
 import numpy as np
 
@@ -28,6 +35,7 @@ def main():
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--nz", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--hw-queues", type=int, default=0)
     args = ap.parse_args()
     n, nz, world, steps = args.n, args.nz, args.world, args.steps
     coeffs = M.bench_materials()

@@ -190,7 +190,8 @@ bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_str
     has_lo_ = has_lo;
     has_hi_ = has_hi;
     stream_ = comm_stream;
-    for (hipEvent_t* e : {&faces_ready_, &ghosts_ready_, &pushed_lo_, &pushed_hi_, &step_done_})
+    for (hipEvent_t* e : {&faces_ready_, &ghosts_ready_, &pushed_lo_[0], &pushed_lo_[1], &pushed_lo_[2], &pushed_lo_[3], &pushed_hi_[0],
+                          &pushed_hi_[1], &pushed_hi_[2], &pushed_hi_[3], &step_done_[0], &step_done_[1]})
         if (!hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
     return true;
 }
@@ -235,7 +236,8 @@ SlabComm::~SlabComm() {
             if (peer->device_ != before) (void)hipSetDevice(before);
         }
     if (comm_) (void)rccl().comm_destroy(comm_);
-    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_, pushed_hi_, step_done_, reduce_in_, reduce_out_})
+    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
+                         pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
     // a local chain is torn down as a whole (wv_comm_destroy on every engine); unlink anyway
@@ -243,14 +245,19 @@ SlabComm::~SlabComm() {
     if (hi_ && hi_->lo_ == this) hi_->lo_ = nullptr;
 }
 
-bool SlabComm::wait_ghosts(hipStream_t compute, std::string* err) {
+bool SlabComm::wait_ghosts(hipStream_t compute, int field, std::string* err) {
     if (local_) {
-        // my ghost planes are written by the neighbours' pushes
-        if (lo_ && lo_->pushed_hi_set_ &&
-            !hip_ok(hipStreamWaitEvent(compute, lo_->pushed_hi_, 0), "hipStreamWaitEvent", err))
+        // my ghost planes of THIS buffer are written by the neighbours' pushes into it -- and by no later ones: a
+        // neighbour that is already a step (or half a pass) ahead in host order has pushed into another buffer since
+        if (field < 0 || field >= 4) {
+            *err = "wait_ghosts: no such field buffer";
             return false;
-        if (hi_ && hi_->pushed_lo_set_ &&
-            !hip_ok(hipStreamWaitEvent(compute, hi_->pushed_lo_, 0), "hipStreamWaitEvent", err))
+        }
+        if (lo_ && lo_->pushed_hi_set_[field] &&
+            !hip_ok(hipStreamWaitEvent(compute, lo_->pushed_hi_[field], 0), "hipStreamWaitEvent", err))
+            return false;
+        if (hi_ && hi_->pushed_lo_set_[field] &&
+            !hip_ok(hipStreamWaitEvent(compute, hi_->pushed_lo_[field], 0), "hipStreamWaitEvent", err))
             return false;
         return true;
     }
@@ -260,8 +267,9 @@ bool SlabComm::wait_ghosts(hipStream_t compute, std::string* err) {
 
 bool SlabComm::step_done(hipStream_t compute, std::string* err) {
     if (!local_) return true;  // RCCL: the matching ncclRecv is issued by this rank itself, in stream order
-    step_done_set_ = true;
-    return hip_ok(hipEventRecord(step_done_, compute), "hipEventRecord", err);
+    const int which = (int)(steps_done_ & 1u);
+    ++steps_done_;
+    return hip_ok(hipEventRecord(step_done_[which], compute), "hipEventRecord", err);
 }
 
 bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) {
@@ -277,11 +285,16 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
     if (local_) {
         // push my face planes into the neighbours' ghost planes of the same buffer.  The neighbour
         // may still be reading that ghost plane (it was part of its `current` one step ago): wait
-        // for the end of its last enqueued step.  Lockstep driving (wv_run_group) guarantees that
-        // every event waited for here has been recorded in host order.
+        // for the end of the step (or two-step pass) BEFORE the one being enqueued -- the event of
+        // that parity, not the neighbour's latest: the lower neighbour has this step enqueued already,
+        // and waiting for its end would put the chain's slabs one behind the other.  Lockstep driving
+        // (wv_run_group) guarantees that every event waited for here has been recorded in host order
+        // and is not recorded again before this slab's step is enqueued.
+        const bool earlier = steps_done_ > 0;
+        const int before = (int)((steps_done_ + 1u) & 1u);
         if (has_lo_ && lo_) {
-            if (lo_->step_done_set_ &&
-                !hip_ok(hipStreamWaitEvent(stream_, lo_->step_done_, 0), "hipStreamWaitEvent", err))
+            if (earlier && lo_->steps_done_ >= steps_done_ &&
+                !hip_ok(hipStreamWaitEvent(stream_, lo_->step_done_[before], 0), "hipStreamWaitEvent", err))
                 return false;
             if (field >= lo_->n_fields_ || !lo_->fields_[field]) {
                 *err = "exchange_faces: the lower neighbour has no such field buffer (slabs of a chain must take the same steps)";
@@ -294,12 +307,12 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
             }
             if (!hip_ok(push_plane(dst, lo_->device_, base + plane_bytes, device_, plane_bytes, stream_), "hipMemcpyAsync", err))
                 return false;
-            if (!hip_ok(hipEventRecord(pushed_lo_, stream_), "hipEventRecord", err)) return false;
-            pushed_lo_set_ = true;
+            if (!hip_ok(hipEventRecord(pushed_lo_[field], stream_), "hipEventRecord", err)) return false;
+            pushed_lo_set_[field] = true;
         }
         if (has_hi_ && hi_) {
-            if (hi_->step_done_set_ &&
-                !hip_ok(hipStreamWaitEvent(stream_, hi_->step_done_, 0), "hipStreamWaitEvent", err))
+            if (earlier && hi_->steps_done_ >= steps_done_ &&
+                !hip_ok(hipStreamWaitEvent(stream_, hi_->step_done_[before], 0), "hipStreamWaitEvent", err))
                 return false;
             if (hi_->plane_bytes_ != plane_bytes) {
                 *err = "neighbouring slabs disagree about the plane size";
@@ -313,8 +326,8 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
             if (!hip_ok(push_plane(dst, hi_->device_, base + (size_t)(nz - 2) * plane_bytes, device_, plane_bytes, stream_),
                         "hipMemcpyAsync", err))
                 return false;
-            if (!hip_ok(hipEventRecord(pushed_hi_, stream_), "hipEventRecord", err)) return false;
-            pushed_hi_set_ = true;
+            if (!hip_ok(hipEventRecord(pushed_hi_[field], stream_), "hipEventRecord", err)) return false;
+            pushed_hi_set_[field] = true;
         }
         return true;
     }

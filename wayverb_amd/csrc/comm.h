@@ -46,8 +46,9 @@ public:
     // The engine's field buffers: base pointers, bytes per plane, planes (ghosts included).
     void set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz);
 
-    // The compute stream must not read ghost planes before the previous exchange has landed.
-    bool wait_ghosts(hipStream_t compute, std::string* err);
+    // The compute stream must not read the ghost planes of field buffer `field` before the exchange that fills them
+    // has landed.
+    bool wait_ghosts(hipStream_t compute, int field, std::string* err);
     // Faces of field buffer `field` (planes 1 and nz-2 when the matching ghost exists) are final on
     // `compute`: exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
     bool exchange_faces(hipStream_t compute, int field, std::string* err);
@@ -85,9 +86,13 @@ private:
     size_t plane_bytes_ = 0;
     // local transport
     SlabComm *lo_ = nullptr, *hi_ = nullptr;
-    hipEvent_t pushed_lo_ = nullptr, pushed_hi_ = nullptr;  // my face has landed in the lower / upper neighbour
-    hipEvent_t step_done_ = nullptr;
-    bool pushed_lo_set_ = false, pushed_hi_set_ = false, step_done_set_ = false;
+    // my face of field buffer f has landed in the lower / upper neighbour (one event per buffer: a slab waits for the
+    // pushes into the buffer it is about to read, whatever its neighbours have pushed since)
+    hipEvent_t pushed_lo_[4] = {nullptr, nullptr, nullptr, nullptr}, pushed_hi_[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pushed_lo_set_[4] = {false, false, false, false}, pushed_hi_set_[4] = {false, false, false, false};
+    // ends of this slab's steps / two-step passes, by parity of their count
+    hipEvent_t step_done_[2] = {nullptr, nullptr};
+    uint64_t steps_done_ = 0;
     // flag OR
     uint64_t* spread_ = nullptr;
 };

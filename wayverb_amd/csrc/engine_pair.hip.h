@@ -497,7 +497,7 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     int* flag2 = flags_ + slot + 1;
     int rc;
     std::string cerr;
-    if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+    if (comm_ && !comm_->wait_ghosts(stream_, cur_, &cerr)) return fail(WV_E_COMM, cerr);
     if (!pre_post_done_ && !(batch_flags_reset_ && !n_recv_ && !source_live)) {  // step t: flag words of both steps, source sample into t, receivers from t
         wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
         pp.flag2 = flag2;
@@ -620,7 +620,7 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     int* flag2 = flags_ + slot + 1;
     int rc;
     std::string cerr;
-    if (comm_ && !comm_->wait_ghosts(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
+    if (comm_ && !comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
     if (!pair_mid_done_ && (n_recv_ || source_live)) {  // step t+1: source sample into t+1, receivers from it
         wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
         pp.flag = nullptr;  // reset in part A, and already written to by the march
