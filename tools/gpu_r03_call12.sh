@@ -1,0 +1,8 @@
+#!/bin/bash
+# (a) the GPU suite (minus its heaviest cases) with the library's host code under ASan + UBSan; (b) 1024^3 as 2 / 4 / 8 slabs
+# twice each (run-to-run spread of the decomposition overhead); (c) the timeline of a slab pass with the runtime's default queues
+export TMPDIR=/tmp; O=gpurun_out/r03; mkdir -p $O
+(timeout 420 tools/sanitizer_run.sh tests -q -x -m gpu -k "not 1024 and not config3 and not div3 and not long and not 10000 and not full_size and not bench_world" 2>&1 | tail -25) > $O/sanitizers_gpu_suite.txt; tail -5 $O/sanitizers_gpu_suite.txt
+for rep in 1 2; do for w in 2 4 8; do python tools/slab_overhead.py --world $w 2>&1 | grep fp64; done; done | tee $O/slab_overhead_one_gpu.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/tl -o t -- python tools/slab_overhead.py --world 8 --steps 8 > $O/tl.log 2>&1; tail -1 $O/tl.log
+python tools/pass_timeline.py $O/tl 4 > $O/slab_pass_timeline_8x128.txt 2>&1; rm -rf $O/tl $O/tl.log

@@ -67,5 +67,33 @@ def build(force=False, verbose=True):
     return LIB
 
 
+SANITIZED_DIR = os.path.join(HERE, "sanitized")
+
+
+def build_sanitized(verbose=True):
+    """The same library with its HOST code under AddressSanitizer + UndefinedBehaviorSanitizer (device code as shipped:
+    -fno-gpu-sanitize), as wayverb_amd/sanitized/libwayverb_amd.so.  Test infrastructure: tools/sanitizer_run.sh puts it in
+    the product library's place on a GPU box and runs the C / C++ / Python callers against it."""
+    os.makedirs(SANITIZED_DIR, exist_ok=True)
+    extra = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g"]
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(SANITIZED_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [HIPCC] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[wayverb_amd.build]", " ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    lib = os.path.join(SANITIZED_DIR, "libwayverb_amd.so")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan"] + objs + ["-o", lib, "-ldl", "-lpthread"]
+    if verbose:
+        print("[wayverb_amd.build]", " ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--sanitized" in sys.argv:
+        print(build_sanitized())
+    else:
+        build(force="--force" in sys.argv)

@@ -41,6 +41,15 @@ constexpr int kNcclUint64 = 5;  // ncclUint64
 constexpr int kNcclSum = 0;     // ncclSum
 constexpr int kNcclMin = 3;     // ncclMin
 
+// local transport: whose device-filling launch was enqueued last on each device (SlabComm::bulk_begin / bulk_end)
+struct DeviceTurn {
+    const void* owner = nullptr;
+    hipEvent_t done = nullptr;
+};
+constexpr int kMaxDevices = 64;
+std::mutex g_turn_mutex;
+DeviceTurn g_turn[kMaxDevices];
+
 std::string& library_override() {
     static std::string path;
     return path;
@@ -191,7 +200,7 @@ bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_str
     has_hi_ = has_hi;
     stream_ = comm_stream;
     for (hipEvent_t* e : {&faces_ready_, &ghosts_ready_, &pushed_lo_[0], &pushed_lo_[1], &pushed_lo_[2], &pushed_lo_[3], &pushed_hi_[0],
-                          &pushed_hi_[1], &pushed_hi_[2], &pushed_hi_[3], &step_done_[0], &step_done_[1]})
+                          &pushed_hi_[1], &pushed_hi_[2], &pushed_hi_[3], &step_done_[0], &step_done_[1], &bulk_done_})
         if (!hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
     return true;
 }
@@ -236,7 +245,12 @@ SlabComm::~SlabComm() {
             if (peer->device_ != before) (void)hipSetDevice(before);
         }
     if (comm_) (void)rccl().comm_destroy(comm_);
-    for (hipEvent_t e : {faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
+    if (local_) {
+        std::lock_guard<std::mutex> lock(g_turn_mutex);
+        DeviceTurn& t = g_turn[device_ % kMaxDevices];
+        if (t.owner == this) t = DeviceTurn{};
+    }
+    for (hipEvent_t e : {bulk_done_, faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
                          pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
@@ -270,6 +284,24 @@ bool SlabComm::step_done(hipStream_t compute, std::string* err) {
     const int which = (int)(steps_done_ & 1u);
     ++steps_done_;
     return hip_ok(hipEventRecord(step_done_[which], compute), "hipEventRecord", err);
+}
+
+bool SlabComm::bulk_begin(hipStream_t compute, std::string* err) {
+    if (!local_ || nranks_ < 2) return true;
+    std::lock_guard<std::mutex> lock(g_turn_mutex);
+    const DeviceTurn& t = g_turn[device_ % kMaxDevices];
+    if (t.owner && t.owner != this) return hip_ok(hipStreamWaitEvent(compute, t.done, 0), "hipStreamWaitEvent", err);
+    return true;
+}
+
+bool SlabComm::bulk_end(hipStream_t compute, std::string* err) {
+    if (!local_ || nranks_ < 2) return true;
+    if (!hip_ok(hipEventRecord(bulk_done_, compute), "hipEventRecord", err)) return false;
+    std::lock_guard<std::mutex> lock(g_turn_mutex);
+    DeviceTurn& t = g_turn[device_ % kMaxDevices];
+    t.owner = this;
+    t.done = bulk_done_;
+    return true;
 }
 
 bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) {

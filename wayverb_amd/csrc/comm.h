@@ -55,6 +55,12 @@ public:
     // End of a step on `compute`: this slab has read the ghost planes of the step's `current` field
     // (the local transport may overwrite them once this has passed).
     bool step_done(hipStream_t compute, std::string* err);
+    // local transport, several slabs on ONE device: the launch that fills the device (the march of a two-step pass, the interior
+    // sweep of a single step) is bracketed by these.  Such launches of different slabs gain nothing from running side by side --
+    // each one alone occupies every CU, two of them halve each other's share of L2 -- so they take turns, in the order the host
+    // enqueued them; the small launches around them (faces, boundary nodes, copies) still overlap with another slab's turn.
+    bool bulk_begin(hipStream_t compute, std::string* err);
+    bool bulk_end(hipStream_t compute, std::string* err);
     // flags[i] <- bitwise OR of flags[i] over all ranks, i < n <= kMaxFlags, ordered on `stream`.
     // (RCCL transport; a local group is OR-ed on the host by wv_run_group.)  SURVEY.md 8(e)
     // "error-flag OR": one rank's NaN must stop every rank at the same step.
@@ -92,6 +98,7 @@ private:
     bool pushed_lo_set_[4] = {false, false, false, false}, pushed_hi_set_[4] = {false, false, false, false};
     // ends of this slab's steps / two-step passes, by parity of their count
     hipEvent_t step_done_[2] = {nullptr, nullptr};
+    hipEvent_t bulk_done_ = nullptr;
     uint64_t steps_done_ = 0;
     // flag OR
     uint64_t* spread_ = nullptr;

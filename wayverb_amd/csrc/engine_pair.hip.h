@@ -534,6 +534,7 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
         for (int k = 0; k < 9; ++k) a.list_start[k] = pair_unit_start_[k];
         grid = 8u * pair_units_longest_;
     }
+    if (comm_ && !comm_->bulk_begin(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // (slabs of one device take turns at the march)
     const bool timed = time_this_launch();
     if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
     // (a variant with the row length as a compile-time constant, NWC, was worth 6 % until the divide sequence went
@@ -558,6 +559,7 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
         ev_used_ += 2;
         timed_steps_ += 2;
     }
+    if (comm_ && !comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
     pair_mid_done_ = pair_list_done_ = false;
     if (xw_active_ && !xw_valid_) {  // the x-facing walls' compact copies, from fields t-1 and t

@@ -212,7 +212,7 @@ wv::PrePostArgs<Real> Engine<Real>::pre_post_args(Real* cur, int slot, bool with
     pp.source_node = source_node_;
     pp.source_kind = io && source_live ? source_kind_ : 0;
     pp.recv = recv_nodes_;
-    pp.recv_out = recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1);
+    pp.recv_out = recv_out_ ? recv_out_ + (size_t)slot * std::max<uint32_t>(n_recv_, 1) : nullptr;  // (no receivers: no buffer)
     pp.n_recv = io ? n_recv_ : 0;
     pp.flag = flags_ + slot;
     pp.flag_init = static_flag_;
@@ -245,7 +245,9 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
         if ((rc = launch_faces(prev, cur, flag, nullptr))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, prv_, &cerr)) return fail(WV_E_COMM, cerr);
+        if (!comm_->bulk_begin(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // (slabs of one device take turns at the interior sweep)
         if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
+        if (!comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
     } else {
         if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
