@@ -8,7 +8,11 @@ both -- on ONE GPU the slabs run one after the other, so (b)/(a) - 1 is the work
 launches, second exchange, fix-up of the face planes), i.e. what a perfect interconnect would still leave of the
 scaling efficiency -- and compares sampled planes (slab faces, ghosts' owners, mid-slab) bit for bit.
 
-    python tools/slab_overhead.py [--world 8] [--nz 1024] [--steps 40] [--hw-queues 16]
+    python tools/slab_overhead.py [--world 8] [--nz 1024] [--steps 40] [--hw-queues 16] [--tuning pair_chunks=1]
+
+`--tuning k=v,...` sets wv_tuning fields of every engine (e.g. pair_chunks=1: a thin slab's march in one round of workgroups,
+which is what costs least on ONE GPU; the engine's own choice for a slab with neighbours is two rounds, so that the exchange
+gets a CU before the march ends).
 
 `--hw-queues N` sets GPU_MAX_HW_QUEUES for this process: the ROCm runtime spreads a process's streams over 4 hardware
 queues unless told otherwise, and 8 slabs x (compute + halo stream) on one GPU then share queues that 8 GPUs would
@@ -36,8 +40,11 @@ def main():
     ap.add_argument("--nz", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--hw-queues", type=int, default=0)
+    ap.add_argument("--tuning", default="")
     args = ap.parse_args()
     n, nz, world, steps = args.n, args.nz, args.world, args.steps
+    if args.tuning:
+        E.default_tuning.update({k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
     coeffs = M.bench_materials()
     sig = np.zeros(steps + 10)
     sig[0] = 1.0
@@ -86,7 +93,7 @@ def main():
                 checked += 1
                 wrong += a.tobytes() != b.tobytes()
     nodes = n * n * nz
-    print("%dx%dx%d fp64, %d steps: one domain %.3f ms/step (%.1f Gnode-updates/s); %d slabs on the same GPU %.3f ms/step "
+    print(("[%s] " % args.tuning if args.tuning else "") + "%dx%dx%d fp64, %d steps: one domain %.3f ms/step (%.1f Gnode-updates/s); %d slabs on the same GPU %.3f ms/step "
           "(%.1f); decomposition overhead %.1f %%; %d sampled planes compared, %d differ"
           % (n, n, nz, steps, t_single, nodes / t_single / 1e6, world, t_slabs, nodes / t_slabs / 1e6,
              100 * (t_slabs / t_single - 1), checked, wrong))

@@ -208,17 +208,26 @@ int Engine<Real>::ensure_pair() {
     const int64_t slots = 256ll * std::max(1, wv::kPairMaxWaves / pair_nw_);
     int chunks = opt_.tuning.pair_chunks;
     if (chunks <= 0) {
-        double best = 0;
+        // A slab with a neighbour: the exchange of its t+1 faces is to run under the march, and whatever carries it (RCCL's
+        // send / receive kernels, the runtime's copy kernels) needs a CU -- a march of ONE round holds every register of every
+        // CU until all its workgroups retire together at the end, and the exchange would start after it.  At least two rounds
+        // then: the first round's end is where the exchange gets in.
+        // (... where that costs little: a mesh that fills two rounds only with much shorter chunks keeps the unconstrained choice)
+        const int64_t want_rounds = (opt_.ghost_lo || opt_.ghost_hi) ? 2 : 1;
+        double best[2] = {0, 0};
+        int at[2] = {0, 0};  // [0] any number of rounds, [1] at least `want_rounds`
         for (int c = 1; c <= std::max(1, owned / 8) && c <= 256; ++c) {
             const int64_t wgs = (int64_t)pair_strips_ * c;
             const int64_t rounds = (wgs + slots - 1) / slots;
             const double zc = (double)((owned + c - 1) / c);
             const double cost = (double)(rounds * slots) / (double)wgs * (zc + 3.0) / zc;
-            if (chunks <= 0 || cost < best - 1e-9) {
-                best = cost;
-                chunks = c;
-            }
+            for (int k = 0; k < 2; ++k)
+                if ((k == 0 || rounds >= want_rounds) && (at[k] == 0 || cost < best[k] - 1e-9)) {
+                    best[k] = cost;
+                    at[k] = c;
+                }
         }
+        chunks = (at[1] && best[1] <= 1.06 * best[0]) ? at[1] : at[0];
     }
     chunks = std::max(1, std::min(chunks, std::max(1, owned / 8)));
     pair_zc_ = (owned + chunks - 1) / chunks;
