@@ -224,9 +224,12 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
  *   WV_QUERY_FIELDS          pressure fields allocated (2, or 4 once two-step passes have been taken)
  *   WV_QUERY_MARCH_LIVE_PERMILLE   rooms that leave part of the mesh outside: the share of the mesh (in wave-sized
  *                            pieces of rows, per 1000) that the two-step march visits; 1000 when it visits everything
- *   WV_QUERY_SWEEP_LIVE_PERMILLE   the same for the single-step sweep's tiles */
+ *   WV_QUERY_SWEEP_LIVE_PERMILLE   the same for the single-step sweep's tiles
+ *   WV_QUERY_MARCH_ROUNDS    how many times over the two-step march's workgroups fill the chip's workgroup slots (0 before the
+ *                            first pass).  A slab with a neighbour marches in two rounds at least where that costs little, so
+ *                            that the exchange of its t+1 faces gets a CU before the march ends */
 enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_QUERY_MARCH_LIVE_PERMILLE = 3,
-       WV_QUERY_SWEEP_LIVE_PERMILLE = 4 };
+       WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

@@ -265,3 +265,39 @@ def test_a_group_refuses_slabs_that_are_out_of_step():
             group.run_steps(4)
     finally:
         group.close()
+
+
+def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
+    """The exchange of a slab's t+1 faces is to run under its march, and whatever carries it (RCCL's send / receive
+    kernels, the runtime's copy kernels) needs a CU.  A march whose workgroups fill the chip's slots exactly once holds
+    every register of every CU until all of them retire together, at its end -- so a slab with a neighbour takes the
+    chunking with two rounds where that costs little (engine_pair.hip.h, ensure_pair), one domain keeps the single
+    round.  1024 x 1024 rows: 256 strips of 8 waves = the chip's 256 workgroup slots."""
+    if _step_mode != "two-step-passes":
+        pytest.skip("about the two-step march")
+    from wayverb_amd.slab import box_slab_mesh
+    n, nz = 1024, 128
+    coeffs = M.bench_materials()
+    engines = []
+    for r in range(2):
+        L = SlabLayout((n, n, nz), r, 2)
+        engines.append(E.Engine(box_slab_mesh(n, n, nz, L, coefficients=coeffs), precision="f64", ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi))
+    group = E.LocalSlabGroup(engines)
+    try:
+        assert all(e.query(E.Engine.QUERY_MARCH_ROUNDS) == 0 for e in engines)      # nothing planned yet
+        assert group.run_steps(4) == (4, 0)
+        assert [e.query(E.Engine.QUERY_PASSES) for e in engines] == [2, 2]
+        assert [e.query(E.Engine.QUERY_MARCH_ROUNDS) for e in engines] == [2, 2]
+    finally:
+        group.close()
+
+    class Whole:
+        zl0, zl1, z0, z1 = 0, nz // 2, 0, nz // 2
+        local_dims = (n, n, nz // 2)
+        plane = n * n
+    single = E.Engine(box_slab_mesh(n, n, nz // 2, Whole, coefficients=coeffs), precision="f64")
+    try:
+        assert single.run_steps(4) == (4, 0)
+        assert single.query(E.Engine.QUERY_MARCH_ROUNDS) == 1
+    finally:
+        single.close()

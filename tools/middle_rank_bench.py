@@ -5,7 +5,10 @@ one-rank RCCL communicator (grouped ncclSend/ncclRecv to self), so everything a 
 face planes first, two exchanges per two-step pass on the halo stream, march overlapped, flag all-reduce -- except
 the xGMI links themselves.  Prints ms per step next to the single-domain engine on the same box.
 
-    python tools/middle_rank_bench.py [--steps 60]
+    python tools/middle_rank_bench.py [--steps 60] [--chunks 1,2,4]
+
+`--chunks`: also time the two-step passes with the march cut into that many chunks along z (wv_tuning::pair_chunks) -- one
+chunk of 1022 planes is ONE round of workgroups, which holds every CU until the march ends: RCCL's kernels wait for it.
 """
 import argparse
 import os
@@ -22,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--chunks", default="")
     args = ap.parse_args()
     n, steps = args.n, args.steps
     nz = n + 2                                     # planes 0 and nz-1 are ghosts
@@ -34,8 +38,12 @@ def main():
     sig[0] = 1.0
     src = (nz // 2) * n * n + (n // 2) * n + n // 2
     out = {}
-    for mode in ("single steps", "two-step passes"):
-        eng = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True, tuning=dict(pair=0 if mode == "single steps" else 1))
+    modes = ["single steps", "two-step passes"] + ["two-step passes, %d chunk(s)" % int(c) for c in args.chunks.split(",") if c]
+    for mode in modes:
+        tuning = dict(pair=0 if mode == "single steps" else 1)
+        if "chunk" in mode:
+            tuning["pair_chunks"] = int(mode.split(",")[1].split()[0])
+        eng = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True, tuning=tuning)
         eng.comm_init(E.Engine.comm_unique_id(), 0, 1)
         eng.set_source(E.SOURCE_HARD, src, sig)
         assert eng.run_steps(20) == (20, 0)
@@ -44,7 +52,10 @@ def main():
         assert eng.run_steps(steps) == (steps, 0)
         eng.synchronize()
         out[mode] = (time.perf_counter() - t0) / steps * 1e3
+        rounds = eng.query(E.Engine.QUERY_MARCH_ROUNDS)
         eng.close()
+        if "chunk" in mode:
+            print("  %s: %.3f ms/step, march in %d round(s) of workgroups" % (mode, out[mode], rounds))
     owned = n * n * n
     print("middle rank of configs[3] on one GPU (RCCL to self): single steps %.3f ms/step (%.1f Gnode-updates/s per rank), "
           "two-step passes %.3f ms/step (%.1f)" % (out["single steps"], owned / out["single steps"] / 1e6,

@@ -236,6 +236,17 @@ int Engine<Real>::query(int what, uint64_t* value) {
             return WV_OK;
         }
         case WV_QUERY_MARCH_LIVE_PERMILLE: *value = pair_units_ ? (uint64_t)(pair_live_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
+        case WV_QUERY_MARCH_ROUNDS: {
+            if (!pair_map_ || pair_nw_ < 1) {
+                *value = 0;
+                return WV_OK;
+            }
+            const uint64_t slots = 256ull * (uint64_t)std::max(1, wv::kPairMaxWaves / pair_nw_);
+            const uint64_t wgs = pair_units_ ? 8ull * pair_units_longest_
+                                             : 8ull * (uint64_t)((pair_strips_ + 7) / 8) * (uint64_t)pair_chunks_ * (uint64_t)std::max(1, pair_windows_);
+            *value = (wgs + slots - 1) / slots;
+            return WV_OK;
+        }
         case WV_QUERY_SWEEP_LIVE_PERMILLE: *value = tile_list_ ? (uint64_t)(tile_active_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }

@@ -461,7 +461,7 @@ class Engine:
         _check(self.lib.wv_kernel_time_detail(self.h, C.byref(ms), C.byref(n), C.byref(steps)))
         return ms.value, n.value, steps.value
 
-    QUERY_PASSES, QUERY_XWALL_ENTRIES, QUERY_FIELDS, QUERY_MARCH_LIVE_PERMILLE, QUERY_SWEEP_LIVE_PERMILLE = 0, 1, 2, 3, 4
+    QUERY_PASSES, QUERY_XWALL_ENTRIES, QUERY_FIELDS, QUERY_MARCH_LIVE_PERMILLE, QUERY_SWEEP_LIVE_PERMILLE, QUERY_MARCH_ROUNDS = 0, 1, 2, 3, 4, 5
 
     def query(self, what):
         """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
