@@ -301,3 +301,30 @@ def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
         assert single.query(E.Engine.QUERY_MARCH_ROUNDS) == 1
     finally:
         single.close()
+
+
+def test_soft_source_on_a_slab_face_for_many_steps(_step_mode):
+    """A source on a slab face is injected by its owner and by the neighbour that holds a ghost copy of the plane.  The
+    owner's exchange of that face plane runs on the halo stream while its compute stream moves on: the next sample must
+    not be added before the exchange has read the plane, or the neighbour adds it a second time (soft sources; about one
+    random chain in 1 500 hit this before SlabComm::wait_ghosts waited for the slab's own pushes too).  Thin slabs, so
+    that a step is over almost before its exchange has started; many steps, several times."""
+    rng = np.random.default_rng(11)
+    dims = (24, 24, 14)
+    gmesh = global_mesh(dims, "box", rng)
+    plane = dims[0] * dims[1]
+    live = gmesh.nodes["boundary_type"] != 0
+    layouts = [SlabLayout(dims, r, 3) for r in range(3)]
+    steps = 300
+    for rep in range(6):
+        z = layouts[1].z1 - 1 if rep % 2 == 0 else layouts[1].z0      # the middle slab's top / bottom face
+        source = z * plane + (7 + rep) * dims[0] + 9
+        assert gmesh.nodes["boundary_type"][source] & M.ID_INSIDE
+        gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0)
+        gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0)
+        signal = rng.uniform(-0.1, 0.1, steps)
+        receivers = [source, source + plane, source - plane]
+        want = single_domain(gmesh, "f64", gprev, gcur, E.SOURCE_SOFT, source, signal, receivers, steps)
+        got = slab_chain(gmesh, 3, "f64", gprev, gcur, E.SOURCE_SOFT, source, signal, receivers, steps)
+        assert want["done"] == steps and want["flag"] == 0
+        assert_same(got, want, gmesh)

@@ -273,6 +273,14 @@ bool SlabComm::wait_ghosts(hipStream_t compute, int field, std::string* err) {
         if (hi_ && hi_->pushed_lo_set_[field] &&
             !hip_ok(hipStreamWaitEvent(compute, hi_->pushed_lo_[field], 0), "hipStreamWaitEvent", err))
             return false;
+        // ... and MY pushes have read my face planes: what follows on the compute stream may write into them -- a source that
+        // lies on a slab face gets its sample added to this very field, and a push that read the plane after that would hand
+        // the neighbour (which adds the sample to its ghost copy itself) the sample twice.  (Found by tools/extended_fuzz.py,
+        // about one chain in 1 500; the RCCL transport's "ghosts ready" event already covers this rank's sends.)
+        for (int f = 0; f < 4; ++f) {
+            if (pushed_lo_set_[f] && !hip_ok(hipStreamWaitEvent(compute, pushed_lo_[f], 0), "hipStreamWaitEvent", err)) return false;
+            if (pushed_hi_set_[f] && !hip_ok(hipStreamWaitEvent(compute, pushed_hi_[f], 0), "hipStreamWaitEvent", err)) return false;
+        }
         return true;
     }
     if (!pending_) return true;

@@ -47,7 +47,7 @@ public:
     void set_fields(void* const* fields, int n_fields, size_t plane_bytes, int nz);
 
     // The compute stream must not read the ghost planes of field buffer `field` before the exchange that fills them
-    // has landed.
+    // has landed -- nor write into this slab's face planes (a source on a slab face) before its own exchanges have read them.
     bool wait_ghosts(hipStream_t compute, int field, std::string* err);
     // Faces of field buffer `field` (planes 1 and nz-2 when the matching ghost exists) are final on
     // `compute`: exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
