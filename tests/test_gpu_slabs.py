@@ -273,9 +273,7 @@ def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
     every register of every CU until all of them retire together, at its end -- so a slab with a neighbour takes the
     chunking with two rounds where that costs little (engine_pair.hip.h, ensure_pair), one domain keeps the single
     round.  1024 x 1024 rows: 256 strips of 8 waves = the chip's 256 workgroup slots."""
-    if _step_mode != "two-step-passes":
-        pytest.skip("about the two-step march")
-    from wayverb_amd.slab import box_slab_mesh
+    from wayverb_amd.slab import box_slab_mesh                  # (meshes this size take two-step passes in either mode)
     n, nz = 1024, 128
     coeffs = M.bench_materials()
     engines = []

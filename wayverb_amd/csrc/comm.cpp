@@ -277,10 +277,8 @@ bool SlabComm::wait_ghosts(hipStream_t compute, int field, std::string* err) {
         // lies on a slab face gets its sample added to this very field, and a push that read the plane after that would hand
         // the neighbour (which adds the sample to its ghost copy itself) the sample twice.  (Found by tools/extended_fuzz.py,
         // about one chain in 1 500; the RCCL transport's "ghosts ready" event already covers this rank's sends.)
-        for (int f = 0; f < 4; ++f) {
-            if (pushed_lo_set_[f] && !hip_ok(hipStreamWaitEvent(compute, pushed_lo_[f], 0), "hipStreamWaitEvent", err)) return false;
-            if (pushed_hi_set_[f] && !hip_ok(hipStreamWaitEvent(compute, pushed_hi_[f], 0), "hipStreamWaitEvent", err)) return false;
-        }
+        // (the halo stream runs them in order: the latest one stands for all)
+        if (last_own_push_ && !hip_ok(hipStreamWaitEvent(compute, last_own_push_, 0), "hipStreamWaitEvent", err)) return false;
         return true;
     }
     if (!pending_) return true;
@@ -349,6 +347,7 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
                 return false;
             if (!hip_ok(hipEventRecord(pushed_lo_[field], stream_), "hipEventRecord", err)) return false;
             pushed_lo_set_[field] = true;
+            last_own_push_ = pushed_lo_[field];
         }
         if (has_hi_ && hi_) {
             if (earlier && hi_->steps_done_ >= steps_done_ &&
@@ -368,6 +367,7 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
                 return false;
             if (!hip_ok(hipEventRecord(pushed_hi_[field], stream_), "hipEventRecord", err)) return false;
             pushed_hi_set_[field] = true;
+            last_own_push_ = pushed_hi_[field];
         }
         return true;
     }

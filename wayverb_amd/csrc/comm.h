@@ -96,6 +96,7 @@ private:
     // pushes into the buffer it is about to read, whatever its neighbours have pushed since)
     hipEvent_t pushed_lo_[4] = {nullptr, nullptr, nullptr, nullptr}, pushed_hi_[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pushed_lo_set_[4] = {false, false, false, false}, pushed_hi_set_[4] = {false, false, false, false};
+    hipEvent_t last_own_push_ = nullptr;  // the latest of the above to be recorded
     // ends of this slab's steps / two-step passes, by parity of their count
     hipEvent_t step_done_[2] = {nullptr, nullptr};
     hipEvent_t bulk_done_ = nullptr;
