@@ -145,7 +145,7 @@ class Chain:
         faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
         rest = [p for p in self.OWNED if p not in faces]
         self.op(S, "faces: sweep + boundary nodes", reads=self.planes(k, cur, self.ALL) | self.planes(k, nxt, faces), writes=self.planes(k, nxt, faces))
-        self.exchange_faces(k, nxt)
+        yield nxt                                           # exchange_faces(nxt): the driver below (transports differ)
         self.bulk(k, "interior sweep", reads=self.planes(k, cur, self.OWNED) | self.planes(k, nxt, rest), writes=self.planes(k, nxt, rest))
         self.op(S, "interior boundary nodes", reads=self.planes(k, cur, self.OWNED) | self.planes(k, nxt, rest), writes=self.planes(k, nxt, rest))
         self.step_done(k)
@@ -160,7 +160,7 @@ class Chain:
         faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
         rest = [p for p in self.OWNED if p not in faces]
         self.op(S, "faces to t+1", reads=self.planes(k, b, self.ALL) | self.planes(k, a, faces), writes=self.planes(k, o1, faces))
-        self.exchange_faces(k, o1)
+        yield o1
         self.bulk(k, "march", reads=self.planes(k, b, self.ALL) | self.planes(k, a, self.OWNED), writes=self.planes(k, o1, rest) | self.planes(k, o2, rest))
         self.op(S, "boundary nodes to t+1", reads=self.planes(k, b, self.OWNED) | self.planes(k, a, rest), writes=self.planes(k, o1, rest))
 
@@ -173,26 +173,76 @@ class Chain:
         faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
         rest = [p for p in self.OWNED if p not in faces]
         self.op(S, "faces to t+2", reads=self.planes(k, o1, self.ALL) | self.planes(k, b, faces), writes=self.planes(k, o2, faces))
-        self.exchange_faces(k, o2)
+        yield o2
         self.op(S, "fix-up list + boundary nodes to t+2", reads=self.planes(k, o1, self.OWNED) | self.planes(k, b, rest), writes=self.planes(k, o2, rest))
         self.step_done(k)
 
     # --- engine_slab.hip.h: group_run ----------------------------------------------------------------------------------
+    def enqueue_all(self, make):
+        """One step (or half a pass) of every slab, lockstep as wv_run_group enqueues them: slab after slab."""
+        for k in range(self.n):
+            for buf in make(k):
+                self.exchange_faces(k, buf)
+
     def run(self, kinds):
-        """kinds: a sequence of "step" / "pass"; every slab takes the same ones, lockstep as wv_run_group enqueues them."""
+        """kinds: a sequence of "step" / "pass"; every slab takes the same ones."""
         prv, cur, spare = 0, 1, [2, 3]
         for kind in kinds:
             if kind == "step":
-                for k in range(self.n):
-                    self.enqueue_step(k, cur, prv)          # in place: the next field goes where `previous` was
+                self.enqueue_all(lambda k: self.enqueue_step(k, cur, prv))          # in place: the next field goes where `previous` was
                 prv, cur = cur, prv
             else:
-                for k in range(self.n):
-                    self.enqueue_pair_a(k, prv, cur, spare[0], spare[1])
-                for k in range(self.n):
-                    self.enqueue_pair_b(k, prv, cur, spare[0], spare[1])
+                self.enqueue_all(lambda k: self.enqueue_pair_a(k, prv, cur, spare[0], spare[1]))
+                self.enqueue_all(lambda k: self.enqueue_pair_b(k, prv, cur, spare[0], spare[1]))
                 prv, cur, spare = spare[0], spare[1], [prv, cur]
         return self
+
+
+class RcclChain(Chain):
+    """The same engine code over the RCCL transport: one process per slab, grouped ncclSend / ncclRecv on the halo stream
+    (comm.cpp, the non-local branch of exchange_faces), "ghosts ready" recorded behind them.  Ranks enqueue independently;
+    any interleaving that keeps each rank's own order is a valid host order, this one goes phase by phase.  A send / receive
+    pair is a rendezvous: what follows either side's group follows what preceded the other side's."""
+
+    def __init__(self, n, source=None, wait_for_ghosts=True):
+        super().__init__(n, Rules(), source)
+        self.wait_for_ghosts = wait_for_ghosts
+        self.exchanges = 0
+
+    def wait_ghosts(self, k, buf):
+        if self.wait_for_ghosts:
+            self.wait(("S", k), ("ghosts_ready", k))
+
+    def step_done(self, k):
+        pass
+
+    def bulk(self, k, name, reads, writes):
+        self.op(("S", k), name, reads, writes)              # (one GPU per rank: nobody to take turns with)
+
+    def enqueue_all(self, make):
+        runs = [make(k) for k in range(self.n)]
+        bufs = [next(r) for r in runs]                      # every rank up to its exchange
+        starts = []
+        for k in range(self.n):
+            self.record(("S", k), ("faces_ready", k))
+            self.wait(("H", k), ("faces_ready", k))
+            starts.append(self.op(("H", k), "ncclGroupStart"))
+        self.exchanges += 1
+        meet = {}
+        for k in range(self.n - 1):
+            self.pending_waits[("R", k, self.exchanges)] = [starts[k], starts[k + 1]]
+            meet[k] = self.op(("R", k, self.exchanges), "send / receive pair of ranks %d and %d meet" % (k, k + 1))
+        for k in range(self.n):
+            faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
+            ghosts = [p for p, nb in (("ghost_lo", self.lo(k)), ("ghost_hi", self.hi(k))) if nb is not None]
+            for pair in (k - 1, k):
+                if pair in meet:
+                    self.wait_op(("H", k), meet[pair])
+            self.op(("H", k), "sends and receives of buffer %d" % bufs[k], reads=self.planes(k, bufs[k], faces), writes=self.planes(k, bufs[k], ghosts))
+            self.record(("H", k), ("ghosts_ready", k))
+        for r in runs:
+            for _ in r:
+                raise AssertionError("one exchange per step or half pass")
 
 
 def unordered_conflicts(chain):
@@ -266,3 +316,13 @@ def test_the_wait_for_the_neighbours_previous_step_is_implied(kinds):
     safety net that costs nothing; this test records that it is one."""
     for source in SOURCES[:3]:
         assert not unordered_conflicts(Chain(3, Rules(war_on_ghosts=False), source).run(kinds))
+
+
+@pytest.mark.parametrize("n,source", CHAINS, ids=str)
+@pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
+def test_the_rccl_transport_orders_every_conflicting_access(n, kinds, source):
+    """The path no box here could run between GPUs: ghosts_ready, recorded on the halo stream behind a rank's sends and
+    receives, is the one event its compute stream waits for -- it covers the receives having landed AND the sends having read
+    the face planes (the race of the in-process transport does not exist here)."""
+    assert not unordered_conflicts(RcclChain(n, source).run(kinds))
+    assert unordered_conflicts(RcclChain(n, source, wait_for_ghosts=False).run(kinds))
