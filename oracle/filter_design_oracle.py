@@ -1,15 +1,16 @@
 """oracle/filter_design_oracle.py -- numpy restatement of the boundary filter design chain.
 TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference designs its wall filters with `itpp::yulewalk`
-(src/waveguide/include/waveguide/arbitrary_magnitude_filter.h:84-92); IT++ is not in the reference
-tree and is fetched unpinned at build time (config/dependencies.cmake:138), and the reference's own
-tests for this path hold no numbers (src/waveguide/tests/arbitrary_magnitude_filter.cpp asserts
-stability only; tests/fitted_boundary.cpp prints).  This file restates the published method
-(Friedlander & Porat 1984, modified Yule-Walker, as arranged in IT++ 4.3 filter_design.cpp)
-independently of wayverb_amd/csrc/filter_design.cpp -- numpy FFT / lstsq / roots instead of the
-hand-written transforms, QR and root finder there -- so agreement between the two checks the
-numerics of the product, not fidelity to IT++.
+PINNED by the reference's own output: the reference designs its wall filters with `itpp::yulewalk`
+(src/waveguide/include/waveguide/arbitrary_magnitude_filter.h:84-92); IT++ is not in the reference tree (fetched
+unpinned at build time, config/dependencies.cmake:138) and the reference's tests for this path hold no numbers
+(src/waveguide/tests/arbitrary_magnitude_filter.cpp asserts stability only; tests/fitted_boundary.cpp prints) -- but the tree
+holds what its `bin/fitted_boundary` utility printed (bin/fitted_boundary/output/coefficients.json: reflectance and impedance
+filters, order 6, of three absorption profiles at 44.1 kHz).  This file restates the published method (Friedlander & Porat
+1984, modified Yule-Walker, in the arrangement of IT++ 4.3's filter_design.cpp) and reproduces all 84 numbers of that file
+to 1e-13 (tests/test_filter_design.py, fixture tests/golden/fitted_boundary_reference.json = that data file).  It is
+independent of wayverb_amd/csrc/filter_design.cpp -- numpy FFT / lstsq / roots instead of the hand-written transforms, QR
+and root finder there.
 
   envelope handling     src/waveguide/src/frequency_domain_envelope.cpp:32-71
   256-point resampling  arbitrary_magnitude_filter.h:65-82, src/core/include/core/cosine_interp.h:45-80
@@ -55,7 +56,7 @@ def autocorrelation(lags, f, m):
     grid[0] = m[0]
     jstart = 0
     for i in range(len(f) - 1):
-        jstop = int(np.floor(f[i + 1] * nfft))
+        jstop = min(nfft, int(np.floor(f[i + 1] * (nfft + 1))) - 1)   # IT++'s index arithmetic (pinned: see the header)
         for j in range(jstart, jstop + 1):
             inc = 0.0 if jstop == jstart else (j - jstart) / (jstop - jstart)
             grid[j] = m[i] * (1 - inc) + m[i + 1] * inc

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Fixed numeric vectors for the wall filter design -> tests/golden/filter_design.npz.
 
-PARITY UNPINNED: the reference calls itpp::yulewalk (IT++ at an unpinned git HEAD, absent from the reference
-tree), so these are NOT outputs of the reference.  They are outputs of this repository's own restatement of the
-published modified Yule-Walker method (oracle/filter_design_oracle.py, numpy), frozen so that a change in
-either implementation is caught: tests/test_filter_design.py holds both the numpy restatement and the C++
-library (wayverb_amd/csrc/filter_design.cpp) to them.
+These are NOT outputs of the reference (its designer, itpp::yulewalk, is absent from its tree): they are outputs of this
+repository's restatement of the published modified Yule-Walker method (oracle/filter_design_oracle.py, numpy) -- which
+reproduces the numbers the reference did leave behind (tests/golden/fitted_boundary_reference.json,
+boundary_test_reference.json: tests/test_filter_design.py) -- frozen at more envelopes and sample rates, so that a change in
+either implementation is caught: tests/test_filter_design.py holds both the numpy restatement and the C++ library
+(wayverb_amd/csrc/filter_design.cpp) to them.
 
     python tests/golden/make_golden_filters.py        (CPU only; rewrites the .npz)
 """

@@ -1,10 +1,11 @@
 """Boundary filter design, host side, no GPU needed.
 
-Parity for this row is UNPINNED (see oracle/filter_design_oracle.py): the reference's designer is
-itpp::yulewalk, which is not in the reference tree.  What is checked: (a) the properties the
-reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp: every designed
-denominator is stable, on the same envelopes), (b) the C++ implementation against the independent
-numpy restatement to 1e-9, (c) that the designed response follows the requested magnitudes."""
+The reference's designer is itpp::yulewalk, which is not in the reference tree -- but the outputs of two of the reference's
+own utilities are (bin/fitted_boundary/output/coefficients.json, bin/boundary_test/output.soft/coefficients.txt), and this row is
+PINNED to them: the last two tests of this file (336 coefficients, product and oracle, to 1e-12).  Besides: (a) the properties
+the reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp: every designed denominator is stable, on
+the same envelopes), (b) the C++ implementation against the independent numpy restatement to 1e-9, (c) that the designed
+response follows the requested magnitudes, (d) frozen vectors at more envelopes and sample rates."""
 import numpy as np
 import pytest
 
@@ -121,8 +122,8 @@ def test_surface_coefficients_run_clean_in_the_oracle(built_library, oracle):
 
 def test_fixed_numeric_vectors(built_library):
     """tests/golden/filter_design.npz (generator: make_golden_filters.py): frozen outputs of this repository's
-    own Yule-Walker restatement -- NOT of the reference (itpp is not in its tree) -- so that a regression in
-    either implementation shows.  Envelopes incl. the reference test's, the concert-hall demo's two
+    own Yule-Walker restatement (which reproduces the reference's committed outputs, see the test below) at more
+    envelopes and sample rates than the reference left numbers for -- so that a regression in either implementation shows.  Envelopes incl. the reference test's, the concert-hall demo's two
     materials and three spectral shapes at three sample rates."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filter_design.npz"))
@@ -149,3 +150,52 @@ def test_fixed_numeric_vectors(built_library):
             imp = F.impedance_coefficients(c)
             assert close(imp["b"], g["impedance_%s_b" % key], 10 * TOL) and close(imp["a"], g["impedance_%s_a" % key], 10 * TOL), key
             assert F.is_stable(c["a"])
+
+
+def test_the_references_own_fitted_boundary_output(built_library):
+    """What pins this row: `bin/fitted_boundary/output/coefficients.json` in the reference tree is what its
+    own bin/fitted_boundary/fitted_boundary.cpp printed -- compute_reflectance_filter_coefficients (through itpp::yulewalk) and
+    to_impedance_coefficients at 44.1 kHz for three absorption profiles (rising 0 -> 1 over the 8 bands, falling 1 -> 0,
+    alternating 0 / 1; fitted_boundary.cpp:47-71).  tests/golden/fitted_boundary_reference.json is that data file, byte for
+    byte.  Product (csrc/filter_design.cpp) and oracle (numpy) both reproduce its 84 numbers to 1e-12."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fitted_boundary_reference.json")
+    records = json.load(open(path))["value0"]
+    profiles = {"sloping_fitted_0": np.linspace(0.0, 1.0, 8), "sloping_fitted_1": np.linspace(1.0, 0.0, 8),
+                "sudden": np.array([0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0])}
+    assert sorted(next(iter(r)) for r in records) == sorted(profiles)
+    for record in records:
+        (name, rec), = record.items()
+        want = {kind: {c: np.array([rec[kind][c]["value%d" % i] for i in range(7)]) for c in "ba"} for kind in ("reflectance", "impedance")}
+        r = F.reflectance_filter(profiles[name], 44100.0)
+        z = F.impedance_coefficients(r)
+        ob, oa = O.reflectance_filter(profiles[name], 44100.0)
+        zb, za = O.to_impedance(ob, oa)
+        for got, kind, c in ((r["b"], "reflectance", "b"), (r["a"], "reflectance", "a"), (z["b"], "impedance", "b"), (z["a"], "impedance", "a"),
+                             (ob, "reflectance", "b"), (oa, "reflectance", "a"), (zb, "impedance", "b"), (za, "impedance", "a")):
+            assert np.abs(got - want[kind][c]).max() <= 1e-12, (name, kind, c, np.abs(got - want[kind][c]).max())
+        assert F.is_stable(r["a"])
+
+
+def test_the_references_own_boundary_test_output(built_library):
+    """A second file the reference left behind: bin/boundary_test/output.soft/coefficients.txt (here
+    tests/golden/boundary_test_reference.json, byte for byte) -- the wall filters of plaster, wood and concrete
+    (boundary_test.cpp:311-331: seven band absorptions each, the eighth band 0) designed for 8 kHz, reflectance and
+    impedance form, once per angle of incidence of that utility's three runs."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boundary_test_reference.json")
+    records = json.load(open(path))
+    materials = {"plaster": [0.08, 0.08, 0.2, 0.5, 0.4, 0.4, 0.36, 0.0], "wood": [0.15, 0.15, 0.11, 0.1, 0.07, 0.06, 0.06, 0.0],
+                 "concrete": [0.02, 0.02, 0.03, 0.03, 0.03, 0.04, 0.07, 0.0]}
+    assert len(records) == 9 and {rec["material"] for rec in records.values()} == set(materials)
+    for rec in records.values():
+        r = F.reflectance_filter(materials[rec["material"]], 8000.0)
+        z = F.impedance_coefficients(r)
+        ob, oa = O.reflectance_filter(materials[rec["material"]], 8000.0)
+        zb, za = O.to_impedance(ob, oa)
+        for got, kind, c in ((r["b"], "reflectance", "b"), (r["a"], "reflectance", "a"), (z["b"], "impedance", "b"), (z["a"], "impedance", "a"),
+                             (ob, "reflectance", "b"), (oa, "reflectance", "a"), (zb, "impedance", "b"), (za, "impedance", "a")):
+            want = np.array([rec[kind][c]["value%d" % i] for i in range(7)])
+            assert np.abs(got - want).max() <= 1e-12, (rec["test"], kind, c)

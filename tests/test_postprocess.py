@@ -2,7 +2,9 @@
 
 Checked against oracle/postprocess_oracle.py: the float32 attenuator arithmetic bit for bit; the
 FFT filters to transform rounding; the resampler (PARITY UNPINNED: the reference calls libsamplerate)
-against exact band-limited interpolation; the chain around them with the resampler injected."""
+against exact band-limited interpolation; the chain around them with the resampler injected.
+(The chain as a whole, with microphone capsules, is held to numbers the reference itself produced in
+tests/test_mic_test_reference.py.)"""
 import numpy as np
 import pytest
 

@@ -25,10 +25,13 @@
 //   3. MA part: the causal half of the autocorrelation is fitted by B_c/A (Shanks), its doubled
 //      real spectrum on 256 points is factored through the cepstrum into a minimum-phase impulse
 //      response, and the numerator is the least-squares Shanks fit to that response.
-// Because the dependency is absent, parity for this row is against this repo's independent numpy
-// restatement of the same steps (test infrastructure; "parity unpinned") and against
-// the properties the reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp:
-// every designed denominator is stable).
+// IT++'s source is absent, but three of its results are not: the reference tree holds the output of its own
+// bin/fitted_boundary utility (bin/fitted_boundary/output/coefficients.json: reflectance and impedance filters of three
+// absorption profiles at 44.1 kHz, designed by the reference through itpp::yulewalk).  This file and the independent numpy
+// restatement (oracle/filter_design_oracle.py, test infrastructure) reproduce all 84 numbers to 1e-13
+// (tests/test_filter_design.py::test_the_references_own_fitted_boundary_output) -- that is what pins this row; the properties
+// the reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp: every designed denominator is
+// stable) are checked besides.
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -176,7 +179,9 @@ std::vector<double> design_autocorrelation(int lags, const std::vector<double>& 
     grid[0] = m[0];
     int jstart = 0;
     for (size_t i = 0; i + 1 < f.size(); ++i) {
-        const int jstop = (int)std::floor(f[i + 1] * (double)nfft);
+        // (IT++'s own index arithmetic -- floor(f (nfft + 1)) - 1, not floor(f nfft): with it the reference's committed
+        // outputs, bin/fitted_boundary/output/coefficients.json, are reproduced to 1e-13; tests/golden/fitted_boundary_reference.json)
+        const int jstop = std::min(nfft, (int)std::floor(f[i + 1] * (double)(nfft + 1)) - 1);
         for (int j = jstart; j <= jstop; ++j) {
             const double inc = jstop == jstart ? 0.0 : (double)(j - jstart) / (double)(jstop - jstart);
             grid[j] = m[i] * (1 - inc) + m[i + 1] * inc;

@@ -20,8 +20,8 @@
 //    96 % of the narrower Nyquist band, stop band from 100 %, >= 140 dB rejection): same
 //    length, gain and band limits, different coefficients.  Parity of this stage is therefore
 //    "unpinned"; it is tested against the analytic behaviour of an ideal band-limited resampler.
-// The HRTF attenuator needs the reference's measured HRTF tables (src/hrtf) and is out of scope;
-// the null and microphone methods are here.
+// What IS pinned: the chain as a whole with microphone capsules, at resampling ratio 1 -- the band energies the reference's own
+// bin/mic_test printed (bin/mic_test/output/*/waveguide.txt) are reproduced to 6e-4 (tests/test_mic_test_reference.py).
 #include <algorithm>
 #include <cmath>
 #include <complex>
