@@ -28,7 +28,7 @@
 // IT++'s source is absent, but three of its results are not: the reference tree holds the output of its own
 // bin/fitted_boundary utility (bin/fitted_boundary/output/coefficients.json: reflectance and impedance filters of three
 // absorption profiles at 44.1 kHz, designed by the reference through itpp::yulewalk).  This file and the independent numpy
-// restatement (oracle/filter_design_oracle.py, test infrastructure) reproduce all 84 numbers to 1e-13
+// restatement kept with the tests reproduce all 84 numbers to 1e-13
 // (tests/test_filter_design.py::test_the_references_own_fitted_boundary_output) -- that is what pins this row; the properties
 // the reference's own tests assert (src/waveguide/tests/arbitrary_magnitude_filter.cpp: every designed denominator is
 // stable) are checked besides.
