@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""The beginning of the reference's `bin/solution_growth` recording for a Dirac through a transparent soft source, over again
+(no GPU): 5.56 x 3.97 x 2.81 m room, 10 kHz, flat walls of absorption 0.006, source and receiver two nodes apart on every axis,
+soft source fed with make_transparent({1}), pressure at the receiver node (bin/solution_growth/solution_growth.cpp:66-196).
+What the reference recorded is in its tree: scripts/python/solution_growth_graphs/solution_growth.dirac.transparent.output.aif
+(85 173 float samples); its first N samples are kept as tests/golden/solution_growth_reference/dirac_transparent_head.npy
+(written by `--write-fixture`, which needs /root/reference).
+
+Only the beginning is comparable: the recording is of the growth a transparent Dirac excites in a closed mesh (it reaches 4e5 by
+the end), which follows rounding.  Set-up chain and coefficients are product code, the stepping is the oracle's (float), the
+transparent signal is restated in tests/test_transparent_source_kat.py (the mesh response comes from the reference's build).
+
+    python tools/solution_growth_reproduction.py [--steps 400] [--write-fixture]
+"""
+import argparse
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from wayverb_amd import engine as E, mesh as M, scene as S, simulation as sim  # noqa: E402
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "solution_growth_reference", "dirac_transparent_head.npy")
+REFERENCE_FILE = "/root/reference/scripts/python/solution_growth_graphs/solution_growth.dirac.transparent.output.aif"
+
+
+def read_aifc_float32(path):
+    d = open(path, "rb").read()
+    assert d[:4] == b"FORM" and d[8:12] == b"AIFC"
+    pos = 12
+    while pos < len(d):
+        cid, size = d[pos:pos + 4], struct.unpack(">I", d[pos + 4:pos + 8])[0]
+        if cid == b"COMM":
+            assert d[pos + 26:pos + 30] == b"FL32"
+        if cid == b"SSND":
+            off = struct.unpack(">I", d[pos + 8:pos + 12])[0]
+            return np.frombuffer(d[pos + 16 + off:pos + 8 + size], dtype=">f4").astype(np.float32)
+        pos += 8 + size + (size & 1)
+    raise ValueError("no sound data")
+
+
+def build(oracle):
+    """solution_growth.cpp:66-107: compute_voxels_and_mesh anchored at the receiver, then set_coefficients(to_flat_coefficients)."""
+    fs, c = 10000.0, 340.0
+    source, receiver = (4.8, 2.18, 2.12), (4.7, 2.08, 2.02)
+    v, t = S.box_scene((0.0, 0.0, 0.0), (5.56, 3.97, 2.81))
+    spacing = np.float32(sim.grid_spacing(c, 1.0 / fs))
+    lo, hi = v[:, :3].min(axis=0), v[:, :3].max(axis=0)
+    c0, c1 = S.compute_adjusted_boundary(lo, hi, np.asarray(receiver, dtype=np.float32), spacing)
+    side = 32
+    vox = E.voxelise(v, t, (c0, c1), side)
+    dims = tuple(int(x) for x in ((c1 - c0) / spacing).astype(np.int32))
+    mask = oracle.nodes_inside(dims, c0, float(spacing), vox, (c0, c1), side, t, v).astype(bool)
+    nodes, _ = oracle.classify(mask)
+    b = oracle.boundary_index_data(nodes, dims, c0, float(spacing), t, v)
+    coeffs = np.zeros(1, dtype=M.coefficients_dtype)
+    coeffs[0] = M.flat_coefficients(0.006)
+    mesh = M.Mesh(dims, nodes, coeffs, b[0], b[1], b[2], spacing=float(spacing))
+    vm = sim.VoxelsAndMesh(vox, (c0, c1), side, v, t, mesh, c0, np.array([[0.006] * 8]))
+    return vm, vm.compute_index(source), vm.compute_index(receiver)
+
+
+def reproduce(steps, oracle, threads=4):
+    import test_transparent_source_kat as T
+    vm, s, r = build(oracle)
+    mesh = vm.mesh
+    for idx in (s, r):
+        assert mesh.nodes["boundary_type"][idx] & M.ID_INSIDE
+    signal = np.zeros(steps)
+    t = T.make_transparent([1.0], T.mesh_impulse_response(steps + 2))
+    signal[:min(steps, len(t))] = t[:steps]
+    prev = np.zeros(mesh.num_nodes, dtype=np.float32)
+    cur = np.zeros(mesh.num_nodes, dtype=np.float32)
+    bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+    done, flag, traces = oracle.run(prev, cur, mesh, bd, E.SOURCE_SOFT, s, signal, steps, [r], threads=threads)
+    assert done == steps and flag == 0
+    return traces[:, 0].astype(np.float32), mesh.dims
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--write-fixture", action="store_true")
+    args = ap.parse_args()
+    if args.write_fixture:
+        head = read_aifc_float32(REFERENCE_FILE)[:1024]
+        os.makedirs(os.path.dirname(FIXTURE), exist_ok=True)
+        np.save(FIXTURE, head)
+        print("wrote", FIXTURE, head.shape)
+    from oracle.oracle import Oracle
+    got, dims = reproduce(args.steps, Oracle())
+    want = np.load(FIXTURE)[:args.steps]
+    print("mesh", dims, "first arrival:", got[:12], "reference:", want[:12])
+    scale = np.abs(want[:100]).max()
+    for n in (50, 100, 200, 300, args.steps):
+        n = min(n, args.steps)
+        print("first %4d samples: max |difference| %.3e (%.2e of the first arrival's %.4f)" % (n, np.abs(got[:n] - want[:n]).max(), np.abs(got[:n] - want[:n]).max() / scale, scale))
+
+
+if __name__ == "__main__":
+    main()
