@@ -13,6 +13,7 @@ transparent signal is restated in tests/test_transparent_source_kat.py (the mesh
     python tools/solution_growth_reproduction.py [--steps 400] [--write-fixture]
 """
 import argparse
+import math
 import os
 import struct
 import sys
@@ -24,8 +25,36 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from wayverb_amd import engine as E, mesh as M, scene as S, simulation as sim  # noqa: E402
 
-FIXTURE = os.path.join(ROOT, "tests", "golden", "solution_growth_reference", "dirac_transparent_head.npy")
-REFERENCE_FILE = "/root/reference/scripts/python/solution_growth_graphs/solution_growth.dirac.transparent.output.aif"
+FIXTURES = os.path.join(ROOT, "tests", "golden", "solution_growth_reference")
+FIXTURE = os.path.join(FIXTURES, "dirac_transparent_head.npy")
+REFERENCE_DIR = "/root/reference/scripts/python/solution_growth_graphs"
+SIGNALS = ("dirac", "sin_modulated_gaussian", "differentiated_gaussian", "ricker")   # (the fifth recording, "pcs", needs design_pcs_source)
+
+
+def fixture(name):
+    return os.path.join(FIXTURES, "%s_transparent_head.npy" % name)
+
+
+def kernel(name, valid_portion=0.1):
+    """The excitation signals of solution_growth.cpp:113-141 (src/core/include/core/kernel.h:16-58, src/core/src/kernel.cpp:14-33),
+    as float like the reference stores them."""
+    fc = valid_portion / 2
+    if name == "dirac":
+        return np.array([1.0], dtype=np.float32)
+    if name == "ricker":
+        delay = int(math.ceil(1.0 / fc))
+        t = np.arange(2 * delay + 1) - delay
+        u = (np.pi * fc * t) ** 2
+        return ((1.0 - 2.0 * u) * np.exp(-u)).astype(np.float32)
+    o = 1.0 / (2.0 * np.pi * fc)
+    delay = int(math.ceil(8.0 * o))
+    t = (np.arange(2 * delay + 1) - delay).astype(np.float64)
+    g = np.exp(-t * t / (2.0 * o * o))
+    if name == "sin_modulated_gaussian":
+        return (-g * np.sin(t / o)).astype(np.float32)
+    if name == "differentiated_gaussian":
+        return (-t * g / (o * o)).astype(np.float32)
+    raise ValueError(name)
 
 
 def read_aifc_float32(path):
@@ -64,14 +93,14 @@ def build(oracle):
     return vm, vm.compute_index(source), vm.compute_index(receiver)
 
 
-def reproduce(steps, oracle, threads=4):
+def reproduce(steps, oracle, threads=4, name="dirac", built=None):
     import test_transparent_source_kat as T
-    vm, s, r = build(oracle)
+    vm, s, r = built or build(oracle)
     mesh = vm.mesh
     for idx in (s, r):
         assert mesh.nodes["boundary_type"][idx] & M.ID_INSIDE
     signal = np.zeros(steps)
-    t = T.make_transparent([1.0], T.mesh_impulse_response(steps + 2))
+    t = T.make_transparent(kernel(name), T.mesh_impulse_response_table())       # (the reference's table has 512 entries)
     signal[:min(steps, len(t))] = t[:steps]
     prev = np.zeros(mesh.num_nodes, dtype=np.float32)
     cur = np.zeros(mesh.num_nodes, dtype=np.float32)
@@ -83,22 +112,27 @@ def reproduce(steps, oracle, threads=4):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--write-fixture", action="store_true")
     args = ap.parse_args()
     if args.write_fixture:
-        head = read_aifc_float32(REFERENCE_FILE)[:1024]
-        os.makedirs(os.path.dirname(FIXTURE), exist_ok=True)
-        np.save(FIXTURE, head)
-        print("wrote", FIXTURE, head.shape)
+        os.makedirs(FIXTURES, exist_ok=True)
+        for name in SIGNALS:
+            head = read_aifc_float32(os.path.join(REFERENCE_DIR, "solution_growth.%s.transparent.output.aif" % name))[:1024]
+            np.save(fixture(name), head)
+            print("wrote", fixture(name), head.shape)
     from oracle.oracle import Oracle
-    got, dims = reproduce(args.steps, Oracle())
-    want = np.load(FIXTURE)[:args.steps]
-    print("mesh", dims, "first arrival:", got[:12], "reference:", want[:12])
-    scale = np.abs(want[:100]).max()
-    for n in (50, 100, 200, 300, args.steps):
-        n = min(n, args.steps)
-        print("first %4d samples: max |difference| %.3e (%.2e of the first arrival's %.4f)" % (n, np.abs(got[:n] - want[:n]).max(), np.abs(got[:n] - want[:n]).max() / scale, scale))
+    oracle = Oracle()
+    built = build(oracle)
+    for name in SIGNALS:
+        got, dims = reproduce(args.steps, oracle, name=name, built=built)
+        want = np.load(fixture(name))[:args.steps]
+        scale = np.abs(want[:200]).max()
+        line = "%-24s peak of the first 200 samples %.5f; max |difference| over the first" % (name, scale)
+        for n in (100, 200, 300, 500, 1024):
+            n = min(n, args.steps)
+            line += "  %d: %.2e" % (n, np.abs(got[:n] - want[:n]).max())
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
