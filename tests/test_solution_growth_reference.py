@@ -41,3 +41,15 @@ def test_a_thousand_samples_of_the_other_recordings(room, oracle, name, bound):
     want = np.load(R.fixture(name))[:steps]
     assert np.abs(want).max() > 0.01
     assert np.abs(got - want).max() <= bound, np.abs(got - want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps,bound", [("dirac", 200, 1e-6), ("sin_modulated_gaussian", 1024, 4e-6), ("differentiated_gaussian", 1024, 2e-6),
+                                               ("ricker", 1024, 2e-6)])
+def test_the_recordings_with_the_engine_stepping(room, oracle, name, steps, bound):
+    """The same with the HIP engine (float) in the oracle's place: the MI355X against the GPU the reference's author ran it on."""
+    got, _ = R.reproduce(steps, oracle, name=name, built=room, use_engine=True)
+    want = np.load(R.fixture(name))[:steps]
+    assert np.abs(got - want).max() <= bound, np.abs(got - want).max()
+    again, _ = R.reproduce(steps, oracle, name=name, built=room)
+    assert got.tobytes() == again.tobytes()                                     # (and the engine's floats are the oracle's)

@@ -93,7 +93,7 @@ def build(oracle):
     return vm, vm.compute_index(source), vm.compute_index(receiver)
 
 
-def reproduce(steps, oracle, threads=4, name="dirac", built=None):
+def reproduce(steps, oracle, threads=4, name="dirac", built=None, use_engine=False):
     import test_transparent_source_kat as T
     vm, s, r = built or build(oracle)
     mesh = vm.mesh
@@ -102,6 +102,14 @@ def reproduce(steps, oracle, threads=4, name="dirac", built=None):
     signal = np.zeros(steps)
     t = T.make_transparent(kernel(name), T.mesh_impulse_response_table())       # (the reference's table has 512 entries)
     signal[:min(steps, len(t))] = t[:steps]
+    if use_engine:                                                              # the HIP engine, float, instead of the oracle
+        eng = E.Engine(mesh, precision="f32")
+        try:
+            done, traces = E.run_fast(eng, E.SOURCE_SOFT, s, signal, [r])
+        finally:
+            eng.close()
+        assert done == steps
+        return np.asarray(traces)[:, 0].astype(np.float32), mesh.dims
     prev = np.zeros(mesh.num_nodes, dtype=np.float32)
     cur = np.zeros(mesh.num_nodes, dtype=np.float32)
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
