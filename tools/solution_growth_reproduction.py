@@ -28,17 +28,78 @@ from wayverb_amd import engine as E, mesh as M, scene as S, simulation as sim  #
 FIXTURES = os.path.join(ROOT, "tests", "golden", "solution_growth_reference")
 FIXTURE = os.path.join(FIXTURES, "dirac_transparent_head.npy")
 REFERENCE_DIR = "/root/reference/scripts/python/solution_growth_graphs"
-SIGNALS = ("dirac", "sin_modulated_gaussian", "differentiated_gaussian", "ricker")   # (the fifth recording, "pcs", needs design_pcs_source)
+SIGNALS = ("dirac", "sin_modulated_gaussian", "differentiated_gaussian", "ricker", "pcs")
+KIND = {name: "transparent" for name in SIGNALS}
+KIND["pcs"] = "soft"                                                            # the fifth recording: a plain soft source (solution_growth.cpp:198-209)
 
 
 def fixture(name):
-    return os.path.join(FIXTURES, "%s_transparent_head.npy" % name)
+    return os.path.join(FIXTURES, "%s_%s_head.npy" % (name, KIND[name]))
+
+
+# ---- the physically-constrained source of src/waveguide/src/pcs.cpp (sheaffer2014), restated: not on the hot path, the fifth recording's input
+def factdbl(t):
+    out = 1.0                                                                   # pcs.h:16-23
+    while t >= 1:
+        out *= t
+        t -= 2
+    return out
+
+
+def maxflat(f0, order, amplitude, length):
+    h = np.zeros(length)                                                        # pcs.cpp:10-33
+    q = 2 * order - 1
+    for n in range(-q, q + 1):
+        if n == 0:
+            continue
+        top = factdbl(q) ** 2 * math.sin(n * 2 * math.pi * f0)
+        bot = n * factdbl(2 * order + n - 1) * factdbl(2 * order - n - 1)
+        h[n + q] = top / (bot * (2 if n % 2 != 0 else math.pi))
+    h[q] = 2 * f0
+    return h * (amplitude / np.abs(h).max())
+
+
+def compute_g0(acoustic_impedance, speed_of_sound, sample_rate, radius):
+    spacing = speed_of_sound * math.sqrt(3.0) / sample_rate                    # pcs.cpp:37-48, config.cpp:19-21
+    return (1.0 / 3) * (acoustic_impedance / speed_of_sound) * (4 * math.pi * radius * radius) / spacing
+
+
+def mech_sphere(mass, f0, q, period):
+    fs = 1 / period                                                             # pcs.cpp:50-65
+    w0 = 2 * math.pi * f0 * fs
+    k = mass * w0 ** 2
+    r = w0 * mass / q
+    beta = w0 / math.tan(w0 * period / 2)
+    den = mass * beta ** 2 + r * beta + k
+    b0 = beta / den
+    return b0, 0.0, -b0, (2 * (k - mass * beta ** 2)) / den, 1 - (2 * r * beta / den)
+
+
+def biquad(signal, coefficients):
+    b0, b1, b2, a1, a2 = coefficients                                           # core/filters_common.h:101-107,130-136
+    z1 = z2 = 0.0
+    out = np.empty(len(signal))
+    for i, x in enumerate(signal):
+        y = x * b0 + z1
+        z1 = x * b1 - a1 * y + z2
+        z2 = x * b2 - a2 * y
+        out[i] = y
+    return out
+
+
+def design_pcs_source(length, acoustic_impedance, speed_of_sound, sample_rate, radius, sphere_mass, low_cutoff_hz, low_q):
+    signal = maxflat(0.075, 16, 0.00025, length)                                # pcs.cpp:69-94
+    signal = biquad(signal, mech_sphere(sphere_mass, low_cutoff_hz / sample_rate, low_q, 1 / sample_rate))
+    signal = signal * compute_g0(acoustic_impedance, speed_of_sound, sample_rate, radius)
+    return biquad(signal, (sample_rate / 2, 0.0, -sample_rate / 2, 0.0, 0.0))
 
 
 def kernel(name, valid_portion=0.1):
     """The excitation signals of solution_growth.cpp:113-141 (src/core/include/core/kernel.h:16-58, src/core/src/kernel.cpp:14-33),
     as float like the reference stores them."""
     fc = valid_portion / 2
+    if name == "pcs":
+        return design_pcs_source(4096, 400, 340.0, 10000.0, 0.05, 0.025, 100, 0.7).astype(np.float32)   # solution_growth.cpp:118-127
     if name == "dirac":
         return np.array([1.0], dtype=np.float32)
     if name == "ricker":
@@ -100,7 +161,9 @@ def reproduce(steps, oracle, threads=4, name="dirac", built=None, use_engine=Fal
     for idx in (s, r):
         assert mesh.nodes["boundary_type"][idx] & M.ID_INSIDE
     signal = np.zeros(steps)
-    t = T.make_transparent(kernel(name), T.mesh_impulse_response_table())       # (the reference's table has 512 entries)
+    t = kernel(name)
+    if KIND[name] == "transparent":
+        t = T.make_transparent(t, T.mesh_impulse_response_table())              # (the reference's table has 512 entries)
     signal[:min(steps, len(t))] = t[:steps]
     if use_engine:                                                              # the HIP engine, float, instead of the oracle
         eng = E.Engine(mesh, precision="f32")
@@ -126,7 +189,7 @@ def main():
     if args.write_fixture:
         os.makedirs(FIXTURES, exist_ok=True)
         for name in SIGNALS:
-            head = read_aifc_float32(os.path.join(REFERENCE_DIR, "solution_growth.%s.transparent.output.aif" % name))[:1024]
+            head = read_aifc_float32(os.path.join(REFERENCE_DIR, "solution_growth.%s.%s.output.aif" % (name, KIND[name])))[:1024]
             np.save(fixture(name), head)
             print("wrote", fixture(name), head.shape)
     from oracle.oracle import Oracle
