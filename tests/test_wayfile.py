@@ -84,3 +84,28 @@ def test_concert_hall_configuration_builds_and_steps_on_the_cpu_chain(oracle, bu
     # 20 m away at 0.44 m per node and one node per step along an axis: nothing has arrived after 60 steps... or has it
     dist_nodes = np.abs(np.array(vm.compute_locator(source)) - np.array(vm.compute_locator(receiver))).sum()
     assert (np.abs(out["trace"][:, 0]).max() > 0) == (dist_nodes <= steps)
+
+
+def test_every_demo_bundle_of_the_reference_reads():
+    """All thirteen project bundles under the reference's demo/evaluation (boxes, the concert hall, the vault with four materials; microphone and
+    HRTF capsules; two receivers) go through the reader.  Needs the reference tree: skipped where it is not (the GPU box); two of the bundles
+    are fixtures of this repository anyway (tests/golden/concert.way, sample.way)."""
+    import glob
+    import os
+    bundles = sorted(glob.glob("/root/reference/demo/evaluation/*/*.way"))
+    if not bundles:
+        pytest.skip("no reference tree here")
+    assert len(bundles) == 13
+    modes = set()
+    for path in bundles:
+        cfg, v, t, absorptions = W.read_way(path)
+        assert len(v) >= 8 and len(t) >= 12 and int(np.asarray(t)[:, 0].max()) < len(absorptions)
+        a = np.asarray(absorptions, dtype=float)
+        assert a.shape[1] == 8 and (a >= 0).all() and (a <= 1).all()
+        assert len(cfg["sources"]) >= 1 and len(cfg["receivers"]) >= 1
+        for r in cfg["receivers"]:
+            assert len(r["position"]) == 3 and r["capsules"]
+            modes.update(c["mode"] for c in r["capsules"])
+        wg = cfg["waveguide"][cfg["waveguide"]["mode"]]
+        assert 0 < wg["usable_portion"] <= 1 and wg["cutoff"] > 0
+    assert modes == {"microphone", "hrtf"}
