@@ -205,3 +205,52 @@ def test_hrtf_postprocess_with_a_flat_table_is_the_omni_microphone(built_library
     assert np.abs(hrtf - mic).max() < 0.02 * np.abs(mic).max()
     # and an ear that hears nothing from anywhere gives silence
     assert np.abs(P.postprocess_hrtf(bands, P.HrtfTable(np.zeros((36, 9, 2, 8))), output_sample_rate=16000.0)).max() == 0
+
+
+def test_hrtf_table_indices_follow_the_references_static_assertions(built_library):
+    """src/core/tests/vector_look_up_table.cpp:9-60 pins `azimuth_to_index` / `elevation_to_index` at compile time for tables of 24 x 11 and
+    20 x 9 cells.  The product keeps those functions inside the look-up (csrc/postprocess.cpp), so they are reached through it: a
+    table whose energies name their own cell, a head in the reference's rest position (looking down -z, `attenuator.cpp:20-35`: the
+    transform is the identity then), and directions built to have exactly the angles of the assertions (`index()` negates the azimuth:
+    vector_look_up_table.h:107-111, az_el.cpp:53-70).  Angles that sit exactly on a cell edge are left out -- a unit vector cannot
+    carry them exactly.  (The run-time cases of that file, `index(pt)` at :64-78, contradict `compute_azimuth` as the tree has it --
+    (0, 0, 1) is azimuth 180 there, not 0 -- and are not followed; orientable.cpp:13-26 is.)"""
+    def cell(az_num, el_num, azimuth_deg, elevation_deg):
+        e = np.zeros((az_num, el_num, 2, 8))
+        e[:, :, :, 0] = (100 * np.arange(az_num)[:, None, None] + np.arange(el_num)[None, :, None])
+        a, l = np.radians(-azimuth_deg), np.radians(elevation_deg)       # index() looks up -azimuth
+        direction = (np.sin(a) * np.cos(l), np.sin(l), -np.cos(a) * np.cos(l))   # compute_pointing, az_el.cpp:72-76
+        code = int(round(float(P.hrtf_attenuation(P.HrtfTable(e), direction)[0])))
+        return code // 100, code % 100
+
+    for azimuth, want in ((0, 0), (5, 0), (-5, 0), (355, 0), (10, 1), (15, 1), (20, 1), (-45, 21)):
+        assert cell(24, 11, azimuth, 0)[0] == want, azimuth
+    for elevation, want in ((0, 5), (5, 5), (-5, 5), (10, 6), (15, 6), (20, 6), (90, 10), (-90, 0)):
+        assert cell(24, 11, 0, elevation)[1] == want, elevation
+    for azimuth, want in ((0, 0), (8, 0), (26, 1), (355, 0), (-5, 0), (180, 10)):
+        assert cell(20, 9, azimuth, 0)[0] == want, azimuth
+    for elevation, want in ((0, 4), (-8, 4), (8, 4), (-10, 3), (90, 8), (-90, 0)):
+        assert cell(20, 9, 0, elevation)[1] == want, elevation
+    # orientable.cpp:13-26 through the same door: straight ahead is azimuth 0, to the right (+x) is +90 degrees = -90 in the table
+    assert cell(24, 11, 0, 0) == (0, 5) and cell(24, 11, -90, 0)[0] == 18
+
+
+def test_head_orientation_follows_the_references_transform_cases(built_library):
+    """src/core/tests/attenuator.cpp:21-78: `transform(orientation, v)` for four head orientations and the six axis directions.  Through the
+    look-up again: the cell a direction lands in for a turned head must be the cell its transformed direction lands in for the head at rest."""
+    e = np.zeros((24, 11, 2, 8))
+    e[:, :, :, 0] = (100 * np.arange(24)[:, None, None] + np.arange(11)[None, :, None])
+    table = P.HrtfTable(e)
+
+    def cell(direction, pointing=(0, 0, -1), up=(0, 1, 0)):
+        return int(round(float(P.hrtf_attenuation(table, direction, pointing, up)[0])))
+
+    axes = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    cases = {((0, 0, -1), (0, 1, 0)): axes,                                                         # the default orientation: identity
+             ((1, 0, 0), (0, 1, 0)): [(0, 0, -1), (0, 0, 1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)],
+             ((0, 0, 1), (0, -1, 0)): [(1, 0, 0), (-1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)],
+             ((1, 0, 0), (0, -1, 0)): [(0, 0, -1), (0, 0, 1), (0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0)]}
+    for (pointing, up), images in cases.items():
+        for v, image in zip(axes, images):
+            assert cell(v, pointing, up) == cell(image), (pointing, up, v, image)
+    assert len({cell(v) for v in axes}) == 6
