@@ -42,6 +42,18 @@ def test_the_reference_data_is_what_the_patterns_predict():
     assert (bi[4][4:] < 0.35 * omni[4][4:]).all() and (card[8][4:] < 0.35 * omni[8][4:]).all()
 
 
+def test_the_band_energy_measure_passes_the_references_own_checks_of_it():
+    """`per_band_energy` is the reference utility's yardstick, restated in the tool: src/frequency_domain/tests/multiband.cpp:9-36 (white noise
+    reads the same in all eight bands, to 20 %) and reconstruction.cpp:13-28 (neighbouring bands' crossovers meet: edge_i (1 + w) = edge_i+1 (1 - w))."""
+    rng = np.random.default_rng(3)
+    lo, hi = 20 / 44100.0, 20000 / 44100.0
+    energy = np.array(R.per_band_energy(rng.uniform(-1, 1, 10000).astype(np.float32), lo, hi))
+    assert (np.abs(energy - energy.mean()) / energy.mean() < 0.2).all(), energy
+    edges, w = R.band_edges(lo, hi, 8), R.width_factor(lo, hi, 8, 1.0)
+    for a, b in zip(edges[:-1], edges[1:]):
+        assert abs((a + a * w) - (b - b * w)) < 1e-9
+
+
 def test_two_angles_of_mic_test_with_the_oracle_stepping(built_library, oracle):
     """Angle 0 (on axis) and angle 5 (112.5 degrees: cardioid and bidirectional capsules both well off their maxima)."""
     indices = [0, 5]
