@@ -226,6 +226,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    halo = None
+    if world > 1:
+        # what the exchange cost this rank: planes handed to neighbours, and how long the compute stream stood at "ghost planes
+        # in place" (every fourth wait is bracketed by events on the engine's stream: the part of the exchange that the interior
+        # work did not hide).  Read before kernel_time_detail, which resets the timing counters.
+        Q = E.Engine
+        waits = eng.query(Q.QUERY_HALO_WAITS)
+        halo = {"bytes_sent_per_step": round(eng.query(Q.QUERY_HALO_BYTES_SENT) / max(1, total_steps)),
+                "exchanges_per_step": round(eng.query(Q.QUERY_HALO_EXCHANGES) / max(1, total_steps), 3),
+                "exposed_wait_us_per_wait": round(eng.query(Q.QUERY_HALO_WAIT_NS) / 1e3 / waits, 2) if waits else None,
+                "timed_waits": int(waits),
+                "passes_with_both_exchanges_under_the_march": int(eng.query(Q.QUERY_EARLY_PASSES)), "passes": int(eng.query(Q.QUERY_PASSES)),
+                "rank": rank}
     kernel_ms, launches, timed_steps = eng.kernel_time_detail()
     eng.enable_kernel_timing(False)
 
@@ -280,10 +293,20 @@ def main():
         "config": {"workload": "%dx%dx%d box mesh, %s pressures, walls of 4 mixed materials (2 flat, 2 frequency-dependent order-6 IIR), hard-source impulse + 1 receiver"
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
                    "per_gpu": "%dx%dx%d z-slab" % (nx, ny, layout.z1 - layout.z0), "decomposition": "z-slabs x%d" % world,
-                   "halo": "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass), overlapped with the interior" if world > 1 else "none",
+                   "halo": "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass, both under the march: the faces' second step runs on that stream between them)" if world > 1 else "none",
+                   "halo_measured": halo,
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     # which bound `frac` is a fraction of: the dominant kernel's own algorithmic bytes (NOT SURVEY.md 8(d)'s
+                     # 24 B per node-update when the engine takes two-step passes -- that figure is below as
+                     # single_step_equivalent / whole_step_frac_at_24B_per_update)
+                     "frac_bound": ("two-step pass, %d B per node-update (4 fields x %d B per node and launch)" % (2 * elem, elem)) if two_step
+                                   else ("single-step sweep, %d B per node-update" % (3 * elem)),
+                     # the WHOLE step (march + boundary launches + source / receiver work + gaps) at that same bound
+                     "whole_step_frac": round((fields_per_launch / steps_per_launch if launches else 3) * elem * owned_nodes
+                                              / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                      "time_steps_per_launch": round(steps_per_launch, 3),
                      "alg_bytes_per_launch": alg_bytes,

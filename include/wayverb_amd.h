@@ -110,7 +110,11 @@ typedef struct wv_tuning {
     int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
     int32_t boundary_xwall;   /* 1: in two-step passes the wall nodes that face along x work on compact copies of what they would gather from the fields */
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
-    int32_t reserved_[7];
+    int32_t slab_early;       /* z-slabs, two-step passes: 1 = the faces AND the planes next to them are stepped ahead of the march, so that both
+                               * halo exchanges of a pass (and the faces' second step, on the halo stream) run under it; 0 = the second exchange
+                               * follows the march (the form of rounds 2 and 3) */
+    int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
+    int32_t reserved_[5];
 } wv_tuning;
 
 typedef struct wv_options {
@@ -227,9 +231,15 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
  *   WV_QUERY_SWEEP_LIVE_PERMILLE   the same for the single-step sweep's tiles
  *   WV_QUERY_MARCH_ROUNDS    how many times over the two-step march's workgroups fill the chip's workgroup slots (0 before the
  *                            first pass).  A slab with a neighbour marches in two rounds at least where that costs little, so
- *                            that the exchange of its t+1 faces gets a CU before the march ends */
+ *                            that the exchange of its t+1 faces gets a CU before the march ends
+ *   WV_QUERY_HALO_WAIT_NS, WV_QUERY_HALO_WAITS   z-slabs with kernel timing on: total time the compute stream stood waiting for
+ *                            ghost planes (the part of the halo exchange the interior work did not hide), over that many timed
+ *                            waits (every fourth); both reset by wv_kernel_time
+ *   WV_QUERY_HALO_EXCHANGES, WV_QUERY_HALO_BYTES_SENT   exchanges issued and bytes handed to neighbours since creation
+ *   WV_QUERY_EARLY_PASSES    two-step passes of a slab that ran both exchanges under the march (wv_tuning::slab_early) */
 enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_QUERY_MARCH_LIVE_PERMILLE = 3,
-       WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5 };
+       WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5, WV_QUERY_HALO_WAIT_NS = 6, WV_QUERY_HALO_WAITS = 7,
+       WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

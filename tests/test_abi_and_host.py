@@ -134,7 +134,7 @@ def test_tuning_reaches_the_options_struct_and_unknown_fields_are_refused(built_
     assert opt.struct_size == ctypes.sizeof(E.WvOptions) and opt.precision == E.PRECISION_F64 and opt.stream_variant == 2
     t = opt.tuning
     assert (t.pair, t.pair_inner_fix, t.pair_wide, t.pair_unit_planes, t.tile_lists, t.fuse_pre_post, t.graph, t.boundary_lds,
-            t.boundary_order, t.boundary_xwall) == (-1, 1, 1, 32, 1, 1, 0, 1, 1, 1)
+            t.boundary_order, t.boundary_xwall, t.slab_early, t.pair_split_rows) == (-1, 1, 1, 32, 1, 1, 0, 1, 1, 1, 1, 0)
     old = dict(E.default_tuning)
     try:
         E.default_tuning.clear()
@@ -153,7 +153,7 @@ def test_tuning_reaches_the_options_struct_and_unknown_fields_are_refused(built_
 def test_no_kernel_of_the_engine_spills(built_library):
     """The march runs on 255 of 256 VGPRs and used to carry 44 B of scratch per lane, worth 7 % of its time:
     the compiler's own account of engine.hip's kernels, written beside the library by wayverb_amd.build, must show no
-    scratch in any of them, two waves per SIMD for the march and at least four for the boundary kernels."""
+    scratch in any of them, two waves per SIMD for the march and at least three for the boundary kernels (126-144 VGPRs)."""
     from wayverb_amd import build as B
     text = open(B.RESOURCES).read()
     blocks = re.split(r"remark: Function Name: ", text)[1:]

@@ -426,3 +426,47 @@ def test_x_facing_walls_on_compact_copies(oracle, dims, src_x, expect_active, ta
     assert a[0] == b[0] == steps and a[1].tobytes() == b[1].tobytes()
     for x, y in zip(a[2], b[2]):
         assert x.tobytes() == y.tobytes()
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_graph_replays_between_passes_leave_no_stale_wall_copies(oracle, tag, dtype):
+    """Round-3 advisor, medium: a batch of 16 is captured as a hipGraph of single steps, a batch of 4 is taken as two
+    two-step passes (which leave the x-facing walls' compact copies valid), the next batch of 16 REPLAYS the graph --
+    no host code of enqueue_step runs -- and the passes after it must refill the copies from the fields instead of
+    using the 16-steps-old ones.  Against the oracle, fields and filter memories, after every run."""
+    nx, ny, nz = 40, 21, 23
+    rng = np.random.default_rng(77)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2), np.array([M.flat_coefficients(0.2)], dtype=M.coefficients_dtype)])
+    mesh = M.box_mesh(nx, ny, nz, coefficients=coeffs, surface_of_face=[0, 1, 2, 0, 1, 2])
+    ci = mesh.compute_index
+    live = mesh.nodes["boundary_type"] != 0
+    init = [np.where(live, rng.uniform(-0.25, 0.25, mesh.num_nodes), 0.0).astype(dtype) for _ in range(2)]
+    lengths = [16, 4, 16, 4, 6, 16, 2]
+    sig = rng.uniform(-0.2, 0.2, sum(lengths))
+    src = ci(nx // 2, ny // 2, nz // 2)
+    recv = [ci(1, 5, 6), ci(2, 5, 6), ci(nx - 2, 7, 4), src]
+    set_tuning(pair=1, graph=1)
+    eng = E.Engine(mesh, precision=tag)
+    try:
+        eng.write_field(init[0], E.BUF_PREVIOUS)
+        eng.write_field(init[1], E.BUF_CURRENT)
+        eng.set_source(E.SOURCE_SOFT, src, sig)
+        eng.set_receivers(recv)
+        prev, cur = init[0].copy(), init[1].copy()
+        bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
+        at, passes = 0, 0
+        for n in lengths:
+            done, flag = eng.run_steps(n)
+            assert (done, flag) == (n, 0)
+            steps, oflag, _ = oracle.run(prev, cur, mesh, bd, E.SOURCE_SOFT, src, sig[at:at + n], n, recv, threads=2)
+            assert (steps, oflag) == (n, 0)           # (n is even: prev / cur are back in their roles)
+            at += n
+            assert eng.read_field(E.BUF_CURRENT).tobytes() == cur.tobytes(), (n, at)
+            assert eng.read_field(E.BUF_PREVIOUS).tobytes() == prev.tobytes(), (n, at)
+            for d in (1, 2, 3):
+                assert eng.read_boundary_data(d).tobytes() == bd[d - 1].tobytes(), (n, at, d)
+            if n < 16:
+                passes += n // 2
+        assert eng.query(E.Engine.QUERY_PASSES) == passes and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
+    finally:
+        eng.close()

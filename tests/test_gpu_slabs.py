@@ -14,18 +14,22 @@ from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes"])
+@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes", "two-step-passes-round-3-order"])
 def _step_mode(request):
-    """Every test of this file runs twice: with the engine's default choice (single steps on meshes this
-    small) and with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
-    twice per pass -- t+1, then t+2 (engine.hip::enqueue_pair_a / _b).  Slabs with fewer than four
-    planes cannot take two-step passes, and then the whole chain falls back together."""
+    """Every test of this file runs three times: with the engine's default choice (single steps on meshes this
+    small); with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
+    twice per pass -- t+1, then t+2 (engine_pair.hip.h, enqueue_pair_a / _b) -- both exchanges under the march, the
+    faces' second step on the halo stream (round 4); and with passes in the order of round 3 (wv_tuning::slab_early = 0:
+    the second exchange after the march), which is also what a slab with a source within two planes of a cut falls back
+    to.  Slabs with fewer than four planes cannot take two-step passes, and then the whole chain falls back together."""
     old = dict(E.default_tuning)
-    if request.param == "two-step-passes":
+    E.default_tuning.pop("pair", None)
+    E.default_tuning.pop("slab_early", None)
+    if request.param.startswith("two-step-passes"):
         E.default_tuning["pair"] = 1
-    else:
-        E.default_tuning.pop("pair", None)
-    yield request.param
+        if request.param.endswith("round-3-order"):
+            E.default_tuning["slab_early"] = 0
+    yield "two-step-passes" if request.param.startswith("two-step-passes") else request.param
     E.default_tuning.clear()
     E.default_tuning.update(old)
 
@@ -100,9 +104,10 @@ def slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, recei
         prev.append(e.read_field(E.BUF_PREVIOUS)[lo:hi])
         for d in range(3):
             bd[d].append(e.read_boundary_data(d + 1))
+    queries = ([e.query(E.Engine.QUERY_PASSES) for e in engines], [e.query(E.Engine.QUERY_EARLY_PASSES) for e in engines])
     group.close()
     return dict(done=done, flag=flag, trace=trace, ghost_trace=ghost_trace, cur=np.concatenate(cur), detail=detail,
-                prev=np.concatenate(prev), bd=[np.concatenate(b) for b in bd])
+                prev=np.concatenate(prev), bd=[np.concatenate(b) for b in bd], queries=queries)
 
 
 def boundary_rows(gmesh, d):
@@ -326,3 +331,45 @@ def test_soft_source_on_a_slab_face_for_many_steps(_step_mode):
         got = slab_chain(gmesh, 3, "f64", gprev, gcur, E.SOURCE_SOFT, source, signal, receivers, steps)
         assert want["done"] == steps and want["flag"] == 0
         assert_same(got, want, gmesh)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("dz", [-3, -2, -1, 0, 1, 2])
+def test_sources_around_a_cut_and_which_slabs_keep_the_older_order(built_library, precision, dz, _step_mode):
+    """Round 4: a slab's pass steps its faces and the planes next to them ahead of the march and the faces once more on the halo
+    stream, between the two exchanges -- unless the source lies in its planes g, f, n next to a cut (the sample of step t+1 goes
+    in after the march; the faces' second step would read those planes before it).  Sources from three planes below a cut to two
+    above it, soft and hard, with receivers on both sides: bit-identical to the single domain, and the slabs that kept the older
+    order are exactly the ones that see the source within two planes of the cut."""
+    rng = np.random.default_rng(400 + dz)
+    dims, world = (36, 20, 45), 3                                  # 15 planes per slab
+    gmesh = global_mesh(dims, "box", rng)
+    dtype = np.float32 if precision == "f32" else np.float64
+    live = gmesh.nodes["boundary_type"] != 0
+    gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    layouts = [SlabLayout(dims, r, world) for r in range(world)]
+    plane = dims[0] * dims[1]
+    cut = layouts[1].z0                                             # first plane of slab 1
+    z = cut + dz
+    source = z * plane + 9 * dims[0] + 17
+    assert gmesh.nodes["boundary_type"][source] & M.ID_INSIDE
+    receivers = [source, source + plane, source - plane, (cut - 1) * plane + 5 * dims[0] + 5, cut * plane + 5 * dims[0] + 5,
+                 (layouts[2].z0) * plane + 11 * dims[0] + 30, 3 * plane + 4 * dims[0] + 4]
+    steps = 26
+    signal = rng.uniform(-0.1, 0.1, steps)
+    for kind in (E.SOURCE_SOFT, E.SOURCE_HARD):
+        want = single_domain(gmesh, precision, gprev, gcur, kind, source, signal, receivers, steps)
+        got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps)
+        assert want["done"] == steps and want["flag"] == 0
+        assert_same(got, want, gmesh)
+        passes, early = got["queries"]
+        if _step_mode == "two-step-passes":
+            assert all(p == (steps - 2) // 2 for p in passes), passes
+            if E.default_tuning.get("slab_early", 1) == 0:
+                assert early == [0, 0, 0]
+            else:
+                # slab 0 sees planes cut-2, cut-1 (its n, f) and cut (its ghost); slab 1 sees cut-1 (ghost), cut, cut+1 (f, n)
+                keeps_old = [cut - 2 <= z <= cut, cut - 1 <= z <= cut + 1, False]
+                assert [e == 0 for e in early] == keeps_old, (early, z - cut)
+                assert all(e in (0, p) for e, p in zip(early, passes))

@@ -12,6 +12,12 @@ at the time the wait is enqueued.
 
 It is a model, kept next to the code it restates (the rules are few); what it is good for: each rule in `Rules` can be switched
 off, and the tests show which hazards that rule, and no other, closes.
+
+Round 4: a two-step pass of a slab steps its face planes AND the planes next to them ahead of the march, and the faces' second
+step runs on the HALO stream between the two exchanges (engine_pair.hip.h, `slab_early_now`): both exchanges are then under the
+march.  The model has the planes that takes (`next_lo` / `next_hi`), the launches on the halo stream, the per-slab fallback to
+the older order when a source lies within two planes of a cut -- neighbours need not agree -- and `Rules.early` switches
+the whole chain back to the older order.
 """
 import itertools
 from dataclasses import dataclass, field
@@ -25,6 +31,8 @@ class Rules:
     previous_step_by_parity: bool = True   # exchange_faces: the neighbour's PREVIOUS step is over (else: its latest enqueued step)
     own_pushes: bool = True                # wait_ghosts: this slab's own pushes have read its face planes
     war_on_ghosts: bool = True             # exchange_faces waits for the neighbour's step end at all
+    early: bool = True                     # two-step passes: faces + next planes first, the faces' t+2 on the halo stream (round 4)
+    halo_waits_for_ghosts: bool = True     # ... whose launches wait for the neighbours' pushes of t+1 (wait_ghosts on the halo stream)
 
 
 @dataclass
@@ -48,6 +56,7 @@ class Chain:
         self.steps_done = [0] * n
         self.last_own_push = [None] * n
         self.last_bulk = None
+        self.early_now = [False] * n
 
     # --- stream primitives -----------------------------------------------------------------------------------
     def op(self, stream, name, reads=(), writes=()):
@@ -89,9 +98,15 @@ class Chain:
             return ["ghost_lo"]
         return []
 
+    def early_pass(self, k):
+        """slab_early_now(): the round-4 order unless a source (or its ghost copy) lies in planes g, f, n of this slab."""
+        if not self.rules.early:
+            return False
+        return not any(p != "inner" for p in self.source_planes(k))
+
     # --- comm.cpp ----------------------------------------------------------------------------------------------
-    def wait_ghosts(self, k, buf):
-        S = ("S", k)
+    def wait_ghosts(self, k, buf, stream=None):
+        S = stream or ("S", k)
         for nb, ev in ((self.lo(k), "pushed_hi"), (self.hi(k), "pushed_lo")):
             if nb is None:
                 continue
@@ -102,10 +117,11 @@ class Chain:
         if self.rules.own_pushes:
             self.wait_op(S, self.last_own_push[k])
 
-    def exchange_faces(self, k, buf):
+    def exchange_faces(self, k, buf, on_halo=False):
         S, H = ("S", k), ("H", k)
-        self.record(S, ("faces_ready", k))
-        self.wait(H, ("faces_ready", k))
+        if not on_halo:                                    # (faces produced on the halo stream itself: stream order)
+            self.record(S, ("faces_ready", k))
+            self.wait(H, ("faces_ready", k))
         c = self.steps_done[k]
         for nb, mine, theirs, ev in ((self.lo(k), "face_lo", "ghost_hi", "pushed_lo"), (self.hi(k), "face_hi", "ghost_lo", "pushed_hi")):
             if nb is None:
@@ -133,8 +149,8 @@ class Chain:
         self.last_bulk = self.op(S, name, reads, writes)
 
     # --- engine_single.hip.h: enqueue_step ---------------------------------------------------------------------------
-    OWNED = ["face_lo", "inner", "face_hi"]
-    ALL = ["ghost_lo", "face_lo", "inner", "face_hi", "ghost_hi"]
+    OWNED = ["face_lo", "next_lo", "inner", "next_hi", "face_hi"]
+    ALL = ["ghost_lo"] + OWNED + ["ghost_hi"]
 
     def enqueue_step(self, k, cur, nxt):
         S = ("S", k)
@@ -145,44 +161,63 @@ class Chain:
         faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
         rest = [p for p in self.OWNED if p not in faces]
         self.op(S, "faces: sweep + boundary nodes", reads=self.planes(k, cur, self.ALL) | self.planes(k, nxt, faces), writes=self.planes(k, nxt, faces))
-        yield nxt                                           # exchange_faces(nxt): the driver below (transports differ)
+        yield nxt, False                                    # exchange_faces(nxt): the driver below (transports differ)
         self.bulk(k, "interior sweep", reads=self.planes(k, cur, self.OWNED) | self.planes(k, nxt, rest), writes=self.planes(k, nxt, rest))
         self.op(S, "interior boundary nodes", reads=self.planes(k, cur, self.OWNED) | self.planes(k, nxt, rest), writes=self.planes(k, nxt, rest))
         self.step_done(k)
 
     # --- engine_pair.hip.h: enqueue_pair_a / _b ----------------------------------------------------------------------
+    def sides(self, k):
+        return [side for side, nb in (("lo", self.lo(k)), ("hi", self.hi(k))) if nb is not None]
+
     def enqueue_pair_a(self, k, a, b, o1, o2):
         S = ("S", k)
+        early = self.early_pass(k)
+        self.early_now[k] = early
         self.wait_ghosts(k, b)
         src = self.source_planes(k)
         if src:
             self.op(S, "source sample into t", reads=self.planes(k, b, src), writes=self.planes(k, b, src))
-        faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
-        rest = [p for p in self.OWNED if p not in faces]
-        self.op(S, "faces to t+1", reads=self.planes(k, b, self.ALL) | self.planes(k, a, faces), writes=self.planes(k, o1, faces))
-        yield o1
-        self.bulk(k, "march", reads=self.planes(k, b, self.ALL) | self.planes(k, a, self.OWNED), writes=self.planes(k, o1, rest) | self.planes(k, o2, rest))
+        faces = ["face_" + side for side in self.sides(k)]
+        first = faces + (["next_" + side for side in self.sides(k)] if early else [])       # stepped ahead of the march
+        rest = [p for p in self.OWNED if p not in first]                                     # t+1 by the march + the big boundary launch
+        marched = [p for p in self.OWNED if p not in faces]                                  # t+2 by the march + the big boundary launch
+        self.op(S, "faces%s to t+1" % (" and the planes next to them" if early else ""),
+                reads=self.planes(k, b, self.ALL) | self.planes(k, a, first), writes=self.planes(k, o1, first))
+        yield o1, False
+        self.bulk(k, "march", reads=self.planes(k, b, self.ALL) | self.planes(k, a, self.OWNED), writes=self.planes(k, o1, rest) | self.planes(k, o2, marched))
         self.op(S, "boundary nodes to t+1", reads=self.planes(k, b, self.OWNED) | self.planes(k, a, rest), writes=self.planes(k, o1, rest))
 
     def enqueue_pair_b(self, k, a, b, o1, o2):
-        S = ("S", k)
-        self.wait_ghosts(k, o1)
+        S, H = ("S", k), ("H", k)
         src = self.source_planes(k)
-        if src:
-            self.op(S, "source sample into t+1", reads=self.planes(k, o1, src), writes=self.planes(k, o1, src))
-        faces = [p for p, nb in (("face_lo", self.lo(k)), ("face_hi", self.hi(k))) if nb is not None]
-        rest = [p for p in self.OWNED if p not in faces]
-        self.op(S, "faces to t+2", reads=self.planes(k, o1, self.ALL) | self.planes(k, b, faces), writes=self.planes(k, o2, faces))
-        yield o2
-        self.op(S, "fix-up list + boundary nodes to t+2", reads=self.planes(k, o1, self.OWNED) | self.planes(k, b, rest), writes=self.planes(k, o2, rest))
+        faces = ["face_" + side for side in self.sides(k)]
+        marched = [p for p in self.OWNED if p not in faces]
+        if self.early_now[k]:
+            # halo stream, behind exchange #1: t+1 ghosts in place -> the faces' second step -> exchange #2
+            near = faces + ["ghost_" + side for side in self.sides(k)] + ["next_" + side for side in self.sides(k)]
+            if self.rules.halo_waits_for_ghosts:
+                self.wait_ghosts(k, o1, stream=H)
+            self.op(H, "faces to t+2 (halo stream)", reads=self.planes(k, o1, near) | self.planes(k, b, faces), writes=self.planes(k, o2, faces))
+            yield o2, True
+            if src:                                         # (a slab with a source or receivers looks at the t+1 ghosts)
+                self.wait_ghosts(k, o1)
+                self.op(S, "source sample into t+1", reads=self.planes(k, o1, src), writes=self.planes(k, o1, src))
+        else:
+            self.wait_ghosts(k, o1)
+            if src:
+                self.op(S, "source sample into t+1", reads=self.planes(k, o1, src), writes=self.planes(k, o1, src))
+            self.op(S, "faces to t+2", reads=self.planes(k, o1, self.ALL) | self.planes(k, b, faces), writes=self.planes(k, o2, faces))
+            yield o2, False
+        self.op(S, "fix-up list + boundary nodes to t+2", reads=self.planes(k, o1, self.OWNED) | self.planes(k, b, marched), writes=self.planes(k, o2, marched))
         self.step_done(k)
 
     # --- engine_slab.hip.h: group_run ----------------------------------------------------------------------------------
     def enqueue_all(self, make):
         """One step (or half a pass) of every slab, lockstep as wv_run_group enqueues them: slab after slab."""
         for k in range(self.n):
-            for buf in make(k):
-                self.exchange_faces(k, buf)
+            for buf, on_halo in make(k):
+                self.exchange_faces(k, buf, on_halo)
 
     def run(self, kinds):
         """kinds: a sequence of "step" / "pass"; every slab takes the same ones."""
@@ -204,14 +239,14 @@ class RcclChain(Chain):
     any interleaving that keeps each rank's own order is a valid host order, this one goes phase by phase.  A send / receive
     pair is a rendezvous: what follows either side's group follows what preceded the other side's."""
 
-    def __init__(self, n, source=None, wait_for_ghosts=True):
-        super().__init__(n, Rules(), source)
+    def __init__(self, n, source=None, wait_for_ghosts=True, early=True):
+        super().__init__(n, Rules(early=early), source)
         self.wait_for_ghosts = wait_for_ghosts
         self.exchanges = 0
 
-    def wait_ghosts(self, k, buf):
+    def wait_ghosts(self, k, buf, stream=None):
         if self.wait_for_ghosts:
-            self.wait(("S", k), ("ghosts_ready", k))
+            self.wait(stream or ("S", k), ("ghosts_ready", k))
 
     def step_done(self, k):
         pass
@@ -221,11 +256,13 @@ class RcclChain(Chain):
 
     def enqueue_all(self, make):
         runs = [make(k) for k in range(self.n)]
-        bufs = [next(r) for r in runs]                      # every rank up to its exchange
+        yielded = [next(r) for r in runs]                   # every rank up to its exchange
+        bufs = [y[0] for y in yielded]
         starts = []
         for k in range(self.n):
-            self.record(("S", k), ("faces_ready", k))
-            self.wait(("H", k), ("faces_ready", k))
+            if not yielded[k][1]:                           # (faces stepped on the halo stream itself need no event)
+                self.record(("S", k), ("faces_ready", k))
+                self.wait(("H", k), ("faces_ready", k))
             starts.append(self.op(("H", k), "ncclGroupStart"))
         self.exchanges += 1
         meet = {}
@@ -275,17 +312,43 @@ def unordered_conflicts(chain):
 
 SEQUENCES = [["step"] * 6, ["pass"] * 5, ["step", "step", "pass", "pass", "step", "pass", "pass", "pass", "step", "step"],
              ["pass", "step", "pass", "step", "step", "pass", "pass"]]
-SOURCES = [None, (1, "face_lo"), (1, "face_hi"), (0, "face_hi"), (1, "inner")]
+SOURCES = [None, (1, "face_lo"), (1, "face_hi"), (0, "face_hi"), (1, "inner"), (1, "next_lo"), (0, "next_hi")]
 
 
-CHAINS = [(n, src) for n in (2, 3, 4) for src in SOURCES if not (src and src[1] == "face_hi" and src[0] + 1 >= n)]   # (the last slab has no upper face)
+CHAINS = [(n, src) for n in (2, 3, 4) for src in SOURCES if not (src and src[1].endswith("_hi") and src[0] + 1 >= n)]   # (the last slab has no upper face)
 
 
+@pytest.mark.parametrize("early", [True, False], ids=["both-exchanges-under-the-march", "round-3-order"])
 @pytest.mark.parametrize("n,source", CHAINS, ids=str)
 @pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
-def test_the_transport_orders_every_conflicting_access(n, kinds, source):
-    bad = unordered_conflicts(Chain(n, Rules(), source).run(kinds))
+def test_the_transport_orders_every_conflicting_access(n, kinds, source, early):
+    chain = Chain(n, Rules(early=early), source).run(kinds)
+    bad = unordered_conflicts(chain)
     assert not bad, bad[:3]
+    if early and "pass" in kinds:                          # (the order under test is the one that ran)
+        near_cut = source is not None and source[1] != "inner"
+        assert any("halo stream" in o.name for o in chain.ops) or (near_cut and n == 2)
+
+
+@pytest.mark.parametrize("kinds", [k for k in SEQUENCES if "pass" in k], ids=lambda s: "".join(k[0] for k in s))
+def test_a_source_near_a_cut_sends_only_the_slabs_that_see_it_back_to_the_older_order(kinds):
+    """The fallback is per slab: with the source on the upper face of slab 1 of 4, slabs 1 and 2 (owner and holder of the ghost
+    copy) keep round 3's order, slabs 0 and 3 step their faces on the halo stream -- and nothing is unordered."""
+    chain = Chain(4, Rules(), (1, "face_hi")).run(kinds)
+    assert not unordered_conflicts(chain)
+    on_halo = {o.stream[1] for o in chain.ops if "halo stream" in o.name}
+    assert on_halo == {0, 3}
+    chain = Chain(4, Rules(), (1, "next_lo")).run(kinds)     # one plane in from the face: the owner alone
+    assert not unordered_conflicts(chain)
+    assert {o.stream[1] for o in chain.ops if "halo stream" in o.name} == {0, 2, 3}
+
+
+@pytest.mark.parametrize("kinds", [k for k in SEQUENCES if "pass" in k], ids=lambda s: "".join(k[0] for k in s))
+def test_the_faces_second_step_on_the_halo_stream_must_wait_for_the_neighbours_pushes(kinds):
+    """What the halo stream's own wait_ghosts is for: without it a slab's face would be stepped to t+2 from a ghost plane its
+    neighbour has not pushed yet (the push runs on the NEIGHBOUR's halo stream).  Every hazard found is that one."""
+    bad = unordered_conflicts(Chain(3, Rules(halo_waits_for_ghosts=False), None).run(kinds))
+    assert bad and all(("push" in a and "halo stream" in b) or ("halo stream" in a and "push" in b) for _, a, _, b, _ in bad), bad[:3]
 
 
 @pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
@@ -293,10 +356,20 @@ def test_without_the_wait_for_its_own_pushes_a_source_on_a_face_races_with_the_p
     """Round 3's race, found by its symptom on the GPU first: the only hazards this rule closes are between a slab's push of a
     face plane and the next source sample into that plane -- and with no source on a face there is none (the neighbours'
     waits order everything else)."""
-    bad = unordered_conflicts(Chain(3, Rules(own_pushes=False), (1, "face_hi")).run(kinds))
+    bad = unordered_conflicts(Chain(3, Rules(own_pushes=False, early=False), (1, "face_hi")).run(kinds))
     assert bad and all("push face_hi" in a and "source sample" in b for _, a, _, b, _ in bad), bad[:3]
-    assert not unordered_conflicts(Chain(3, Rules(own_pushes=False), None).run(kinds))
-    assert not unordered_conflicts(Chain(3, Rules(own_pushes=False), (1, "inner")).run(kinds))
+    assert not unordered_conflicts(Chain(3, Rules(own_pushes=False, early=False), None).run(kinds))
+    assert not unordered_conflicts(Chain(3, Rules(own_pushes=False, early=False), (1, "inner")).run(kinds))
+
+
+@pytest.mark.parametrize("kinds", [k for k in SEQUENCES if "pass" in k], ids=lambda s: "".join(k[0] for k in s))
+def test_with_the_faces_stepped_on_the_halo_stream_that_wait_is_what_joins_the_two_streams(kinds):
+    """Round 4: the halo stream now carries launches that write this slab's own planes (the faces' t+2), not only copies out of
+    them.  The compute stream's wait for the slab's latest push -- the last thing on the halo stream in a pass -- is then what
+    orders the NEXT pass behind them, source or no source: without it the faces' second step races with everything that reads or
+    rewrites those planes afterwards, and every hazard involves the halo stream's launch or the push behind it."""
+    bad = unordered_conflicts(Chain(3, Rules(own_pushes=False), None).run(kinds))
+    assert bad and all("halo stream" in a or "halo stream" in b or "push" in a or "push" in b for _, a, _, b, _ in bad), bad[:3]
 
 
 @pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
@@ -324,5 +397,6 @@ def test_the_rccl_transport_orders_every_conflicting_access(n, kinds, source):
     """The path no box here could run between GPUs: ghosts_ready, recorded on the halo stream behind a rank's sends and
     receives, is the one event its compute stream waits for -- it covers the receives having landed AND the sends having read
     the face planes (the race of the in-process transport does not exist here)."""
-    assert not unordered_conflicts(RcclChain(n, source).run(kinds))
-    assert unordered_conflicts(RcclChain(n, source, wait_for_ghosts=False).run(kinds))
+    for early in (True, False):
+        assert not unordered_conflicts(RcclChain(n, source, early=early).run(kinds))
+        assert unordered_conflicts(RcclChain(n, source, wait_for_ghosts=False, early=early).run(kinds))

@@ -114,6 +114,8 @@ int main(int argc, char** argv) {
     a.cls_pitch = cls_pitch;
     a.z_begin = 0;
     a.z_end = n;
+    a.out1_z0 = 0;
+    a.out1_z1 = n;
     a.nw = pitch / 128;
     a.strips = (n + 3) / 4;
     a.strips_per_xcd = (a.strips + 7) / 8;

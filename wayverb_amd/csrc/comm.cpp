@@ -54,12 +54,16 @@ std::string& library_override() {
     static std::string path;
     return path;
 }
+// the override and "has the loader run" are read and written under one lock: wv_comm_use_library racing with another
+// thread's first communicator call either lands before the load or is refused
+std::mutex g_library_mutex;
 bool g_library_loaded = false;
 
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        std::lock_guard<std::mutex> lock(g_library_mutex);
         g_library_loaded = true;
         if (!library_override().empty()) {  // wv_comm_use_library: this file and nothing else
             r.handle = dlopen(library_override().c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -128,6 +132,7 @@ __global__ void flag_gather_kernel(const uint64_t* in, int* flags, int n) {
 }  // namespace
 
 bool SlabComm::use_library(const char* path, std::string* err) {
+    std::lock_guard<std::mutex> lock(g_library_mutex);
     if (g_library_loaded) {
         *err = "the collective library is already loaded: wv_comm_use_library must come before the first communicator call";
         return false;
@@ -191,6 +196,10 @@ bool SlabComm::init_local(int rank, int nranks, int device, hipStream_t comm_str
         *err = "ghost_lo/ghost_hi of the engine do not match its position in the slab chain";
         return false;
     }
+    if (device < 0 || device >= kMaxDevices) {
+        *err = "device ordinal beyond the in-process transport's turn table";
+        return false;
+    }
     if (!hip_ok(hipSetDevice(device), "hipSetDevice", err)) return false;
     local_ = true;
     device_ = device;
@@ -247,10 +256,10 @@ SlabComm::~SlabComm() {
     if (comm_) (void)rccl().comm_destroy(comm_);
     if (local_) {
         std::lock_guard<std::mutex> lock(g_turn_mutex);
-        DeviceTurn& t = g_turn[device_ % kMaxDevices];
+        DeviceTurn& t = g_turn[device_];
         if (t.owner == this) t = DeviceTurn{};
     }
-    for (hipEvent_t e : {bulk_done_, faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
+    for (hipEvent_t e : {halo_joined_, bulk_done_, faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
                          pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
@@ -295,7 +304,7 @@ bool SlabComm::step_done(hipStream_t compute, std::string* err) {
 bool SlabComm::bulk_begin(hipStream_t compute, std::string* err) {
     if (!local_ || nranks_ < 2) return true;
     std::lock_guard<std::mutex> lock(g_turn_mutex);
-    const DeviceTurn& t = g_turn[device_ % kMaxDevices];
+    const DeviceTurn& t = g_turn[device_];
     if (t.owner && t.owner != this) return hip_ok(hipStreamWaitEvent(compute, t.done, 0), "hipStreamWaitEvent", err);
     return true;
 }
@@ -304,13 +313,19 @@ bool SlabComm::bulk_end(hipStream_t compute, std::string* err) {
     if (!local_ || nranks_ < 2) return true;
     if (!hip_ok(hipEventRecord(bulk_done_, compute), "hipEventRecord", err)) return false;
     std::lock_guard<std::mutex> lock(g_turn_mutex);
-    DeviceTurn& t = g_turn[device_ % kMaxDevices];
+    DeviceTurn& t = g_turn[device_];
     t.owner = this;
     t.done = bulk_done_;
     return true;
 }
 
-bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) {
+bool SlabComm::join_halo(hipStream_t compute, std::string* err) {
+    if (!halo_joined_ && !hip_ok(hipEventCreateWithFlags(&halo_joined_, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    if (!hip_ok(hipEventRecord(halo_joined_, stream_), "hipEventRecord", err)) return false;
+    return hip_ok(hipStreamWaitEvent(compute, halo_joined_, 0), "hipStreamWaitEvent", err);
+}
+
+bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err, bool on_halo_stream) {
     if (field < 0 || field >= n_fields_ || !fields_[field] || nz_ < 3) {
         *err = "exchange_faces: no such field buffer";
         return false;
@@ -318,8 +333,11 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err) 
     const size_t plane_bytes = plane_bytes_;
     const int nz = nz_;
     char* base = static_cast<char*>(fields_[field]);
-    if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
-    if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
+    if (!on_halo_stream) {
+        if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
+        if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
+    }
+    planes_sent_ += (loopback_ ? 2u : 0u) + (!loopback_ && has_lo_ ? 1u : 0u) + (!loopback_ && has_hi_ ? 1u : 0u);
     if (local_) {
         // push my face planes into the neighbours' ghost planes of the same buffer.  The neighbour
         // may still be reading that ghost plane (it was part of its `current` one step ago): wait

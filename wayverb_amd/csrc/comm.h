@@ -51,7 +51,15 @@ public:
     bool wait_ghosts(hipStream_t compute, int field, std::string* err);
     // Faces of field buffer `field` (planes 1 and nz-2 when the matching ghost exists) are final on
     // `compute`: exchange them into the neighbours' ghost planes (planes nz-1 / 0 over there).
-    bool exchange_faces(hipStream_t compute, int field, std::string* err);
+    // `on_halo_stream`: the faces were produced by launches on the halo stream itself (a slab's two-step pass that steps its
+    // faces to t+2 there, between the two exchanges: engine_pair.hip.h) -- stream order covers it, `compute` is not involved.
+    bool exchange_faces(hipStream_t compute, int field, std::string* err, bool on_halo_stream = false);
+    // Everything enqueued on the halo stream so far happens before whatever `compute` is given next (the flag words of a
+    // batch are read back on the compute stream; launches on the halo stream write to them too).
+    bool join_halo(hipStream_t compute, std::string* err);
+    // planes handed to neighbours so far (each plane_bytes() long)
+    uint64_t planes_sent() const { return planes_sent_; }
+    size_t plane_bytes() const { return plane_bytes_; }
     // End of a step on `compute`: this slab has read the ghost planes of the step's `current` field
     // (the local transport may overwrite them once this has passed).
     bool step_done(hipStream_t compute, std::string* err);
@@ -84,6 +92,8 @@ private:
     hipStream_t stream_ = nullptr;
     hipEvent_t faces_ready_ = nullptr;
     hipEvent_t ghosts_ready_ = nullptr;
+    hipEvent_t halo_joined_ = nullptr;
+    uint64_t planes_sent_ = 0;
     hipEvent_t reduce_in_ = nullptr, reduce_out_ = nullptr;  // or_flags: compute stream -> halo stream -> compute stream
     bool pending_ = false;
     // field geometry

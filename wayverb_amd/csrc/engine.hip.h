@@ -40,10 +40,14 @@ public:
     int build_tile_lists(int z0, int z1);
     // ---- engine_single.hip.h
     int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr, int zb0 = 0, int zb1 = 0);
-    int launch_faces(Real* prev, const Real* cur, int* flag, Real* out);
+    // (`planes`: how many owned planes next to each neighbour -- 1: the face planes, 2: the faces and the planes next to them)
+    int launch_faces(Real* prev, const Real* cur, int* flag, Real* out, int planes = 1);
     wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const;
     // (z0 = z1 = -1: the boundary nodes of a slab's face planes)
-    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false);
+    // (z0 = z1 = -2: of the two planes next to each neighbour; `levels`: a two-step pass's launch over the bulk of the mesh,
+    // in which the x-facing walls go by position on their compact copies)
+    int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false,
+                        bool levels = false);
     wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
     // ---- engine_pair.hip.h
@@ -56,6 +60,9 @@ public:
     int build_xwall();
     void xwall_args(wv::BoundaryArgs<Real>& b) const;
     int enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
+    bool slab_early_now() const;
+    int begin_halo_wait_timing();
+    int end_halo_wait_timing(int token);
     int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
     int batch_pair_eligible(int* eligible) override;
     int batch_pair_prepare(int* ready, int* singles_first) override;
@@ -141,10 +148,12 @@ private:
         int source_kind;
         uint64_t signal_ptr, recv_ptr;
         bool lists;
+        uint64_t cur_ptr, prv_ptr;
         bool operator==(const GraphKey& o) const {
             return batch == o.batch && cur == o.cur && source_live == o.source_live && can_fuse == o.can_fuse &&
                    n_recv == o.n_recv && source_node == o.source_node && source_kind == o.source_kind &&
-                   signal_ptr == o.signal_ptr && recv_ptr == o.recv_ptr && lists == o.lists;
+                   signal_ptr == o.signal_ptr && recv_ptr == o.recv_ptr && lists == o.lists && cur_ptr == o.cur_ptr &&
+                   prv_ptr == o.prv_ptr;
         }
     };
     hipGraphExec_t graph_exec_ = nullptr;
@@ -190,6 +199,17 @@ private:
     uint32_t* zorder_rest_ = nullptr;  // (same allocation as zorder_)
     uint32_t* face_order_ = nullptr;   // (same allocation) the entries of a slab's face plane(s)
     uint32_t face_n_ = 0;
+    uint32_t* early_order_ = nullptr;  // (same allocation) the entries of the two planes next to each neighbour
+    uint32_t early_n_ = 0;
+    // a slab's two-step pass with both exchanges under the march (engine_pair.hip.h): planes whose t+1 the march stores
+    int pair_s0_ = 0, pair_s1_ = 0;
+    bool pair_early_ = false;          // the pass in flight is one (decided in part A, read by part B)
+    // time the compute stream spends waiting for ghost planes (wv_enable_kernel_timing on a slab): event pairs around wait_ghosts
+    std::vector<hipEvent_t> halo_events_;
+    int halo_ev_used_ = 0;
+    unsigned halo_timing_calls_ = 0;
+    double halo_wait_ms_ = 0;
+    uint64_t halo_wait_n_ = 0, halo_exchanges_ = 0, early_passes_ = 0;
     std::vector<uint32_t> plane_start_, plane_start_rest_;
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)
@@ -208,6 +228,8 @@ private:
     void* scratch_ = nullptr;
     Real courant_ = 0, courant_sq_ = 0;
     hipStream_t stream_ = nullptr, comm_stream_ = nullptr;
+    hipStream_t on_ = nullptr;  // the launch helpers' stream when it is not the compute stream (a slab's face work on its halo stream)
+    hipStream_t st() const { return on_ ? on_ : stream_; }
     StreamPlan plan_;
     int tune_variant_ = -1, tune_ry_ = 0, tune_nwx_ = 0, tune_nwy_ = 0, tune_zchunks_ = 0;
     std::vector<hipEvent_t> events_;

@@ -26,6 +26,42 @@ int Engine<Real>::drain_timing() {
         ++time_n_;
     }
     ev_used_ = 0;
+    for (int i = 0; i + 1 < halo_ev_used_; i += 2) {
+        float ms = 0;
+        WV_HIP(hipEventElapsedTime(&ms, halo_events_[i], halo_events_[i + 1]));
+        halo_wait_ms_ += ms;
+        ++halo_wait_n_;
+    }
+    halo_ev_used_ = 0;
+    return WV_OK;
+}
+
+// Kernel timing on a slab: how long the compute stream stands at "ghost planes in place" -- the part of the halo exchange that
+// the interior work did not hide -- between a pair of events around every fourth such wait (the pair itself costs stream time).
+template <typename Real>
+int Engine<Real>::begin_halo_wait_timing() {
+    if (!timing || !comm_ || (halo_timing_calls_++ & 3u) != 0) return -1;
+    if (halo_events_.empty()) {
+        halo_events_.resize(2 * 160);
+        for (auto& e : halo_events_)
+            if (hipEventCreate(&e) != hipSuccess) {
+                (void)hipGetLastError();
+                e = nullptr;
+            }
+    }
+    if (halo_ev_used_ + 2 > (int)halo_events_.size() || !halo_events_[halo_ev_used_] || !halo_events_[halo_ev_used_ + 1]) return -1;
+    if (hipEventRecord(halo_events_[halo_ev_used_], stream_) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return halo_ev_used_;
+}
+
+template <typename Real>
+int Engine<Real>::end_halo_wait_timing(int token) {
+    if (token < 0) return WV_OK;
+    WV_HIP(hipEventRecord(halo_events_[token + 1], stream_));
+    halo_ev_used_ = token + 2;
     return WV_OK;
 }
 
@@ -76,7 +112,10 @@ uint64_t Engine<Real>::plan_batch(uint64_t remaining) {
     batch_flags_reset_ = false;
     if (comm_ && batch) {
         static_assert(sizeof(int) == 4, "flag words are 32 bit");
-        if (hipMemsetD32Async((hipDeviceptr_t)flags_, static_flag_, (size_t)batch, stream_) == hipSuccess) batch_flags_reset_ = true;
+        if (hipMemsetD32Async((hipDeviceptr_t)flags_, static_flag_, (size_t)batch, stream_) == hipSuccess)
+            batch_flags_reset_ = true;
+        else
+            (void)hipGetLastError();  // (the steps then reset their flag words one by one; nothing sticky is left behind)
     }
     return batch;
 }
@@ -100,6 +139,8 @@ template <typename Real>
 int Engine<Real>::collect_batch(uint64_t batch) {
     DeviceGuard guard(device_);
     std::string cerr;
+    // a slab's faces may have been stepped on its halo stream, which raises flag bits like any other launch
+    if (comm_ && !comm_->join_halo(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     if (comm_ && !comm_->or_flags(stream_, flags_, (int)batch, &cerr)) return fail(WV_E_COMM, cerr);
     WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (n_recv_) {
@@ -176,7 +217,18 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             int singles_first = -1;
             if (eligible) {
                 int ready = 0, mine = 0;
-                if ((rc = batch_pair_prepare(&ready, &mine))) return rc;
+                rc = batch_pair_prepare(&ready, &mine);
+                if (rc && chain) {
+                    // Whatever went wrong here (an allocation beside the spare fields, mostly) the other ranks are about to
+                    // enter the all-reduce below: a rank that returned now would leave them there for good.  The chain stays
+                    // with single steps instead -- which need nothing that was not there before -- and this rank does not ask
+                    // again (wv_last_error keeps what happened).
+                    pair_failed_ = true;
+                    ready = mine = 0;
+                    (void)hipGetLastError();
+                    rc = WV_OK;
+                }
+                if (rc) return rc;
                 if (chain) {  // min of (2 - singles) = the most single sweeps any rank needs first
                     uint64_t words[2] = {(uint64_t)ready, (uint64_t)(2 - mine)};
                     if (!comm_->agree_min(stream_, words, 2, &cerr)) return fail(WV_E_COMM, cerr);
@@ -220,6 +272,9 @@ int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* ste
     time_n_ = 0;
     timed_steps_ = 0;
     timing_launches_ = 0;  // the next launch is timed again
+    halo_wait_ms_ = 0;
+    halo_wait_n_ = 0;
+    halo_timing_calls_ = 0;
     return WV_OK;
 }
 
@@ -248,6 +303,11 @@ int Engine<Real>::query(int what, uint64_t* value) {
             return WV_OK;
         }
         case WV_QUERY_SWEEP_LIVE_PERMILLE: *value = tile_list_ ? (uint64_t)(tile_active_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
+        case WV_QUERY_HALO_WAIT_NS: *value = (uint64_t)(halo_wait_ms_ * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_HALO_WAITS: *value = halo_wait_n_; return WV_OK;
+        case WV_QUERY_HALO_EXCHANGES: *value = halo_exchanges_; return WV_OK;
+        case WV_QUERY_HALO_BYTES_SENT: *value = comm_ ? comm_->planes_sent() * (uint64_t)comm_->plane_bytes() : 0; return WV_OK;
+        case WV_QUERY_EARLY_PASSES: *value = early_passes_; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

@@ -82,6 +82,10 @@ int Engine<Real>::ensure_pair() {
     pair_z1_ = z_end_ - (opt_.ghost_hi ? 1 : 0);
     m.march_begin = pair_z0_;
     m.march_end = pair_z1_;
+    // ... and when the planes next to the faces are stepped to t+1 with them (slab_early_now), the march stores its t+1 values one
+    // plane further in
+    pair_s0_ = z_begin_ + (opt_.ghost_lo ? 2 : 0);
+    pair_s1_ = z_end_ - (opt_.ghost_hi ? 2 : 0);
     // may boundary entries finish the inside nodes they face?  (once per mesh)
     if (pair_inner_ok_ < 0) {
         pair_inner_ok_ = 0;
@@ -487,14 +491,23 @@ void Engine<Real>::parallel_sort(std::vector<uint64_t>& v) {
 // Steps `slot` and `slot + 1` of a batch in one pass: fields (prv_, cur_) = (t-1, t) in, the spare
 // fields receive t+1 and t+2 and become (previous, current).
 //
-// On a slab the two time levels each need the neighbours' face planes, so a pass has two exchanges:
-//   part A  face planes to t+1 (sweep + boundary nodes, out of place) -> exchange #1 of the t+1 field
-//           -> march over the planes in between (t+1 and t+2) + their boundary nodes to t+1,
-//           overlapping the exchange
-//   part B  ghosts of t+1 landed -> source / receivers on t+1 -> face planes to t+2 (fix-up list of all
-//           their nodes + boundary nodes) -> exchange #2 of the t+2 field -> the other fix-up nodes and
-//           boundary nodes to t+2, overlapping it.
-// A chain inside one process (wv_run_group) enqueues part A of every slab before part B of any.
+// On a slab the two time levels each need the neighbours' face planes, so a pass has two exchanges.  Both run under the march
+// (round 4; slab_early_now()).  With f = a face plane, n = the owned plane next to it, g = the ghost plane beyond it:
+//   compute stream  [ghosts of t in place] -> f AND n to t+1 (one sweep launch + one launch for their boundary nodes, out of place)
+//                   -> MARCH over n .. n' (t+1 and t+2; it computes n's t+1 again for its own use but stores t+1 only from
+//                   the plane after n: its placeholders must not land on n's finished boundary values) -> boundary nodes of
+//                   the planes in between to t+1 -> [source / receivers on t+1] -> fix-up list, boundary nodes n .. n' to t+2
+//   halo stream     [f, n at t+1 final] -> exchange #1 (t+1 faces) -> f to t+2: a plain step of the face plane from t+1 at g, f, n
+//                   (sweep + boundary launch, on this stream) -> exchange #2 (t+2 faces)
+// Nothing on the halo stream needs the march: f's t+2 reads t+1 at g (exchange #1), f and n (the early launches).  The compute
+// stream meets the halo stream again at the next pass's "ghosts in place".  Five launches on the compute stream, two beside it.
+// A source within two planes of a cut (planes g, f, n: its t+1 sample would have to be in place before f's t+2) keeps THAT slab on
+// the older order, which differs in where things are enqueued, not in what is exchanged, so neighbours need not agree:
+//   part A  face planes to t+1 -> exchange #1 -> march over the planes in between + their boundary nodes to t+1
+//   part B  ghosts of t+1 landed -> source / receivers on t+1 -> face planes to t+2 -> exchange #2 (nothing left to hide
+//           behind but the last boundary launch) -> fix-up list and boundary nodes to t+2.
+// A chain inside one process (wv_run_group) enqueues part A of every slab before part B of any: part B opens with the halo
+// stream's wait for the neighbours' pushes of t+1, which must have been enqueued by then (comm.h, local transport).
 // `fuse_mid`: the source / receiver work of step t+1 (and a short fix-up list) rides in the t+1 boundary launch
 template <typename Real>
 int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live, bool fuse_mid) {
@@ -506,7 +519,13 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     int* flag2 = flags_ + slot + 1;
     int rc;
     std::string cerr;
-    if (comm_ && !comm_->wait_ghosts(stream_, cur_, &cerr)) return fail(WV_E_COMM, cerr);
+    const bool early = slab_early_now();
+    pair_early_ = early;
+    if (comm_) {
+        const int token = begin_halo_wait_timing();
+        if (!comm_->wait_ghosts(stream_, cur_, &cerr)) return fail(WV_E_COMM, cerr);
+        if ((rc = end_halo_wait_timing(token))) return rc;
+    }
     if (!pre_post_done_ && !(batch_flags_reset_ && !n_recv_ && !source_live)) {  // step t: flag words of both steps, source sample into t, receivers from t
         wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
         pp.flag2 = flag2;
@@ -514,9 +533,10 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     }
     pre_post_done_ = false;  // (else: the boundary launch before this pass has done it)
     if (comm_) {
-        if ((rc = launch_faces(A, B, flag1, O1))) return rc;
+        if ((rc = launch_faces(A, B, flag1, O1, early ? 2 : 1))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
+        ++halo_exchanges_;
     }
     wv::PairArgs<Real> a{};
     a.prev = A;
@@ -532,6 +552,8 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
     a.cls_pitch = cls_pitch_;
     a.z_begin = pair_z0_;
     a.z_end = pair_z1_;
+    a.out1_z0 = early ? pair_s0_ : pair_z0_;
+    a.out1_z1 = early ? pair_s1_ : pair_z1_;
     a.nw = pair_nw_;
     a.zc = pair_zc_;
     a.chunks = pair_chunks_;
@@ -594,10 +616,10 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
             nx.pitch = pitch_;
             pair_list_done_ = true;
         }
-        if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, &nx, O1))) return rc;
+        if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, &nx, O1, false, true))) return rc;
         pair_mid_done_ = true;
-    } else if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, nullptr, O1))) {
-        return rc;
+    } else if ((rc = launch_boundary(A, B, flag1, early ? pair_s0_ : pair_z0_, early ? pair_s1_ : pair_z1_, nullptr, O1, false, true))) {
+        return rc;  // (early: the planes next to the faces have been to t+1 already)
     }
     WV_HIP(hipGetLastError());
     return WV_OK;
@@ -631,17 +653,36 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     int* flag2 = flags_ + slot + 1;
     int rc;
     std::string cerr;
-    if (comm_ && !comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
-    if (!pair_mid_done_ && (n_recv_ || source_live)) {  // step t+1: source sample into t+1, receivers from it
+    const bool io_mid = !pair_mid_done_ && (n_recv_ || source_live);  // step t+1: source sample into t+1, receivers from it
+    if (comm_ && pair_early_) {
+        // halo stream, behind exchange #1: ghost planes of t+1 in place -> the face planes to t+2, one more plain step of theirs
+        // from t+1 at the ghost plane, the face and the plane next to it (all final since part A) -> exchange #2
+        if (!comm_->wait_ghosts(comm_stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
+        on_ = comm_stream_;
+        rc = launch_faces(B, O1, flag2, O2);
+        on_ = nullptr;
+        if (rc) return rc;
+        WV_HIP(hipGetLastError());
+        if (!comm_->exchange_faces(stream_, spare_[1], &cerr, true)) return fail(WV_E_COMM, cerr);
+        ++halo_exchanges_;
+        // compute stream: only a slab with a source or receivers looks at the t+1 ghosts (a receiver's neighbours may lie there)
+        if (io_mid && !comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
+    } else if (comm_) {
+        const int token = begin_halo_wait_timing();
+        if (!comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
+        if ((rc = end_halo_wait_timing(token))) return rc;
+    }
+    if (io_mid) {
         wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
         pp.flag = nullptr;  // reset in part A, and already written to by the march
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
-    if (comm_) {
+    if (comm_ && !pair_early_) {
         // the face planes to t+2: one more plain step of theirs, from the t+1 field with its ghost planes in place
         if ((rc = launch_faces(B, O1, flag2, O2))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
+        ++halo_exchanges_;
     }
     // t+2 of the nodes next to a boundary node / the source, from the complete t+1; then the boundary nodes
     // (most of them are faced by a boundary node and finished by its entry in the launch after this one)
@@ -651,14 +692,15 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
         // this launch (no boundary node, no node an entry finishes)
         wv::PrePostArgs<Real> nx = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
         if (fuse_next == 2) nx.flag2 = flags_ + slot + 3;
-        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, &nx, O2, pair_inner_ok_ > 0))) return rc;
+        if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, &nx, O2, pair_inner_ok_ > 0, true))) return rc;
         pre_post_done_ = true;
-    } else if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0))) {
+    } else if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0, true))) {
         return rc;
     }
     WV_HIP(hipGetLastError());
     if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     ++passes_taken_;
+    early_passes_ += pair_early_ ? 1 : 0;
     // roles: (previous, current) = (t+1, t+2); the fields that held t-1 and t are the spares now
     const int a_idx = prv_, b_idx = cur_;
     prv_ = spare_[0];
@@ -666,6 +708,20 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     spare_[0] = a_idx;
     spare_[1] = b_idx;
     return WV_OK;
+}
+
+// May this slab's next pass step its faces and the planes next to them ahead of the march (both exchanges under it)?
+template <typename Real>
+bool Engine<Real>::slab_early_now() const {
+    if (!comm_ || opt_.tuning.slab_early == 0 || !(opt_.ghost_lo || opt_.ghost_hi)) return false;
+    const int lo = opt_.ghost_lo ? 2 : 0, hi = opt_.ghost_hi ? 2 : 0;
+    if (z_end_ - z_begin_ < lo + hi + 4) return false;  // (something has to be left in between)
+    if (source_kind_ != WV_SOURCE_NONE) {
+        // the sample of step t+1 goes in after the march; a face's t+2 would read planes g, f, n before that
+        const int sz = (int)(source_node_ / ((uint64_t)pitch_ * (uint64_t)ny_));
+        if ((opt_.ghost_lo && sz < z_begin_ + 2) || (opt_.ghost_hi && sz >= z_end_ - 2)) return false;
+    }
+    return true;
 }
 
 // part 0 / 1 of the two-step pass that covers steps i and i + 1 of the batch

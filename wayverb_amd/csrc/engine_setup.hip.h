@@ -167,8 +167,12 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
             x.nz = nz_;
             x.pitch = pitch_;
             x.cls_pitch = cls_pitch_;
-            x.march_begin = z_begin_ + (opt_.ghost_lo ? 1 : 0);
-            x.march_end = z_end_ - (opt_.ghost_hi ? 1 : 0);
+            // (a slab: not in the face planes, which the march does not produce, nor -- when its passes may step the planes next
+            // to the faces ahead of the march, wv_tuning::slab_early -- in those: whoever steps a plane to t+1 outside the pass's
+            // two big boundary launches does it by gathering from the fields, and the copies of its entries would go stale)
+            const int off = opt_.tuning.slab_early != 0 ? 2 : 1;
+            x.march_begin = z_begin_ + (opt_.ghost_lo ? off : 0);
+            x.march_end = z_end_ - (opt_.ghost_hi ? off : 0);
             hipLaunchKernelGGL(wv::xwall_eligible_kernel, dim3((n1_ + 255) / 256), dim3(256), 0, stream_, x);
             WV_HIP(hipGetLastError());
             WV_HIP(hipMemcpyAsync(eligible.data(), flags_mem.p, n1_, hipMemcpyDeviceToHost, stream_));
@@ -300,17 +304,30 @@ int Engine<Real>::build_plane_order() {
         face_n_ = (uint32_t)face.size();
         if (face.empty()) face.push_back(0);
     }
+    // ... and of the TWO planes next to each neighbour (a two-step pass that steps them ahead of its march: engine_pair.hip.h)
+    std::vector<uint32_t> early;
+    {
+        const int lo = opt_.ghost_lo ? 2 : 0, hi = opt_.ghost_hi ? 2 : 0;
+        const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+        early.assign(order.begin() + plane_start_[z_begin_], order.begin() + plane_start_[zi0]);
+        early.insert(early.end(), order.begin() + plane_start_[zi1], order.begin() + plane_start_[z_end_]);
+        early_n_ = (uint32_t)early.size();
+        if (early.empty()) early.push_back(0);
+    }
     uint32_t* staged = nullptr;
-    WV_HIP(hipMalloc((void**)&staged, (order.size() + rest.size() + face.size()) * sizeof(uint32_t)));
+    WV_HIP(hipMalloc((void**)&staged, (order.size() + rest.size() + face.size() + early.size()) * sizeof(uint32_t)));
     if (hipMemcpy(staged, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(staged + order.size(), rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(staged + order.size() + rest.size(), face.data(), face.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(staged + order.size() + rest.size(), face.data(), face.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(staged + order.size() + rest.size() + face.size(), early.data(), early.size() * sizeof(uint32_t), hipMemcpyHostToDevice) !=
+            hipSuccess) {
         (void)hipFree(staged);
         return fail(WV_E_HIP, "copying the plane order of the boundary entries to the device failed");
     }
     zorder_ = staged;
     zorder_rest_ = staged + order.size();
     face_order_ = zorder_rest_ + rest.size();
+    early_order_ = face_order_ + face.size();
     return WV_OK;
 }
 
@@ -511,6 +528,9 @@ void Engine<Real>::release() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& e : events_) (void)hipEventDestroy(e);
     events_.clear();
+    for (auto& e : halo_events_)
+        if (e) (void)hipEventDestroy(e);
+    halo_events_.clear();
     for (int i = 0; i < 4; ++i)
         if (field_[i]) (void)hipFree(field_[i]);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);

@@ -12,13 +12,13 @@ template <int RY, int NWX, int NWY>
 void Engine<Real>::launch_shape(const wv::StreamArgs<Real>& a, unsigned grid) {
     if (plan_.variant == 2) {
         hipLaunchKernelGGL((wv::stream_sweep_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
-                           stream_, a);
+                           st(), a);
     } else if (plan_.variant == 3) {
         hipLaunchKernelGGL((wv::stream_sweep_nolds_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
-                           stream_, a);
+                           st(), a);
     } else {
         hipLaunchKernelGGL((wv::stream_march_kernel<Real, RY, NWX, NWY>), dim3(grid), dim3(64 * NWX * NWY), 0,
-                           stream_, a);
+                           st(), a);
     }
 }
 
@@ -90,10 +90,10 @@ int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, 
         a.tiles_per_xcd = (a.total_tiles + 7) / 8;
         grid = (unsigned)a.tiles_per_xcd * 8u;
     }
-    timed = timed && time_this_launch();
+    timed = timed && !on_ && time_this_launch();
     if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
     if (plan_.variant == 1) {
-        hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, stream_, a);
+        hipLaunchKernelGGL(wv::stream_naive_kernel<Real>, dim3(grid), dim3(plan_.block), 0, st(), a);
     } else if (plan_.ry == 2) {
         launch_ry<2>(a, grid);
     } else {
@@ -139,8 +139,9 @@ wv::BoundaryArgs<Real> Engine<Real>::boundary_args(Real* prev, const Real* cur, 
 // those planes (the sweep writes boundary nodes' old values back, see X_STORE_ALL).
 // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
 template <typename Real>
-int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner) {
-    const bool faces = z0 == -1 && z1 == -1;
+int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner,
+                                  bool levels) {
+    const bool faces = z0 == z1 && (z0 == -1 || z0 == -2);
     if (!n_entries_ || (z0 >= z1 && !faces)) return WV_OK;
     wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
     if (out) b.next = out;
@@ -151,14 +152,15 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
         nx = *next;
         nx.fused = 1;
     }
-    // a two-step pass's launches over the marched planes: the x-facing walls by position, on their compact copies
-    const bool xw = out && xw_active_ && z0 == pair_z0_ && z1 == pair_z1_;
+    // a two-step pass's launches over the bulk of the mesh: the x-facing walls by position, on their compact copies
+    // (all of them lie in the planes of either such launch: xwall_eligible_kernel, engine_setup.hip.h)
+    const bool xw = out && xw_active_ && levels;
     uint32_t n = n_entries_ - (xw ? n_xw_ : 0u);
     if (faces) {
         const int rc = build_plane_order();
         if (rc != WV_OK) return rc;
-        b.order = face_order_;
-        b.n_order = n = face_n_;
+        b.order = z0 == -1 ? face_order_ : early_order_;
+        b.n_order = n = z0 == -1 ? face_n_ : early_n_;
         if (!n) return WV_OK;
     } else if (z0 > z_begin_ || z1 < z_end_) {
         const int rc = build_plane_order();
@@ -177,25 +179,25 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
     const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && opt_.tuning.boundary_lds != 0;
     const dim3 grid((n + 255) / 256), block(256);
     if (lds && fix_inner)
-        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, stream_, b, nx);
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, st(), b, nx);
     else if (lds)
-        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false>), grid, block, 0, stream_, b, nx);
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false>), grid, block, 0, st(), b, nx);
     else if (fix_inner)
-        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, true>), grid, block, 0, stream_, b, nx);
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, true>), grid, block, 0, st(), b, nx);
     else
-        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false>), grid, block, 0, stream_, b, nx);
+        hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false>), grid, block, 0, st(), b, nx);
     return WV_OK;
 }
 
 // A slab's face plane(s) -- the first owned plane when there is a lower neighbour, the last when there is an upper one --
 // one step on: the sweep over both in ONE launch, then their boundary nodes in one.  `out`: as launch_stream.
 template <typename Real>
-int Engine<Real>::launch_faces(Real* prev, const Real* cur, int* flag, Real* out) {
-    const int lo = opt_.ghost_lo ? 1 : 0, hi = opt_.ghost_hi ? 1 : 0;
+int Engine<Real>::launch_faces(Real* prev, const Real* cur, int* flag, Real* out, int planes) {
+    const int lo = opt_.ghost_lo ? planes : 0, hi = opt_.ghost_hi ? planes : 0;
     const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
     int rc = launch_stream(prev, cur, flag, z_begin_, zi0, false, out, zi1, z_end_);
     if (rc) return rc;
-    return launch_boundary(prev, cur, flag, -1, -1, nullptr, out);
+    return launch_boundary(prev, cur, flag, -planes, -planes, nullptr, out);
 }
 
 // One loop body: [pre/post on device] + pressure update + boundary update; flag -> flags_[slot]
@@ -272,8 +274,11 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
 // Capture (once per batch shape) and replay a batch of `batch` steps.
 template <typename Real>
 int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) {
+    // (the field pointers are part of the key: a veto of two-step passes frees the spare fields and a later batch
+    // allocates new ones, and after passes `cur_` / `prv_` may name any two of the four)
     const GraphKey key{batch, cur_, source_live, can_fuse, n_recv_, source_node_, source_kind_, (uint64_t)(uintptr_t)signal_,
-                       (uint64_t)(uintptr_t)recv_nodes_, lists_built_ && tile_list_ != nullptr};
+                       (uint64_t)(uintptr_t)recv_nodes_, lists_built_ && tile_list_ != nullptr,
+                       (uint64_t)(uintptr_t)field_[cur_], (uint64_t)(uintptr_t)field_[prv_]};
     if (!graph_exec_ || !(key == graph_key_)) {
         if (graph_exec_) {
             (void)hipGraphExecDestroy(graph_exec_);
@@ -312,6 +317,10 @@ int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) 
     WV_HIP(hipMemcpyAsync(signal_base_dev_, &signal_pos_, sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
     WV_HIP(hipGraphLaunch(graph_exec_, stream_));
     // batch is even: the fields are back in their roles
+    // A replay runs no host code of enqueue_step: what that clears per step has to be cleared here -- the fields have moved
+    // on without the x-facing walls' compact copies (a two-step pass after this must refill them), and every plane has
+    // been through `batch` full sweeps.
+    xw_valid_ = false;
     return WV_OK;
 }
 

@@ -47,6 +47,11 @@ struct PairArgs {
     int* flag2;        // ... of step t+1 -> t+2
     int ny, nz, pitch, cls_pitch;
     int z_begin, z_end;  // planes to produce
+    // planes whose t+1 values are STORED, [z_begin, z_end) or one plane less at an end: on a slab the planes next to the face
+    // planes get their t+1 from the launch that steps the faces (complete, boundary nodes included, before this kernel runs --
+    // engine_pair.hip.h, the early-faces pass); the march still computes them, for its own t+2, but must not put its
+    // placeholders over finished boundary values.  t+2 is stored on every produced plane.
+    int out1_z0, out1_z1;
     int nw;              // waves per workgroup (pitch / wave tile width)
     int zc, chunks;      // planes per workgroup, workgroups along z
     int strips, strips_per_xcd;
@@ -300,6 +305,7 @@ __device__ __forceinline__ void pair_march_body(const PairArgs<Real>& a) {
         load_b(b_nn, z + 2);
         load_p(pv, z + 1);
         const uint32_t code_word = (X & PX_NO_MAP) ? 0x55555555u : codes_of(z);
+        Real* const o1_base = (z >= a.out1_z0 && z < a.out1_z1) ? a.out1 : a.out2;
         if (X & PX_NO_COMPUTE) {  // (tools/pair_tune only)
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -348,7 +354,10 @@ __device__ __forceinline__ void pair_march_body(const PairArgs<Real>& a) {
                     t.store_cached(a.out1, y0 + r, z, o1);
                     t.store_cached(a.out2, y0 + r, z, o2);
                 } else {
-                    t.store(a.out1, y0 + r, z, o1);
+                    // (a plane whose t+1 is not to be stored -- PairArgs::out1_z0 -- sends it to the t+2 field instead, where the
+                    // store after it, same lane, same address, replaces it: a scalar select of the base pointer, where a branch
+                    // around the store cost the double march 12 B of scratch)
+                    t.store(o1_base, y0 + r, z, o1);
                     t.store(a.out2, y0 + r, z, o2);
                 }
             }

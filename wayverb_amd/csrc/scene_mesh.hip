@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -315,9 +316,10 @@ extern "C" int wv_scene_mesh_create_engine(const wv_scene_mesh* sm, const wv_coe
     wv_options opt;
     wv_default_options(&opt);
     if (options) {
-        if (options->struct_size != (int32_t)sizeof(wv_options))
-            return wv::fail_with(WV_E_INVALID_ARGUMENT, "wv_options::struct_size does not match this library");
-        opt = *options;
+        // as wv_create: a caller built against a shorter wv_options gives its prefix, the rest keeps the defaults
+        const size_t n = std::min<size_t>(sizeof(opt), options->struct_size > 0 ? (size_t)options->struct_size : sizeof(opt));
+        std::memcpy(&opt, options, n);
+        opt.struct_size = (int32_t)sizeof(opt);
     }
     opt.device = sm->device;
     opt.nodes_on_device = 1;
