@@ -454,7 +454,7 @@ def test_graph_replays_between_passes_leave_no_stale_wall_copies(oracle, tag, dt
         eng.set_receivers(recv)
         prev, cur = init[0].copy(), init[1].copy()
         bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
-        at, passes = 0, 0
+        at = 0
         for n in lengths:
             done, flag = eng.run_steps(n)
             assert (done, flag) == (n, 0)
@@ -465,8 +465,26 @@ def test_graph_replays_between_passes_leave_no_stale_wall_copies(oracle, tag, dt
             assert eng.read_field(E.BUF_PREVIOUS).tobytes() == prev.tobytes(), (n, at)
             for d in (1, 2, 3):
                 assert eng.read_boundary_data(d).tobytes() == bd[d - 1].tobytes(), (n, at, d)
-            if n < 16:
-                passes += n // 2
-        assert eng.query(E.Engine.QUERY_PASSES) == passes and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
+        # the first batch follows a caller's write into the fields: two single full sweeps, then 7 passes; the later batches of 16
+        # go by graph (the second such one is a replay), everything shorter by passes: 7 + 2 + 2 + 3 + 1
+        assert eng.query(E.Engine.QUERY_PASSES) == 15 and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("split", [1, 3])
+@pytest.mark.parametrize("dims,tag", [((330, 11, 9), "f64"), ((640, 14, 12), "f64"), ((768, 9, 13), "f64"), ((900, 10, 9), "f64"),
+                                      ((1024, 6, 7), "f64"), ((1000, 12, 10), "f32"), ((2048, 9, 8), "f32")])
+def test_short_rows_marched_as_overlapping_windows(oracle, dims, tag, split):
+    """wv_tuning::pair_split_rows (measurement): a row of 3 to 8 waves as windows of at most 4 (or 3) waves, halo waves included,
+    so that two workgroups share a CU -- the WIDE march's mechanism on rows that would fit one workgroup.  Same bits as the
+    oracle: fields, filter memories, traces, receivers on both sides of every seam between waves."""
+    dtype = np.float64 if tag == "f64" else np.float32
+    case = _random_case(dims, seed=dims[0] + 1, steps=13, reentrant=False)
+    ci = case["mesh"].compute_index
+    wave_cols = 128 if tag == "f64" else 256
+    seams = [x for k in range(1, dims[0] // wave_cols + 1) for x in (k * wave_cols - 1, k * wave_cols) if 2 <= x < dims[0] - 2]
+    case["recv"] = [ci(x, dims[1] // 2, dims[2] // 2) for x in seams[:48]]
+    want = run_oracle(oracle, case, dtype, threads=4)
+    set_tuning(pair=1, pair_split_rows=split)
+    _same(run_engine(case, tag), want)

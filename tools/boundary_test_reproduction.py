@@ -191,7 +191,8 @@ def reproduce(angle_indices, use_engine=False, threads=None, source="transparent
             reflected, = stepper.run(wall, g["source"], [g["receiver"]], signal, impedance[name])
             subbed = direct - reflected * window
             freq, db, clipped = measured_reflectance_db(image, subbed)
-            key = "%s_%d_%d" % (name, int(az * 180 / np.pi), int(el * 180 / np.pi))          # graphs.py:137-139
+            # graphs.py:137-139 on the angles as the utility wrote them to coefficients.txt: floats (0.5235987901687622 for pi / 6)
+            key = "%s_%d_%d" % (name, int(float(np.float32(az)) * 180 / np.pi), int(float(np.float32(el)) * 180 / np.pi))
             out[key] = dict(freq=freq, measured_db=db, clipped=clipped, free_image=image, subbed=subbed,
                             predicted_db=predicted_reflectance_db(impedance[name], az, el, freq))
             if log:

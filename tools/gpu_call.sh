@@ -7,7 +7,7 @@
 #   kernels                      rocprofv3 --kernel-trace --stats of bench.py (short) -> rocprof_kernel_stats.csv
 #   pmc                          FETCH_SIZE / WRITE_SIZE passes of bench.py (separate passes, kernel trace only) -> pmc_summary.json
 #   slabs[:<worlds>[:<tuning>]]  tools/slab_overhead.py for the given worlds (default 2,4,8), twice each -> slab_overhead_one_gpu.txt
-#   timeline[:<tuning>]          rocprofv3 kernel + copy trace of 8 x 128 planes -> slab_pass_timeline_8x128[_tuning].txt
+#   timeline[:<tuning>]          rocprofv3 kernel trace (the copy-trace domain crashes rocprofv3 on this image) of 8 x 128 planes -> slab_pass_timeline_8x128[_tuning].txt
 #   middle                       tools/middle_rank_bench.py
 #   boundary_test                tools/boundary_test_reproduction.py --engine, both sources -> boundary_test_*.{txt,npz}
 #   run:<command>                anything else, output to run_N.txt
@@ -44,7 +44,7 @@ print('  ->', d['value'], d['unit'], '| kernel', r['kernel'], r['kernel_ms'], 'm
       for rep in 1 2; do for w in ${worlds//,/ }; do python tools/slab_overhead.py --world $w $tun 2>&1 | grep fp64; done; done | tee -a $O/slab_overhead_one_gpu.txt ;;
     timeline)
       tun=""; tag=""; [ -n "$arg" ] && tun="--tuning $arg" && tag="_${arg//[=,]/_}"
-      rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -o t -- python tools/slab_overhead.py --world 8 --steps 8 $tun > $O/tl.log 2>&1
+      rocprofv3 --kernel-trace --output-format csv -d $O/tl -o t -- python tools/slab_overhead.py --world 8 --steps 8 $tun > $O/tl.log 2>&1
       python tools/pass_timeline.py $O/tl 4 > $O/slab_pass_timeline_8x128$tag.txt 2>&1; head -3 $O/slab_pass_timeline_8x128$tag.txt; rm -rf $O/tl $O/tl.log ;;
     middle) python tools/middle_rank_bench.py 2>&1 | grep "middle rank" | tee -a $O/middle_rank_bench.txt ;;
     boundary_test)

@@ -203,6 +203,28 @@ int Engine<Real>::ensure_pair() {
         }
         if (at < row_waves) return fail(WV_E_STATE, "row too long for the two-step pass");  // (pair_eligible rules it out)
         pair_nw_ = widest;  // waves per workgroup
+    } else if (opt_.tuning.pair_split_rows != 0 && pair_nw_ >= 3) {
+        // Measurement (wv_tuning::pair_split_rows): a row of 3 .. 8 waves is one workgroup per CU where 8 wave slots are free, and
+        // such marches run at 3.5 TB/s.  The same row as windows of at most 4 waves (halo waves included, as in
+        // the WIDE march above) puts two workgroups on a CU -- for 40-57 % more waves run than stored.
+        const int row_waves = pair_nw_, cap = opt_.tuning.pair_split_rows > 1 ? opt_.tuning.pair_split_rows : 4;
+        int at = 0, widest = 0;
+        while (at < row_waves && pair_windows_ < wv::kPairMaxWindows) {
+            const int lo_halo = at > 0 ? 1 : 0;
+            int end = at + cap - lo_halo;
+            if (end < row_waves) end -= 1;
+            end = std::max(at + 1, std::min(end, row_waves));
+            const int first = at - lo_halo, count = end + (end < row_waves ? 1 : 0) - first;
+            pair_win_[0][pair_windows_] = (uint8_t)first;
+            pair_win_[1][pair_windows_] = (uint8_t)count;
+            pair_win_[2][pair_windows_] = (uint8_t)at;
+            pair_win_[3][pair_windows_] = (uint8_t)end;
+            widest = std::max(widest, count);
+            ++pair_windows_;
+            at = end;
+        }
+        if (at < row_waves) return fail(WV_E_STATE, "pair_split_rows: too many windows");
+        pair_nw_ = widest;
     }
     pair_strips_ = (ny_ + wv::kPairRows - 1) / wv::kPairRows;
     const int owned = pair_z1_ - pair_z0_;

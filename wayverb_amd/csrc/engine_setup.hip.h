@@ -35,7 +35,16 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
     DeviceGuard guard(opt.device);  // the caller's current device is restored on return
     WV_HIP(hipGetDevice(&device_));
     WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+    {
+        // the halo stream above the compute stream: what it carries (exchanges, a slab's face planes stepped between them) is small
+        // and on the critical path of the neighbours, and it competes for CUs with a march that fills the chip
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        }
+    }
 
     // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
     field_bytes_ = stored_nodes_ * sizeof(Real);
