@@ -44,16 +44,19 @@ def main():
         from wayverb_amd import engine as E
 
         def chains(seed, _fn=S.test_random_slab_chains_equal_the_single_domain):
-            for pair in (None, 1):  # the engine's choice of stepping, then two-step passes forced (the test's _step_mode fixture)
+            # the engine's choice of stepping, two-step passes forced with both exchanges under the march (round 4), and in round 3's
+            # order (the test's _step_mode fixture)
+            for pair, early in ((None, 1), (1, 1), (1, 0)):
                 old = dict(E.default_tuning)
                 if pair is not None:
                     E.default_tuning["pair"] = pair
+                    E.default_tuning["slab_early"] = early
                 try:
                     _fn(None, seed, "two-step-passes" if pair else "single-steps")
                 finally:
                     E.default_tuning.clear()
                     E.default_tuning.update(old)
-        families.append(("random slab chains against the single domain, both stepping modes", chains))
+        families.append(("random slab chains against the single domain, single steps and passes in both orders", chains))
     except Exception:  # noqa: BLE001
         traceback.print_exc()
     failed = False
@@ -75,7 +78,7 @@ def main():
                 elif p == "built_library":
                     kw[p] = None
                 elif p == "mode":
-                    kw[p] = ["default", "passes", "single-steps", "graph-replay"][seed % 4]
+                    kw[p] = ["default", "passes", "single-steps", "graph-replay", "graph-and-passes"][seed % 5]
                 else:
                     kw[p] = None
             try:
