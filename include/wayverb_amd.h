@@ -114,7 +114,8 @@ typedef struct wv_tuning {
                                * halo exchanges of a pass (and the faces' second step, on the halo stream) run under it; 0 = the second exchange
                                * follows the march (the form of rounds 2 and 3) */
     int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
-    int32_t reserved_[5];
+    int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
+    int32_t reserved_[4];
 } wv_tuning;
 
 typedef struct wv_options {

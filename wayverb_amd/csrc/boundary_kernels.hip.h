@@ -372,15 +372,17 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
 // is a boundary node -- then they were final when the sweep before this launch ended (engine.hip).
 // FIX: the second launch of a two-step pass, where 1-D entries also finish the inside node they face
 // (BoundaryArgs::fix_z0 / fix_z1).
-template <typename Real, bool LDSC, bool FIX = false>
-__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
+// (`block` of `blocks`: this workgroup's place among the boundary workgroups of the launch -- all of it for boundary_kernel, the
+// tail of the grid for plane_step_kernel.)
+template <typename Real, bool LDSC, bool FIX>
+__device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
         for (uint32_t w = threadIdx.x; w < a.n_coeffs * 14u; w += 256) s_coeffs[w] = a.coeffs[w];
         __syncthreads();
     }
     const double* coeffs = LDSC ? s_coeffs : a.coeffs;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = block * blockDim.x + threadIdx.x;
     int bad = 0;
     if (a.xw_n) {
         // two-step pass: the first xw_n entries (x-facing walls) by their compact copies, whole workgroups of them
@@ -398,7 +400,12 @@ __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> 
         boundary_entry<Real, FIX>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
-    if (next.fused && blockIdx.x == gridDim.x - 1) pre_post_body<Real>(next, threadIdx.x, 256);
+    if (next.fused && block == blocks - 1) pre_post_body<Real>(next, threadIdx.x, 256);
+}
+
+template <typename Real, bool LDSC, bool FIX = false>
+__global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
+    boundary_body<Real, LDSC, FIX>(a, next, blockIdx.x, gridDim.x);
 }
 
 // Which 1-D entries may live on compact copies (xwall_node): facing along x, in the planes the march produces, the

@@ -19,6 +19,7 @@
 #include "boundary_kernels.hip.h"
 #include "pair_kernels.hip.h"
 #include "stream_kernels.hip.h"
+#include "plane_kernels.hip.h"
 
 namespace wv {
 
@@ -39,15 +40,27 @@ public:
     // ---- engine_setup.hip.h
     int build_tile_lists(int z0, int z1);
     // ---- engine_single.hip.h
-    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr, int zb0 = 0, int zb1 = 0);
+    // (`plan_only`: the launch's arguments and grid are handed back instead of launched -- launch_faces puts them into one launch
+    // with the planes' boundary entries)
+    struct StreamLaunch {
+        wv::StreamArgs<Real> args;
+        unsigned grid = 0;
+    };
+    int launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out = nullptr, int zb0 = 0, int zb1 = 0,
+                      StreamLaunch* plan_only = nullptr);
     // (`planes`: how many owned planes next to each neighbour -- 1: the face planes, 2: the faces and the planes next to them)
     int launch_faces(Real* prev, const Real* cur, int* flag, Real* out, int planes = 1);
     wv::BoundaryArgs<Real> boundary_args(Real* prev, const Real* cur, int* flag) const;
     // (z0 = z1 = -1: the boundary nodes of a slab's face planes)
     // (z0 = z1 = -2: of the two planes next to each neighbour; `levels`: a two-step pass's launch over the bulk of the mesh,
     // in which the x-facing walls go by position on their compact copies)
+    struct BoundaryLaunch {
+        wv::BoundaryArgs<Real> args;
+        unsigned blocks = 0;
+        bool lds = false;
+    };
     int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false,
-                        bool levels = false);
+                        bool levels = false, BoundaryLaunch* plan_only = nullptr);
     wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
     // ---- engine_pair.hip.h

@@ -35,16 +35,10 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
     DeviceGuard guard(opt.device);  // the caller's current device is restored on return
     WV_HIP(hipGetDevice(&device_));
     WV_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    {
-        // the halo stream above the compute stream: what it carries (exchanges, a slab's face planes stepped between them) is small
-        // and on the critical path of the neighbours, and it competes for CUs with a march that fills the chip
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, greatest) != hipSuccess) {
-            (void)hipGetLastError();
-            WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
-        }
-    }
+    // (The halo stream at a higher priority than the compute stream was tried in round 4: one rank per GPU gains nothing -- what the
+    // stream carries waits for the march's workgroups to retire either way -- and several slabs on ONE device lose a quarter, their
+    // halo work cutting into each other's marches: 8 x 128 planes +32 % instead of +10 %.  HISTORY.md.)
+    WV_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
 
     // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
     field_bytes_ = stored_nodes_ * sizeof(Real);

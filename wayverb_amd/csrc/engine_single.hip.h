@@ -40,8 +40,9 @@ void Engine<Real>::launch_ry(const wv::StreamArgs<Real>& a, unsigned grid) {
 // `out`: where the new field goes (null: in place, over `prev`).  Planes [z0, z1) and, in the same launch, [zb0, zb1)
 // further up (a slab's two face planes).
 template <typename Real>
-int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out, int zb0, int zb1) {
-    if (zb0 < zb1 && z0 >= z1) return launch_stream(prev, cur, flag, zb0, zb1, timed, out);
+int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, int z1, bool timed, Real* out, int zb0, int zb1,
+                                StreamLaunch* plan_only) {
+    if (zb0 < zb1 && z0 >= z1) return launch_stream(prev, cur, flag, zb0, zb1, timed, out, 0, 0, plan_only);
     if (zb0 < zb1 && plan_.variant != 2 && plan_.variant != 3) {  // (the measurement variants take one range at a time)
         const int rc = launch_stream(prev, cur, flag, z0, z1, timed, out);
         return rc ? rc : launch_stream(prev, cur, flag, zb0, zb1, false, out);
@@ -89,6 +90,11 @@ int Engine<Real>::launch_stream(Real* prev, const Real* cur, int* flag, int z0, 
         a.total_tiles = a.tiles_x * a.tiles_y * a.chunks_z;
         a.tiles_per_xcd = (a.total_tiles + 7) / 8;
         grid = (unsigned)a.tiles_per_xcd * 8u;
+    }
+    if (plan_only) {
+        plan_only->args = a;
+        plan_only->grid = grid;
+        return WV_OK;
     }
     timed = timed && !on_ && time_this_launch();
     if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
@@ -140,7 +146,7 @@ wv::BoundaryArgs<Real> Engine<Real>::boundary_args(Real* prev, const Real* cur, 
 // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
 template <typename Real>
 int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner,
-                                  bool levels) {
+                                  bool levels, BoundaryLaunch* plan_only) {
     const bool faces = z0 == z1 && (z0 == -1 || z0 == -2);
     if (!n_entries_ || (z0 >= z1 && !faces)) return WV_OK;
     wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
@@ -177,6 +183,12 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
         n += b.xw_pad;
     }
     const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && opt_.tuning.boundary_lds != 0;
+    if (plan_only) {
+        plan_only->args = b;
+        plan_only->blocks = (n + 255) / 256;
+        plan_only->lds = lds;
+        return WV_OK;
+    }
     const dim3 grid((n + 255) / 256), block(256);
     if (lds && fix_inner)
         hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, st(), b, nx);
@@ -195,6 +207,23 @@ template <typename Real>
 int Engine<Real>::launch_faces(Real* prev, const Real* cur, int* flag, Real* out, int planes) {
     const int lo = opt_.ghost_lo ? planes : 0, hi = opt_.ghost_hi ? planes : 0;
     const int zi0 = std::min(z_begin_ + lo, z_end_), zi1 = std::max(z_end_ - hi, zi0);
+    // One launch for both halves of these planes' step (plane_kernels.hip.h) where the sweep has the product's shape: its
+    // workgroups, then the boundary entries' -- no "sweep, then boundary kernel" when the sweep leaves boundary nodes alone.
+    if (opt_.tuning.fuse_planes != 0 && plan_.variant == 2 && plan_.ry == 4 && plan_.nwx == 1 && plan_.nwy == 4 && n_entries_) {
+        StreamLaunch sw;
+        BoundaryLaunch bd;
+        int rc = launch_stream(prev, cur, flag, z_begin_, zi0, false, out, zi1, z_end_, &sw);
+        if (rc) return rc;
+        if ((rc = launch_boundary(prev, cur, flag, -planes, -planes, nullptr, out, false, false, &bd))) return rc;
+        if (sw.grid && bd.blocks) {
+            const dim3 grid(sw.grid + bd.blocks), block(256);
+            if (bd.lds)
+                hipLaunchKernelGGL((wv::plane_step_kernel<Real, true>), grid, block, 0, st(), sw.args, bd.args, (uint32_t)sw.grid);
+            else
+                hipLaunchKernelGGL((wv::plane_step_kernel<Real, false>), grid, block, 0, st(), sw.args, bd.args, (uint32_t)sw.grid);
+            return WV_OK;
+        }
+    }
     int rc = launch_stream(prev, cur, flag, z_begin_, zi0, false, out, zi1, z_end_);
     if (rc) return rc;
     return launch_boundary(prev, cur, flag, -planes, -planes, nullptr, out);

@@ -411,19 +411,21 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_nolds_kernel(cons
 // the list and single waves by the entry's wave mask; a skipped wave publishes nothing, so its
 // neighbours load that halo row themselves.
 // ---------------------------------------------------------------------------------------------
-template <typename Real, int RY, int NWX, int NWY>
-__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
+// (The body is a device function so that plane_step_kernel, boundary_kernels.hip.h, can run it beside the boundary entries of
+// the same planes in one launch -- there with masked stores, X = X_SWEEP & ~X_STORE_ALL, so that it leaves boundary nodes alone.
+// `block`: this workgroup's index among the sweep's workgroups.)
+template <typename Real, int RY, int NWX, int NWY, int X>
+__device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, unsigned block) {
     using V = typename Vec16<Real>::type;
     constexpr int WX = TileIO<Real>::WX;
-    constexpr int X = X_SWEEP;
     __shared__ V halo[NWY][NWX][2][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wx = wave % NWX, wy = wave / NWX;
 
-    const int xcd = blockIdx.x & 7;
-    int j = blockIdx.x >> 3;
+    const int xcd = block & 7;
+    int j = block >> 3;
     int tl, z, stripe;
     uint32_t mask = ~0u;  // which waves of this workgroup have something to update
     if (a.tile_list) {
@@ -501,6 +503,11 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const Stre
     if (__any(bad != 0)) {
         if (bad) atomicOr(a.flag, bad);
     }
+}
+
+template <typename Real, int RY, int NWX, int NWY>
+__global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_kernel(const StreamArgs<Real> a) {
+    stream_sweep_body<Real, RY, NWX, NWY, X_SWEEP>(a, blockIdx.x);
 }
 
 }  // namespace wv
