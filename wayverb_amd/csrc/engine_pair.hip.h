@@ -515,14 +515,14 @@ void Engine<Real>::parallel_sort(std::vector<uint64_t>& v) {
 //
 // On a slab the two time levels each need the neighbours' face planes, so a pass has two exchanges.  Both run under the march
 // (round 4; slab_early_now()).  With f = a face plane, n = the owned plane next to it, g = the ghost plane beyond it:
-//   compute stream  [ghosts of t in place] -> f AND n to t+1 (one sweep launch + one launch for their boundary nodes, out of place)
+//   compute stream  [ghosts of t in place] -> f AND n to t+1 (one launch: sweep + their boundary nodes side by side, out of place)
 //                   -> MARCH over n .. n' (t+1 and t+2; it computes n's t+1 again for its own use but stores t+1 only from
 //                   the plane after n: its placeholders must not land on n's finished boundary values) -> boundary nodes of
 //                   the planes in between to t+1 -> [source / receivers on t+1] -> fix-up list, boundary nodes n .. n' to t+2
 //   halo stream     [f, n at t+1 final] -> exchange #1 (t+1 faces) -> f to t+2: a plain step of the face plane from t+1 at g, f, n
-//                   (sweep + boundary launch, on this stream) -> exchange #2 (t+2 faces)
+//                   (one launch, on this stream) -> exchange #2 (t+2 faces)
 // Nothing on the halo stream needs the march: f's t+2 reads t+1 at g (exchange #1), f and n (the early launches).  The compute
-// stream meets the halo stream again at the next pass's "ghosts in place".  Five launches on the compute stream, two beside it.
+// stream meets the halo stream again at the next pass's "ghosts in place".  Four launches on the compute stream, one beside it.
 // A source within two planes of a cut (planes g, f, n: its t+1 sample would have to be in place before f's t+2) keeps THAT slab on
 // the older order, which differs in where things are enqueued, not in what is exchanged, so neighbours need not agree:
 //   part A  face planes to t+1 -> exchange #1 -> march over the planes in between + their boundary nodes to t+1
