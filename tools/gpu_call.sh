@@ -11,6 +11,8 @@
 #   middle                       tools/middle_rank_bench.py
 #   boundary_test                tools/boundary_test_reproduction.py --engine, both sources -> boundary_test_*.{txt,npz}
 #   run:<command>                anything else, output to run_N.txt
+# (A task is ONE shell word: quote it on the gpurun command line, and name tests by node id -- tests/x.py::test_y -- rather than with
+# `-k "a or b"`, whose inner quotes do not survive the trip.)
 R=$1; shift
 export TMPDIR=/tmp; O=gpurun_out/$R; mkdir -p $O
 n=0
