@@ -20,15 +20,18 @@ def _step_mode(request):
     small); with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
     twice per pass -- t+1, then t+2 (engine_pair.hip.h, enqueue_pair_a / _b) -- both exchanges under the march, the
     faces' second step on the halo stream (round 4); and with passes in the order of round 3 (wv_tuning::slab_early = 0:
-    the second exchange after the march), which is also what a slab with a source within two planes of a cut falls back
-    to.  Slabs with fewer than four planes cannot take two-step passes, and then the whole chain falls back together."""
+    the second exchange after the march, and the planes around the exchanges in two launches, sweep then boundary nodes:
+    wv_tuning::fuse_planes = 0), which is also what a slab with a source within two planes of a cut falls back to.  Slabs with
+    fewer than four planes cannot take two-step passes, and then the whole chain falls back together."""
     old = dict(E.default_tuning)
     E.default_tuning.pop("pair", None)
     E.default_tuning.pop("slab_early", None)
+    E.default_tuning.pop("fuse_planes", None)
     if request.param.startswith("two-step-passes"):
         E.default_tuning["pair"] = 1
         if request.param.endswith("round-3-order"):
             E.default_tuning["slab_early"] = 0
+            E.default_tuning["fuse_planes"] = 0
     yield "two-step-passes" if request.param.startswith("two-step-passes") else request.param
     E.default_tuning.clear()
     E.default_tuning.update(old)
