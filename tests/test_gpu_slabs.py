@@ -278,12 +278,14 @@ def test_a_group_refuses_slabs_that_are_out_of_step():
         group.close()
 
 
-def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
+def test_a_slab_with_a_neighbour_elsewhere_marches_in_two_rounds(_step_mode):
     """The exchange of a slab's t+1 faces is to run under its march, and whatever carries it (RCCL's send / receive
     kernels, the runtime's copy kernels) needs a CU.  A march whose workgroups fill the chip's slots exactly once holds
-    every register of every CU until all of them retire together, at its end -- so a slab with a neighbour takes the
-    chunking with two rounds where that costs little (engine_pair.hip.h, ensure_pair), one domain keeps the single
-    round.  1024 x 1024 rows: 256 strips of 8 waves = the chip's 256 workgroup slots."""
+    every register of every CU until all of them retire together, at its end -- so a slab with a neighbour on another GPU
+    (RCCL: here a rank that is its own neighbour) takes the chunking with two rounds where that costs little
+    (engine_pair.hip.h, ensure_pair); one domain keeps the single round, and so do slabs of one process that share a device:
+    they take turns at the march, nothing could run beside it.  1024 x 1024 rows: 256 strips of 8 waves = the chip's 256
+    workgroup slots."""
     from wayverb_amd.slab import box_slab_mesh                  # (meshes this size take two-step passes in either mode)
     n, nz = 1024, 128
     coeffs = M.bench_materials()
@@ -296,7 +298,7 @@ def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
         assert all(e.query(E.Engine.QUERY_MARCH_ROUNDS) == 0 for e in engines)      # nothing planned yet
         assert group.run_steps(4) == (4, 0)
         assert [e.query(E.Engine.QUERY_PASSES) for e in engines] == [2, 2]
-        assert [e.query(E.Engine.QUERY_MARCH_ROUNDS) for e in engines] == [2, 2]
+        assert [e.query(E.Engine.QUERY_MARCH_ROUNDS) for e in engines] == [1, 1]      # two slabs, one device
     finally:
         group.close()
 
@@ -310,6 +312,16 @@ def test_a_slab_with_a_neighbour_marches_in_two_rounds(_step_mode):
         assert single.query(E.Engine.QUERY_MARCH_ROUNDS) == 1
     finally:
         single.close()
+    # a middle rank over RCCL (its own neighbour on both sides): two rounds
+    nodes, counts = E.make_box_nodes(n, n, 8 * 64, z_begin=3 * 64 - 1, z_count=66, number_from=3 * 64, number_to=4 * 64)
+    bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1) for d in range(3)]
+    rank = E.Engine(M.Mesh((n, n, 66), nodes, coeffs, *bidx), precision="f64", ghost_lo=True, ghost_hi=True)
+    try:
+        rank.comm_init(E.Engine.comm_unique_id(), 0, 1)
+        assert rank.run_steps(4) == (4, 0)
+        assert rank.query(E.Engine.QUERY_PASSES) == 2 and rank.query(E.Engine.QUERY_MARCH_ROUNDS) == 2
+    finally:
+        rank.close()
 
 
 def test_soft_source_on_a_slab_face_for_many_steps(_step_mode):

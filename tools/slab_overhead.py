@@ -10,9 +10,9 @@ scaling efficiency -- and compares sampled planes (slab faces, ghosts' owners, m
 
     python tools/slab_overhead.py [--world 8] [--nz 1024] [--steps 40] [--hw-queues 16] [--tuning pair_chunks=1]
 
-`--tuning k=v,...` sets wv_tuning fields of every engine (e.g. pair_chunks=1: a thin slab's march in one round of workgroups,
-which is what costs least on ONE GPU; the engine's own choice for a slab with neighbours is two rounds, so that the exchange
-gets a CU before the march ends).
+`--tuning k=v,...` sets wv_tuning fields of every engine (e.g. pair_chunks=2: a thin slab's march in two rounds of workgroups,
+the engine's choice for a slab whose neighbours live on other GPUs, so that the exchange gets a CU before the march ends; slabs
+that share one device, as here, march in one round -- they take turns anyway; slab_early=0: round 3's order of a pass).
 
 `--hw-queues N` sets GPU_MAX_HW_QUEUES for this process: the ROCm runtime spreads a process's streams over 4 hardware
 queues unless told otherwise, and 8 slabs x (compute + halo stream) on one GPU then share queues that 8 GPUs would

@@ -80,6 +80,13 @@ public:
     // local transport: everything this slab has pushed into its neighbours has landed
     hipStream_t halo_stream() const { return stream_; }
 
+    // Does any neighbour live on another GPU (RCCL: always; in-process: a linked slab on another device)?  What runs beside a
+    // slab's march then needs a CU of THIS device while the march holds them all; slabs that share one device take turns anyway.
+    bool peers_elsewhere() const {
+        if (!local_) return true;
+        return (lo_ && lo_->device_ != device_) || (hi_ && hi_->device_ != device_);
+    }
+
     int rank() const { return rank_; }
     int nranks() const { return nranks_; }
     bool is_local() const { return local_; }

@@ -239,7 +239,9 @@ int Engine<Real>::ensure_pair() {
         // CU until all its workgroups retire together at the end, and the exchange would start after it.  At least two rounds
         // then: the first round's end is where the exchange gets in.
         // (... where that costs little: a mesh that fills two rounds only with much shorter chunks keeps the unconstrained choice)
-        const int64_t want_rounds = (opt_.ghost_lo || opt_.ghost_hi) ? 2 : 1;
+        // (slabs of one process that share this device take turns at the march -- SlabComm::bulk_begin -- and nothing runs beside
+        // it that the next slab's march would not displace anyway: one round there)
+        const int64_t want_rounds = ((opt_.ghost_lo || opt_.ghost_hi) && (!comm_ || comm_->peers_elsewhere())) ? 2 : 1;
         double best[2] = {0, 0};
         int at[2] = {0, 0};  // [0] any number of rounds, [1] at least `want_rounds`
         for (int c = 1; c <= std::max(1, owned / 8) && c <= 256; ++c) {
