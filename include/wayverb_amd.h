@@ -112,7 +112,8 @@ typedef struct wv_tuning {
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
     int32_t slab_early;       /* z-slabs, two-step passes: 1 = the faces AND the planes next to them are stepped ahead of the march, so that both
                                * halo exchanges of a pass (and the faces' second step, on the halo stream) run under it; 0 = the second exchange
-                               * follows the march (the form of rounds 2 and 3) */
+                               * follows the march (the form of rounds 2 and 3); -1 (default) = 1 where a neighbour lives on another GPU (RCCL,
+                               * or a slab of this process on another device), 0 between slabs that share a device */
     int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
     int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
     int32_t reserved_[4];

@@ -56,7 +56,7 @@ void wv_default_options(wv_options* o) {
     t.boundary_lds = 1;
     t.boundary_order = 1;
     t.boundary_xwall = 1;
-    t.slab_early = 1;
+    t.slab_early = -1;
     t.pair_split_rows = 0;
     t.fuse_planes = 1;
 }

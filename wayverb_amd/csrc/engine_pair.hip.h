@@ -738,6 +738,10 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
 template <typename Real>
 bool Engine<Real>::slab_early_now() const {
     if (!comm_ || opt_.tuning.slab_early == 0 || !(opt_.ghost_lo || opt_.ghost_hi)) return false;
+    // (by default only where a neighbour lives on another GPU: the order sweeps two more planes per pass to get the exchanges out
+    // early, and between slabs that share a device there is no transfer worth hiding -- their copies take 20 us on a chip that is
+    // theirs in turns)
+    if (opt_.tuning.slab_early < 0 && !comm_->peers_elsewhere()) return false;
     const int lo = opt_.ghost_lo ? 2 : 0, hi = opt_.ghost_hi ? 2 : 0;
     if (z_end_ - z_begin_ < lo + hi + 4) return false;  // (something has to be left in between)
     if (source_kind_ != WV_SOURCE_NONE) {
