@@ -187,6 +187,17 @@ int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32
  * the two fields (an engine that takes two-step passes rotates four). */
 int wv_device_buffer(wv_engine* e, int buffer, void** device_ptr);
 
+/* The state `run` carries from one loop iteration to the next (waveguide.h:80-123: `previous`, `current` and the boundary filter
+ * memories), with the step count, the position in the source signal and the recorded receiver rows, copied aside ON THE DEVICE
+ * (wv_checkpoint: two more fields of memory, allocated by the first call; WV_E_HIP when there is no room, the engine untouched) and
+ * put back (wv_rollback: the engine continues from the checkpoint and, being deterministic, reproduces the abandoned steps bit for
+ * bit).  For callers that run batches of steps ahead of per-step observers: `canonical`'s pressure callback may look at the field
+ * of ANY step (canonical.h:66-69), so the C++ mirror runs batches speculatively and re-runs up to the step an observer looks at.
+ * The source and the receivers must be the ones in place at the checkpoint (WV_E_STATE otherwise); wv_drop_checkpoint frees the copy. */
+int wv_checkpoint(wv_engine* e);
+int wv_rollback(wv_engine* e);
+int wv_drop_checkpoint(wv_engine* e);
+
 /* ---- stepping: the generic path ------------------------------------------------------------- */
 
 /* One loop body of waveguide.h:82-119 without the callbacks: clear flag, launch the update

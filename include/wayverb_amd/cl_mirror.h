@@ -8,14 +8,24 @@
 // (CL/cl.hpp, as src/core/include/core/cl/include.h does) makes `waveguide::canonical` serve such a
 // callback whenever the compute context it is given carries an OpenCL context (the reference's
 // core::compute_context: cl::Context context; cl::Device device -- core/cl/common.h:13-22):
-// a float mirror of the step's pressure field lives in a cl::Buffer of that context and is refreshed
-// (HIP field -> host -> cl::Buffer) before each call.
+// a float mirror of the step's pressure field lives in a cl::Buffer of that context.
 //
-// That refresh moves the whole field every step -- what the reference's own loop avoids only because
-// its field already is a cl::Buffer.  `cl_mirror_wanted()` lets the owner of the callback say when a
-// reader is actually attached (one line in combined::engine: `cl_mirror_wanted() = [&] { return
-// !waveguide_node_pressures_changed_.empty(); }`); without it every step is mirrored, which is always
-// correct.
+// WHEN the mirror is refreshed (HIP field -> host -> cl::Buffer: the whole field crosses PCIe twice,
+// 2 x 4.3 GB at 1024^3 -- what the reference's own loop avoids only because its field already is a
+// cl::Buffer) is SURVEY.md 8(b)'s "single behavioural deviation": ONLY FOR THE STEPS SOMEBODY WANTS IT.
+// A read of a real cl::Buffer cannot be seen from here (reads of the engine's own handles can, see
+// waveguide.h), so the owner of the listener says so:
+//
+//     waveguide::cl_mirror_wanted() = [&] { return !waveguide_node_pressures_changed_.empty(); };
+//
+// -- one line where the listener is connected (the application that calls
+// engine::connect_waveguide_node_pressures_changed, src/combined/src/engine.cpp:260-264; src/combined
+// itself stays as it is), or `cl_mirror_always()` for "whenever the callback runs".  While the predicate
+// is empty or returns false the buffer keeps its zeros and `canonical` runs whole batches of two-step
+// passes on the device; a step for which it returns true gets exactly its own field (if the run has already
+// passed that step: roll back, re-run up to it -- waveguide.h, run_device_observed), and the run goes on
+// step by step for as long as it keeps returning true.  `cl_mirror_planes()` narrows the refresh to a
+// range of z planes (a visualiser's slice).
 #pragma once
 
 #include <functional>
@@ -25,10 +35,24 @@
 namespace wayverb {
 namespace waveguide {
 
-/// Empty (default): mirror every step.  Otherwise: mirror the steps for which it returns true.
+/// Empty (default) or returning false: nobody reads the cl::Buffer, it is not refreshed (it holds zeros).
+/// Returning true when evaluated for a step: that step's field is in the buffer when the callback runs.
 inline std::function<bool()>& cl_mirror_wanted() {
     static std::function<bool()> f;
     return f;
+}
+/// `cl_mirror_wanted() = cl_mirror_always();` -- every step is mirrored (the behaviour of a plain OpenCL field).
+inline std::function<bool()> cl_mirror_always() {
+    return [] { return true; };
+}
+/// Planes [z_begin, z_begin + z_count) are refreshed; z_count < 0 (default): the whole field.
+struct mirror_planes final {
+    int z_begin = 0;
+    int z_count = -1;
+};
+inline mirror_planes& cl_mirror_planes() {
+    static mirror_planes p;
+    return p;
 }
 
 namespace detail {
@@ -36,29 +60,50 @@ namespace detail {
 class cl_mirror_bridge final {
 public:
     template <typename Context>
-    cl_mirror_bridge(const Context& cc, wv_engine* e, size_t nodes)
+    cl_mirror_bridge(const Context& cc, wv_engine* e, size_t nodes, size_t plane_nodes, field_guard* guard)
             : engine_{e},
+              guard_{guard},
+              plane_nodes_{plane_nodes ? plane_nodes : 1},
               queue_{cc.context, cc.device},
               buffer_{cc.context, CL_MEM_READ_WRITE, sizeof(cl_float) * nodes},
-              staging_(nodes, 0.0f) {
-        queue_.enqueueWriteBuffer(buffer_, CL_TRUE, 0, sizeof(cl_float) * staging_.size(), staging_.data());
+              nodes_{nodes} {
+        // zeros until somebody wants the field (make_zeroed_buffer is what the reference's own field starts as, waveguide.h:47-56)
+        const std::vector<float> zeros(std::min<size_t>(nodes, size_t{4} << 20), 0.0f);
+        for (size_t at = 0; at < nodes; at += zeros.size())
+            queue_.enqueueWriteBuffer(buffer_, CL_TRUE, sizeof(cl_float) * at, sizeof(cl_float) * std::min(zeros.size(), nodes - at),
+                                      zeros.data());
     }
-    bool per_step() const { return true; }
+    bool wanted_now() const {
+        const auto& wanted = cl_mirror_wanted();
+        return wanted && wanted();
+    }
     template <typename Callback>
     void invoke(Callback& callback, size_t step, size_t steps) {
-        const auto& wanted = cl_mirror_wanted();
-        if (!wanted || wanted()) {
-            // the step's pre-update `current` is the PREVIOUS buffer after wv_run's swap (waveguide.h:121-123)
-            check(wv_read_field(engine_, WV_BUF_PREVIOUS, staging_.data(), 4));
-            queue_.enqueueWriteBuffer(buffer_, CL_TRUE, 0, sizeof(cl_float) * staging_.size(), staging_.data());
+        if (wanted_now()) {
+            guard_->touch();  // the engine's PREVIOUS buffer now holds this step's pre-update `current` (waveguide.h:121-123)
+            if (staging_.size() != nodes_) staging_.assign(nodes_, 0.0f);  // (host memory for the field only once it is wanted)
+            const size_t planes_total = nodes_ / plane_nodes_;
+            const mirror_planes want = cl_mirror_planes();
+            const size_t z0 = want.z_count < 0 ? 0 : std::min((size_t)std::max(want.z_begin, 0), planes_total);
+            const size_t zn = want.z_count < 0 ? planes_total : std::min((size_t)want.z_count, planes_total - z0);
+            if (zn) {
+                float* at = staging_.data() + z0 * plane_nodes_;
+                check(wv_read_planes(engine_, WV_BUF_PREVIOUS, (int32_t)z0, (int32_t)zn, at, 4));
+                queue_.enqueueWriteBuffer(buffer_, CL_TRUE, sizeof(cl_float) * z0 * plane_nodes_,
+                                          sizeof(cl_float) * zn * plane_nodes_, at);
+            }
+            ++last_run_stats().fields_mirrored;
         }
         callback(queue_, static_cast<const cl::Buffer&>(buffer_), step, steps);
     }
 
 private:
     wv_engine* engine_;
+    field_guard* guard_;
+    size_t plane_nodes_;
     cl::CommandQueue queue_;
     cl::Buffer buffer_;
+    size_t nodes_;
     std::vector<float> staging_;
 };
 
@@ -68,7 +113,9 @@ struct callback_bridge_for<Context, decltype(void(cl::CommandQueue{std::declval<
                                                                    std::declval<const Context&>().device}))>
         final {
     using type = cl_mirror_bridge;
-    static type* make(const Context& cc, wv_engine* e, size_t nodes) { return new type{cc, e, nodes}; }
+    static type* make(const Context& cc, wv_engine* e, size_t nodes, size_t plane_nodes, field_guard* guard) {
+        return new type{cc, e, nodes, plane_nodes, guard};
+    }
 };
 
 }  // namespace detail

@@ -28,8 +28,14 @@
 //     WAYVERB_AMD_HAVE_REFERENCE_CORE says the real headers are there.
 //   - `run_device` / `canonical` keep the source and the receivers on the GPU: no per-step PCIe
 //     round trip.  `run` with arbitrary callbacks synchronises every step, like the
-//     reference does; so does `canonical` when its pressure callback can see the field (the
-//     reference's 4-argument form) unless the callback is wrapped in `progress_only`.
+//     reference does.  `canonical` runs AHEAD of its pressure callback: steps are taken in batches
+//     (two-step passes on the device) and the callbacks of a batch fire afterwards, in order, with
+//     the same arguments as in the reference.  A callback that looks at the field -- the reference's
+//     4-argument form may, canonical.h:66-69 -- gets exactly its step's field all the same: the
+//     engine is rolled back to the checkpoint taken before the batch and re-run up to that step
+//     (wv_checkpoint / wv_rollback), and the run then proceeds step by step for as long as somebody
+//     keeps looking.  Nobody has to say in advance whether a callback reads (`progress_only` is a
+//     promise that it never does, which saves the checkpoints).
 #pragma once
 
 #include <algorithm>
@@ -38,7 +44,9 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <ctime>
 #include <experimental/optional>
+#include <functional>
 #include <iterator>
 #include <memory>
 #include <stdexcept>
@@ -77,6 +85,24 @@ inline void throw_for_flag(int flag) {
 }
 }  // namespace detail
 
+namespace detail {
+/// What stands between `canonical`'s pressure callback and the field.  The run is ahead of its observers (see the header
+/// comment): the field of the LAST step of a batch is on the device, that of an earlier step is brought back the moment an
+/// observer looks -- every access through a `buffer` handle, or the cl::Buffer mirror when its owner wants it, calls touch().
+struct field_guard final {
+    std::function<void()> materialise;  // makes the engine's PREVIOUS buffer hold the field of the step being fired
+    bool fresh = true;                  // the device holds the field of the step being fired
+    bool looked = false;                // somebody looked during the callback being fired
+    void touch() {
+        looked = true;
+        if (!fresh && materialise) {
+            materialise();
+            fresh = true;
+        }
+    }
+};
+}  // namespace detail
+
 /// What a step callback sees instead of cl::CommandQueue (hard_source.h:17, directional_receiver.h:36).
 class queue final {
 public:
@@ -89,9 +115,14 @@ private:
 /// What a step callback sees instead of cl::Buffer: one of the engine's two pressure fields.
 class buffer final {
 public:
-    buffer(wv_engine* e, int which, size_t items, int precision = WV_PRECISION_F64)
-            : e_{e}, which_{which}, items_{items}, precision_{precision} {}
-    wv_engine* engine() const { return e_; }
+    buffer(wv_engine* e, int which, size_t items, int precision = WV_PRECISION_F64, detail::field_guard* guard = nullptr)
+            : e_{e}, which_{which}, items_{items}, precision_{precision}, guard_{guard} {}
+    /// The engine whose field this is, for wv_read_planes & co. on the handle.  Asking for it counts as looking at the
+    /// field (in `canonical` the step's field is brought back first, see detail::field_guard).
+    wv_engine* engine() const {
+        if (guard_) guard_->touch();
+        return e_;
+    }
     int which() const { return which_; }
     size_t items() const { return items_; }
     int precision() const { return precision_; }  // WV_PRECISION_*: how the engine stores pressures
@@ -101,6 +132,7 @@ private:
     int which_;
     size_t items_;
     int precision_;
+    detail::field_guard* guard_;
 };
 
 }  // namespace waveguide
@@ -553,6 +585,31 @@ private:
 
 }  // namespace postprocessor
 
+/// What the calling thread's most recent `run_device` / `canonical` did, for tests, tools and the curious.
+struct run_stats final {
+    size_t steps = 0;            // loop iterations completed (= callbacks fired)
+    size_t batches = 0;          // wv_run calls that advanced the run
+    size_t checkpoints = 0;      // batches taken speculatively (wv_checkpoint before them)
+    size_t rollbacks = 0;        // times an observer looked at a step the run had already passed
+    size_t steps_rerun = 0;      // steps computed a second time after a rollback
+    size_t fields_looked_at = 0; // callbacks during which somebody looked at the field
+    size_t fields_mirrored = 0;  // cl_mirror.h: whole-field (or plane-range) copies into the cl::Buffer
+    uint64_t passes = 0;         // two-step passes the engine took (WV_QUERY_PASSES)
+    double seconds = 0;          // wall time of the step loop (engine set-up excluded)
+};
+inline run_stats& last_run_stats() {
+    static thread_local run_stats s;
+    return s;
+}
+
+namespace detail {
+inline double seconds_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+}  // namespace detail
+
 // ---- run_device: single-node source + node receivers, device resident -----------------------------
 /// Equivalent to `run(cc, mesh, hard/soft_source(node, begin, end), <read `receivers` each step>,
 /// keep_going)`, without a host round trip per step.  `on_batch(first_step, n_steps, samples)` is
@@ -584,12 +641,28 @@ size_t run_device(const Context& cc, const Mesh& mesh, source_kind kind, size_t 
     detail::check(wv_set_receivers(engine.get(), receivers.data(), (uint32_t)receivers.size()));
     size_t done_total = 0;
     std::vector<double> samples;
+    run_stats& stats = last_run_stats();
+    stats = run_stats{};
+    const double t0 = detail::seconds_now();
+    struct at_exit final {  // (also when a flag or a callback throws)
+        run_stats& stats;
+        wv_engine* e;
+        const size_t& done_total;
+        double t0;
+        ~at_exit() {
+            uint64_t passes = 0;
+            if (wv_query(e, WV_QUERY_PASSES, &passes) == WV_OK) stats.passes = passes;
+            stats.steps = done_total;
+            stats.seconds = detail::seconds_now() - t0;
+        }
+    } finish{stats, engine.get(), done_total, t0};
     while (done_total < signal.size() && keep_going) {
         const uint64_t want = std::min<uint64_t>(batch, signal.size() - done_total);
         uint64_t done = 0;
         int32_t flag = 0;
         detail::check(wv_run(engine.get(), want, &done, &flag));
         if (done) {
+            ++stats.batches;
             samples.resize((size_t)done * receivers.size());
             detail::check(wv_fetch_receivers(engine.get(), done_total, done, samples.data()));
             detail::call_on_batch(on_batch, engine.get(), done_total, (size_t)done, samples, 0);
@@ -621,8 +694,8 @@ constexpr double compute_sampling_frequency(const single_band_parameters& p) {  
     return compute_sampling_frequency(p.cutoff, p.usable_portion);
 }
 
-/// Marks a pressure callback that never looks at the field (progress bars): `canonical` then keeps
-/// whole batches of steps on the device instead of synchronising after every step.
+/// Marks a pressure callback that never looks at the field (progress bars): a promise that saves `canonical` the
+/// checkpoints it otherwise takes so that a callback MAY look (see the header comment).
 template <typename F>
 struct progress_only_t final {
     F f;
@@ -641,8 +714,9 @@ public:
     // wv_run has swapped the fields by the time the callback fires: the step's pre-update `current`
     // (what waveguide.h:121 hands to `post`) is the engine's PREVIOUS buffer now
     // (the handle carries the ENGINE's pressure type: a callback may branch on buffer::precision(), as soft_source does)
-    handle_bridge(wv_engine* e, size_t nodes) : queue_{e}, current_{e, WV_BUF_PREVIOUS, nodes, default_precision()} {}
-    bool per_step() const { return true; }  // the callback may read the field: it must be the step's field
+    handle_bridge(wv_engine* e, size_t nodes, size_t /*plane_nodes*/, field_guard* guard)
+            : queue_{e}, current_{e, WV_BUF_PREVIOUS, nodes, default_precision(), guard} {}
+    bool wanted_now() const { return false; }  // whether a callback reads shows when it does (the handle tells the guard)
     template <typename Callback>
     void invoke(Callback& callback, size_t step, size_t steps) {
         callback(queue_, static_cast<const buffer&>(current_), step, steps);
@@ -655,7 +729,9 @@ private:
 template <typename Context, typename = void>
 struct callback_bridge_for final {  // cl_mirror.h specialises this for contexts with a cl::Context member
     using type = handle_bridge;
-    static type* make(const Context&, wv_engine* e, size_t nodes) { return new type{e, nodes}; }
+    static type* make(const Context&, wv_engine* e, size_t nodes, size_t plane_nodes, field_guard* guard) {
+        return new type{e, nodes, plane_nodes, guard};
+    }
 };
 
 // a callback that cannot see the field: (step, steps) only, or wrapped in progress_only
@@ -677,6 +753,111 @@ void fire(Bridge& bridge, progress_only_t<F>& callback, size_t step, size_t step
 template <typename Bridge, typename Callback>
 void fire(Bridge&, Callback& callback, size_t step, size_t steps, std::false_type) {
     callback(step, steps);
+}
+
+/// The device-resident run of `run_device`, AHEAD of per-step observers that may look at the field.
+///
+/// `observe(step, row)` is called once per completed step, in order, with the step's receiver samples; while it runs,
+/// `guard.touch()` (any access through a guarded `buffer` handle, or the bridge) makes the engine's PREVIOUS buffer the
+/// step's pre-update `current` -- what waveguide.h:121 hands to `post`.
+///
+/// Batches grow 1, 2, 4 ... `max_batch` while nobody looks.  Before a batch of more than one step the engine's state is
+/// copied aside on the device (wv_checkpoint: 2 fields + filter memories, about the traffic of one step); a look at step i
+/// of the batch rolls the engine back and re-runs i + 1 steps (bit-identical: the engine is deterministic), the rest of
+/// the batch is abandoned and run again later, and the run proceeds one step at a time until `hold_steps` steps have
+/// gone by unobserved.  `wanted_now()` (the bridge knows a reader is attached) keeps it at one step per batch too.
+/// Without room for the checkpoint the run simply stays at one step per batch, like the reference's loop.
+template <typename Context, typename Mesh, typename It, typename MakeBridge, typename WantedNow, typename Observe>
+size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
+                           const std::vector<uint64_t>& receivers, field_guard& guard, MakeBridge&& make_bridge,
+                           WantedNow&& wanted_now, Observe&& observe, const std::atomic_bool& keep_going,
+                           size_t max_batch = 256, size_t hold_steps = 16) {
+    auto engine = make_engine(cc, mesh, default_precision());
+    wv_engine* e = engine.get();
+    std::vector<double> signal(begin, end);
+    check(wv_set_source(e, (int)kind, source_node, signal.data(), signal.size()));
+    check(wv_set_receivers(e, receivers.data(), (uint32_t)receivers.size()));
+    make_bridge(e);
+    run_stats& stats = last_run_stats();
+    stats = run_stats{};
+    const double t0 = seconds_now();
+    const size_t n_recv = receivers.size();
+    size_t done_total = 0, batch = 1, hold = 0;
+    bool can_speculate = max_batch > 1;
+    std::vector<double> samples;
+    const auto finish = [&] {
+        uint64_t passes = 0;
+        if (wv_query(e, WV_QUERY_PASSES, &passes) == WV_OK) stats.passes = passes;
+        stats.steps = done_total;
+        stats.seconds = seconds_now() - t0;
+        guard.materialise = nullptr;
+    };
+    try {
+        while (done_total < signal.size() && keep_going) {
+            size_t want = std::min(batch, signal.size() - done_total);
+            if (wanted_now()) want = 1;
+            if (want > 1) {
+                if (wv_checkpoint(e) == WV_OK) {
+                    ++stats.checkpoints;
+                } else {  // no room for a copy of the fields: one step at a time from here on
+                    can_speculate = false;
+                    batch = want = 1;
+                }
+            }
+            uint64_t done = 0;
+            int32_t flag = 0;
+            check(wv_run(e, want, &done, &flag));
+            if (done) {
+                ++stats.batches;
+                samples.resize((size_t)done * n_recv);
+                check(wv_fetch_receivers(e, done_total, done, samples.data()));
+            }
+            size_t fired = 0;
+            bool looked = false, rewound = false;
+            for (size_t i = 0; i < (size_t)done && !rewound; ++i) {
+                // the fields of a batch that met a flag have advanced past the failing step: none of them is a step's
+                guard.fresh = i + 1 == (size_t)done && flag == 0;
+                guard.looked = false;
+                guard.materialise = [&, i] {
+                    check(wv_rollback(e));
+                    uint64_t again = 0;
+                    int32_t flag_again = 0;
+                    check(wv_run(e, i + 1, &again, &flag_again));
+                    if (again != i + 1 || flag_again)
+                        throw engine_error("wayverb_amd: the re-run after a rollback did not reproduce the batch");
+                    ++stats.rollbacks;
+                    stats.steps_rerun += i + 1;
+                    rewound = true;
+                };
+                observe(done_total + i, samples.data() + i * n_recv);
+                ++fired;
+                if (guard.looked) {
+                    looked = true;
+                    ++stats.fields_looked_at;
+                }
+            }
+            done_total += fired;
+            if (!rewound) {
+                throw_for_flag(flag);
+                if (done < want) break;
+            }
+            // pace: one step at a time while somebody is looking, doubling batches once nobody has for a while
+            if (looked) {
+                batch = 1;
+                hold = hold_steps;
+            } else if (hold > fired) {
+                hold -= fired;
+            } else {
+                hold = 0;
+                if (can_speculate) batch = std::min(max_batch, batch * 2);
+            }
+        }
+    } catch (...) {
+        finish();
+        throw;
+    }
+    finish();
+    return done_total;
 }
 
 /// canonical.h:29-88.  `callback(queue, buffer, step, ideal_steps)` fires once per completed step, in
@@ -710,21 +891,39 @@ std::experimental::optional<band> canonical_impl(const Context& cc, const Mesh& 
     constexpr bool sees_field = takes_field<callback_t>::value;
     band ret{{}, sample_rate};
     ret.directional.reserve(ideal_steps);
-    // one bridge per run, made on the first batch (it needs the engine run_device creates)
     using bridge_t = typename callback_bridge_for<Context>::type;
     std::unique_ptr<bridge_t> bridge;
-    const size_t steps = run_device(
-            cc, mesh, source_kind::hard, compute_mesh_index(source), input.begin(), input.end(), nodes,
-            [&](size_t first, size_t n, const std::vector<double>& s, wv_engine* e) {
-                if (!bridge) bridge.reset(callback_bridge_for<Context>::make(cc, e, num_nodes));
-                for (size_t i = 0; i < n; ++i) {
-                    float nb[6];
-                    for (int k = 0; k < 6; ++k) nb[k] = (float)s[i * 7 + 1 + k];
-                    ret.directional.emplace_back(dr.accumulate((float)s[i * 7], nb));
-                    fire(*bridge, callback, first + i, ideal_steps, std::integral_constant<bool, sees_field>{});
-                }
-            },
-            keep_going, sees_field ? 1 : 256);
+    field_guard guard;  // (declared before the bridge's handles use it; fresh and without a way back unless the run below says otherwise)
+    const size_t plane_nodes = (size_t)mesh.get_descriptor().dimensions.x * (size_t)mesh.get_descriptor().dimensions.y;
+    const auto record = [&](const double* row) {
+        float nb[6];
+        for (int k = 0; k < 6; ++k) nb[k] = (float)row[1 + k];
+        ret.directional.emplace_back(dr.accumulate((float)row[0], nb));
+    };
+    size_t steps = 0;
+    if (sees_field) {
+        steps = run_device_observed(
+                cc, mesh, source_kind::hard, compute_mesh_index(source), input.begin(), input.end(), nodes, guard,
+                [&](wv_engine* e) { bridge.reset(callback_bridge_for<Context>::make(cc, e, num_nodes, plane_nodes, &guard)); },
+                [&] { return bridge->wanted_now(); },
+                [&](size_t step, const double* row) {
+                    record(row);
+                    fire(*bridge, callback, step, ideal_steps, std::integral_constant<bool, sees_field>{});
+                },
+                keep_going);
+    } else {
+        // the callback cannot see the field (or has promised not to look): whole batches, no checkpoints
+        steps = run_device(
+                cc, mesh, source_kind::hard, compute_mesh_index(source), input.begin(), input.end(), nodes,
+                [&](size_t first, size_t n, const std::vector<double>& s, wv_engine* e) {
+                    if (!bridge) bridge.reset(callback_bridge_for<Context>::make(cc, e, num_nodes, plane_nodes, &guard));
+                    for (size_t i = 0; i < n; ++i) {
+                        record(s.data() + i * 7);
+                        fire(*bridge, callback, first + i, ideal_steps, std::integral_constant<bool, sees_field>{});
+                    }
+                },
+                keep_going, 256);
+    }
     if (steps != ideal_steps) return std::experimental::nullopt;
     return ret;
 }

@@ -182,8 +182,118 @@ std::unique_ptr<waveguide_base> make_waveguide_ptr(const waveguide::single_band_
 
 using namespace wayverb;
 
-int main() {
+namespace {
+using pressure_callback_t = std::function<void(cl::CommandQueue& queue, const cl::Buffer& buffer, size_t step, size_t steps)>;
+
+// ---- `combined_shape_test rate N steps`: what the UNCHANGED caller gets, against run_device on the same mesh -------------------
+// An N^3 box; the waveguide leg of combined::engine::impl::run as written (engine.cpp:150-173) through
+// concrete_waveguide::run (type-erased cl:: callback), no listener connected; the same through the engine's own handles
+// (generic lambda, the bin/ programs' form: mic_offset_rotate.cpp:155-167); a listener connected all along; and `run_device`
+// (whole batches, nobody can look) as the yardstick.  One line of JSON on stdout.
+int rate(int n, size_t steps) {
+    const core::compute_context cc{};
+    const core::environment env{};
+    const float spacing = 0.05f;
+    const auto wall = waveguide::to_flat_coefficients(0.1);
+    const waveguide::voxels_and_mesh vm{{}, core::box{}, 0, waveguide::make_box_mesh(n, n, n, spacing, wall), {}};
+    const auto& d = vm.mesh.get_descriptor();
+    const double sample_rate = waveguide::compute_sample_rate(d, env.speed_of_sound);
+    const double t = ((double)steps - 0.5) / sample_rate;
+    const glm::vec3 source{n / 2 * spacing, n / 2 * spacing, n / 2 * spacing};
+    const glm::vec3 receiver{(n / 2 + 5) * spacing, n / 2 * spacing, n / 2 * spacing};
+    const std::atomic_bool keep_going{true};
+    const waveguide::single_band_parameters params{sample_rate * 0.15, 0.6};
+    const auto waveguide_ = combined::make_waveguide_ptr(params);
+    const double nodes = (double)n * n * n;
+    struct leg {
+        const char* name;
+        waveguide::run_stats stats;
+        std::vector<waveguide::postprocessor::directional_receiver::output> records;
+    };
+    std::vector<leg> legs;
+    const auto gnode = [&](const waveguide::run_stats& s) { return nodes * (double)s.steps / s.seconds / 1e9; };
+
+    // the yardstick: nobody can look
+    {
+        auto out = waveguide::detail::canonical_impl(cc, vm.mesh, t, source, receiver, env, keep_going,
+                                                     waveguide::progress_only([](auto&, const auto&, auto, auto) {}));
+        REQUIRE(bool(out) && out->directional.size() == steps);
+        legs.push_back({"run_device", waveguide::last_run_stats(), out->directional});
+    }
+    // src/combined as it is written, nobody listening (the predicate of the application's one line says so)
+    struct {
+        bool attached = false;
+        size_t calls = 0;
+        bool empty() const { return !attached; }
+        void operator()(std::vector<float>, double) { ++calls; }
+    } listeners;
+    waveguide::cl_mirror_wanted() = [&] { return !listeners.empty(); };
+    size_t progress_calls = 0;
+    const pressure_callback_t as_written = [&](auto& queue, const auto& buffer, auto step, auto steps_) {
+        if (!listeners.empty()) {
+            auto pressures = core::read_from_buffer<float>(queue, buffer);
+            listeners(std::move(pressures), step / sample_rate * env.speed_of_sound);
+        }
+        progress_calls += steps_ != 0;
+    };
+    {
+        auto out = waveguide_->run(cc, vm, source, receiver, env, t, keep_going, as_written);
+        REQUIRE(bool(out) && out->front().band.directional.size() == steps && progress_calls == steps);
+        legs.push_back({"combined_unchanged_no_listener", waveguide::last_run_stats(), out->front().band.directional});
+    }
+    // the same with the predicate left empty (the default)
+    waveguide::cl_mirror_wanted() = nullptr;
+    {
+        auto out = waveguide_->run(cc, vm, source, receiver, env, t, keep_going, as_written);
+        REQUIRE(bool(out));
+        legs.push_back({"combined_unchanged_default", waveguide::last_run_stats(), out->front().band.directional});
+    }
+    // the engine's own handles, generic lambda that never looks (bin/mic_test/mic_offset_rotate.cpp:155-167)
+    struct hip_context {
+    } hip_cc;
+    {
+        size_t calls = 0;
+        auto out = waveguide::canonical(hip_cc, vm, source, receiver, env, params, t, keep_going,
+                                        [&](auto&, const auto&, auto, auto) { ++calls; });
+        REQUIRE(bool(out) && calls == steps);
+        legs.push_back({"handles_callback_never_looks", waveguide::last_run_stats(), out->front().band.directional});
+    }
+    // a listener connected all along: every step mirrored (a short run: each step moves the field over PCIe twice)
+    const size_t few = std::min<size_t>(steps, 12);
+    {
+        listeners.attached = true;
+        waveguide::cl_mirror_wanted() = [&] { return !listeners.empty(); };
+        auto out = waveguide_->run(cc, vm, source, receiver, env, ((double)few - 0.5) / sample_rate, keep_going, as_written);
+        waveguide::cl_mirror_wanted() = nullptr;
+        REQUIRE(bool(out) && listeners.calls == few);
+        legs.push_back({"combined_listener_every_step", waveguide::last_run_stats(), {}});
+    }
+    for (size_t i = 1; i + 1 < legs.size(); ++i)
+        REQUIRE(legs[i].records.size() == steps &&
+                std::memcmp(legs[i].records.data(), legs[0].records.data(), steps * sizeof(legs[0].records[0])) == 0);
+    std::printf("{\"n\": %d, \"steps\": %zu", n, steps);
+    for (const auto& l : legs)
+        std::printf(", \"%s\": {\"gnode_per_s\": %.2f, \"seconds\": %.4f, \"steps\": %zu, \"batches\": %zu, \"checkpoints\": %zu, "
+                    "\"rollbacks\": %zu, \"passes\": %llu, \"fields_mirrored\": %zu}",
+                    l.name, gnode(l.stats), l.stats.seconds, l.stats.steps, l.stats.batches, l.stats.checkpoints, l.stats.rollbacks,
+                    (unsigned long long)l.stats.passes, l.stats.fields_mirrored);
+    std::printf("}\n");
+    // the unchanged caller runs two-step passes, and at (nearly) run_device's rate
+    const bool big = nodes >= 4.5e6;
+    for (size_t i = 1; i <= 3; ++i) {
+        if (big) REQUIRE(legs[i].stats.passes > 0);
+        REQUIRE(legs[i].stats.rollbacks == 0 && legs[i].stats.fields_mirrored == 0);
+        if (big && steps >= 1000) REQUIRE(gnode(legs[i].stats) >= 0.9 * gnode(legs[0].stats));
+    }
+    std::puts("COMBINED RATE OK");
+    return 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
     try {
+        if (argc >= 2 && std::strcmp(argv[1], "rate") == 0)
+            return rate(argc >= 3 ? std::atoi(argv[2]) : 256, argc >= 4 ? (size_t)std::atoll(argv[3]) : 1500);
         const core::compute_context compute_context_{};  // the ray tracer's context: OpenCL
         // a 6 x 5 x 4 m box room, two materials -- what engine.cpp:98-103 builds from the scene
         core::scene_data scene;
@@ -207,39 +317,53 @@ int main() {
         // ---- engine.cpp:150-173 ---------------------------------------------------------------------
         struct {
             std::vector<std::pair<std::vector<float>, double>> got;
+            std::vector<size_t> at_step;
             bool attached = true;
             bool empty() const { return !attached; }
             void operator()(std::vector<float> p, double distance) { got.emplace_back(std::move(p), distance); }
         } waveguide_node_pressures_changed_;
         std::vector<double> progress;
         auto engine_state_changed_ = [&](int, double p) { progress.push_back(p); };
-        const double max_stochastic_time = 0.12;
+        const double max_stochastic_time = 0.3;
+        size_t every = 0;  // > 0: the listener is connected for every `every`-th step only (it disconnects / reconnects itself)
 
-        auto waveguide_output = waveguide_->run(
-                compute_context_, voxels_and_mesh_, source_, receiver_, environment_, max_stochastic_time, keep_going,
-                [&](auto& queue, const auto& buffer, auto step, auto steps) {
-                    //  If there are node pressure listeners.
-                    if (!waveguide_node_pressures_changed_.empty()) {
-                        auto pressures = core::read_from_buffer<float>(queue, buffer);
-                        const auto time = step / waveguide_->compute_sampling_frequency();
-                        const auto distance = time * environment_.speed_of_sound;
-                        waveguide_node_pressures_changed_(std::move(pressures), distance);
-                    }
-                    engine_state_changed_(0, step / (steps - 1.0));
-                });
+        // the application's one line, where it connects its listener (cl_mirror.h): src/combined itself is as written below
+        waveguide::cl_mirror_wanted() = [&] { return !waveguide_node_pressures_changed_.empty(); };
+
+        const auto run_as_written = [&] {
+            return waveguide_->run(
+                    compute_context_, voxels_and_mesh_, source_, receiver_, environment_, max_stochastic_time, keep_going,
+                    [&](auto& queue, const auto& buffer, auto step, auto steps) {
+                        //  If there are node pressure listeners.
+                        if (!waveguide_node_pressures_changed_.empty()) {
+                            auto pressures = core::read_from_buffer<float>(queue, buffer);
+                            const auto time = step / waveguide_->compute_sampling_frequency();
+                            const auto distance = time * environment_.speed_of_sound;
+                            waveguide_node_pressures_changed_(std::move(pressures), distance);
+                            waveguide_node_pressures_changed_.at_step.push_back(step);
+                        }
+                        engine_state_changed_(0, step / (steps - 1.0));
+                        if (every) waveguide_node_pressures_changed_.attached = (step + 1) % every == 0;
+                    });
+        };
+        auto waveguide_output = run_as_written();
         REQUIRE(keep_going && waveguide_output);
 
         // ---- what must hold -------------------------------------------------------------------------
-        const auto& band = waveguide_output->front().band;
+        const auto band = waveguide_output->front().band;
         const size_t steps = band.directional.size();
         const auto& d = voxels_and_mesh_.mesh.get_descriptor();
-        REQUIRE(steps == (size_t)std::ceil(band.sample_rate * max_stochastic_time) && steps > 40);
+        REQUIRE(steps == (size_t)std::ceil(band.sample_rate * max_stochastic_time) && steps > 250);
         REQUIRE(progress.size() == steps && progress.front() == 0.0 && progress.back() == 1.0);
         REQUIRE(waveguide_node_pressures_changed_.got.size() == steps);
+        // a listener that is there from the start costs no rollback: the run never gets ahead of it
+        REQUIRE(waveguide::last_run_stats().fields_mirrored == steps && waveguide::last_run_stats().rollbacks == 0 &&
+                waveguide::last_run_stats().batches == steps);
         const size_t receiver_index = waveguide::compute_index(d, receiver_);
         const size_t source_index = waveguide::compute_index(d, source_);
+        const auto every_step = waveguide_node_pressures_changed_.got;
         for (size_t i = 0; i < steps; ++i) {
-            const auto& p = waveguide_node_pressures_changed_.got[i].first;
+            const auto& p = every_step[i].first;
             REQUIRE(p.size() == waveguide::compute_num_nodes(d));
             // the cl::Buffer held step i's field: the receiver's sample of that step is in it ...
             REQUIRE(p[receiver_index] == band.directional[i].pressure);
@@ -247,30 +371,113 @@ int main() {
             if (i == 0) REQUIRE(p[source_index] == (float)waveguide::rectilinear_calibration_factor(d.spacing, 400.0));
             if (i > 0) REQUIRE(p[source_index] == 0.0f);
         }
-        // the same run with the engine's own handles and the same callback text gives the same fields
-        std::vector<std::vector<float>> fields;
-        // (a context with OpenCL members always takes the mirror; the handle form is reached through
-        // a context without them)
+        const auto same_records = [&](const std::vector<waveguide::bandpass_band>& other) {
+            return other.front().band.directional.size() == steps &&
+                   std::memcmp(other.front().band.directional.data(), band.directional.data(), steps * sizeof(band.directional[0])) == 0;
+        };
+
+        // ---- a listener connected for every k-th step only: it receives exactly those steps' fields, whether the run has to
+        // come back for them (k = 40, 97: batches have grown past the step by then) or never got ahead (k = 7) ------------------
+        for (size_t k : {size_t{40}, size_t{7}, size_t{97}}) {
+            every = k;
+            waveguide_node_pressures_changed_.got.clear();
+            waveguide_node_pressures_changed_.at_step.clear();
+            waveguide_node_pressures_changed_.attached = true;  // step 0 is a multiple of k
+            progress.clear();
+            const auto out = run_as_written();
+            const auto stats = waveguide::last_run_stats();
+            REQUIRE(bool(out) && same_records(*out) && progress.size() == steps);
+            REQUIRE(waveguide_node_pressures_changed_.got.size() == (steps + k - 1) / k);
+            for (size_t j = 0; j < waveguide_node_pressures_changed_.got.size(); ++j) {
+                const size_t step = waveguide_node_pressures_changed_.at_step[j];
+                REQUIRE(step == j * k);
+                REQUIRE(std::memcmp(waveguide_node_pressures_changed_.got[j].first.data(), every_step[step].first.data(),
+                                    every_step[step].first.size() * sizeof(float)) == 0);
+            }
+            REQUIRE(stats.fields_mirrored == waveguide_node_pressures_changed_.got.size());
+            if (k == 7) REQUIRE(stats.rollbacks == 0 && stats.batches == steps);  // never more than 16 steps without a look
+            if (k >= 40) REQUIRE(stats.rollbacks >= 2 && stats.batches < steps);
+            std::printf("listener every %zu steps: %zu batches, %zu checkpoints, %zu rollbacks, %zu steps re-run of %zu\n", k, stats.batches,
+                        stats.checkpoints, stats.rollbacks, stats.steps_rerun, steps);
+        }
+        every = 0;
+
+        // ---- the same run with the engine's own handles and the same callback text gives the same fields, and nobody has to
+        // say whether the callback looks: the handle tells -------------------------------------------------------------------
+        // (a context with OpenCL members always takes the mirror; the handle form is reached through a context without them)
         struct hip_context {
         } hip_cc;
-        const auto handles = waveguide::canonical(hip_cc, voxels_and_mesh_, source_, receiver_, environment_,
+        for (size_t k : {size_t{1}, size_t{40}, size_t{0}}) {
+            std::vector<std::vector<float>> fields;
+            std::vector<size_t> at;
+            size_t calls = 0;
+            const auto handles = waveguide::canonical(hip_cc, voxels_and_mesh_, source_, receiver_, environment_,
+                                                      waveguide::single_band_parameters{150.0, 0.6}, max_stochastic_time, keep_going,
+                                                      [&](auto& queue, const auto& buffer, auto step, auto) {
+                                                          ++calls;
+                                                          if (k && step % k == 0) {
+                                                              fields.push_back(core::read_from_buffer<float>(queue, buffer));
+                                                              at.push_back(step);
+                                                          }
+                                                      });
+            const auto stats = waveguide::last_run_stats();
+            REQUIRE(bool(handles) && same_records(*handles) && calls == steps);
+            REQUIRE(fields.size() == (k ? (steps + k - 1) / k : 0) && stats.fields_looked_at == fields.size());
+            for (size_t j = 0; j < fields.size(); ++j)
+                REQUIRE(std::memcmp(fields[j].data(), every_step[at[j]].first.data(), fields[j].size() * sizeof(float)) == 0);
+            if (k == 1) REQUIRE(stats.rollbacks == 0 && stats.batches == steps);
+            if (k == 40) REQUIRE(stats.rollbacks >= 2);
+            if (k == 0) REQUIRE(stats.rollbacks == 0 && stats.batches <= 12);  // 1 + 2 + 4 + ... steps per batch
+            std::printf("handles, a look every %zu steps: %zu batches, %zu checkpoints, %zu rollbacks\n", k, stats.batches, stats.checkpoints,
+                        stats.rollbacks);
+        }
+        // read_value on the handle of a step the run has passed: the same machinery, one value
+        {
+            std::vector<float> seen;
+            const auto out = waveguide::canonical(hip_cc, voxels_and_mesh_, source_, receiver_, environment_,
                                                   waveguide::single_band_parameters{150.0, 0.6}, max_stochastic_time, keep_going,
-                                                  [&](auto& queue, const auto& buffer, auto, auto) {
-                                                      fields.push_back(core::read_from_buffer<float>(queue, buffer));
+                                                  [&](auto& queue, const auto& buffer, auto step, auto) {
+                                                      if (step % 50 == 49) seen.push_back(core::read_value<float>(queue, buffer, receiver_index));
                                                   });
-        REQUIRE(bool(handles) && fields.size() == steps);
-        for (size_t i = 0; i < steps; ++i)
-            REQUIRE(std::memcmp(fields[i].data(), waveguide_node_pressures_changed_.got[i].first.data(),
-                                fields[i].size() * sizeof(float)) == 0);
-        // no listener attached + the predicate set: nothing is mirrored, the run is the same
+            REQUIRE(bool(out) && same_records(*out) && seen.size() == steps / 50);
+            for (size_t j = 0; j < seen.size(); ++j) REQUIRE(seen[j] == band.directional[j * 50 + 49].pressure);
+        }
+
+        // ---- no listener: nothing is mirrored, whole batches, the run is the same -- with the application's predicate and
+        // with the default (an empty predicate: SURVEY.md 8(b), the buffer keeps its zeros) ------------------------------------
         waveguide_node_pressures_changed_.attached = false;
-        waveguide::cl_mirror_wanted() = [&] { return !waveguide_node_pressures_changed_.empty(); };
-        const auto quiet = waveguide_->run(compute_context_, voxels_and_mesh_, source_, receiver_, environment_,
-                                           max_stochastic_time, keep_going,
-                                           [&](auto&, const auto&, auto, auto) {});
-        waveguide::cl_mirror_wanted() = nullptr;
-        REQUIRE(bool(quiet) && std::memcmp(quiet->front().band.directional.data(), band.directional.data(),
-                                           steps * sizeof(band.directional[0])) == 0);
+        for (int with_predicate = 1; with_predicate >= 0; --with_predicate) {
+            if (!with_predicate) waveguide::cl_mirror_wanted() = nullptr;
+            float seen_max = 0;
+            const auto quiet = waveguide_->run(compute_context_, voxels_and_mesh_, source_, receiver_, environment_,
+                                               max_stochastic_time, keep_going, [&](auto& queue, const auto& buffer, auto step, auto) {
+                                                   if (step == 100)
+                                                       for (float v : core::read_from_buffer<float>(queue, buffer)) seen_max = std::max(seen_max, std::fabs(v));
+                                               });
+            const auto stats = waveguide::last_run_stats();
+            REQUIRE(bool(quiet) && same_records(*quiet));
+            REQUIRE(stats.fields_mirrored == 0 && stats.rollbacks == 0 && stats.batches <= 12 && seen_max == 0.0f);
+        }
+        // cl_mirror_always + a range of planes: only those planes of the buffer follow the field
+        {
+            waveguide::cl_mirror_wanted() = waveguide::cl_mirror_always();
+            const size_t z_mid = (size_t)d.dimensions.z / 2;
+            waveguide::cl_mirror_planes() = waveguide::mirror_planes{(int)z_mid, 2};
+            const size_t plane = (size_t)d.dimensions.x * d.dimensions.y;
+            bool ok = true;
+            const auto sliced = waveguide_->run(compute_context_, voxels_and_mesh_, source_, receiver_, environment_, max_stochastic_time,
+                                                keep_going, [&](auto& queue, const auto& buffer, auto step, auto) {
+                                                    if (step % 64 != 63) return;
+                                                    const auto p = core::read_from_buffer<float>(queue, buffer);
+                                                    for (size_t i = 0; i < p.size(); ++i) {
+                                                        const bool in = i >= z_mid * plane && i < (z_mid + 2) * plane;
+                                                        ok = ok && p[i] == (in ? every_step[step].first[i] : 0.0f);
+                                                    }
+                                                });
+            waveguide::cl_mirror_wanted() = nullptr;
+            waveguide::cl_mirror_planes() = waveguide::mirror_planes{};
+            REQUIRE(bool(sliced) && same_records(*sliced) && ok);
+        }
     } catch (const cl::Error& e) {
         std::printf("OpenCL error: %s (%d)\n", e.what(), e.err());
         return 3;

@@ -78,6 +78,22 @@ def test_combined_call_shape_runs_with_real_opencl_types(built_library):
     assert "COMBINED SHAPE OK" in p.stdout
 
 
+@pytest.mark.gpu
+def test_unchanged_combined_caller_runs_at_run_device_rate(built_library):
+    """`combined_shape_test rate 512 1500`: engine.cpp:150-173 as written (type-erased cl:: callback, no listener) on a 512^3
+    box takes two-step passes, needs no rollback, gives run_device's records bit for bit and >= 0.9 x its rate; likewise a
+    generic lambda on the engine's handles.  The JSON line goes to gpurun_out/ when that exists (profiles/r05)."""
+    _build_shape_test(built_library)
+    p = subprocess.run([SHAPE_EXE, "rate", "512", "1500"], capture_output=True, text=True, timeout=900)
+    if p.returncode == 3:
+        pytest.skip("no OpenCL GPU device on this box: " + p.stdout.strip())
+    assert p.returncode == 0 and "COMBINED RATE OK" in p.stdout, p.stdout + p.stderr
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "combined_caller_rate_512.json"), "w") as f:
+            f.write(p.stdout.splitlines()[0] + "\n")
+
+
 C_SRC = os.path.join(ROOT, "examples", "box_run.c")
 C_EXE = os.path.join(ROOT, "examples", "box_run")
 

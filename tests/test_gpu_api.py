@@ -311,3 +311,50 @@ def test_frequency_independent_walls_beside_filtered_ones(oracle, built_library,
         flat_rows = np.isin(o_bd[0]["coefficient_index"], [0, 1])
         assert not o_bd[0]["filter_memory"][flat_rows].any()
         assert o_bd[0]["filter_memory"][~flat_rows].any()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("n,tuning", [(40, {}), (168, {}), (168, {"pair": 0})])
+def test_checkpoint_and_rollback_reproduce_the_abandoned_steps(built_library, precision, n, tuning):
+    """wv_checkpoint / wv_rollback (what `canonical` runs ahead of its observers on): after a rollback the engine continues
+    from the checkpoint and reproduces the abandoned steps bit for bit -- fields, filter memories, receiver rows, step count
+    and position in the source signal -- on single steps (40^3) and on two-step passes (168^3), and a second rollback to the
+    same checkpoint does so again."""
+    from helpers import set_tuning
+    set_tuning(**tuning)
+    try:
+        rng = np.random.default_rng(5)
+        coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2),
+                                 np.array([M.flat_coefficients(0.1)], dtype=M.coefficients_dtype)])
+        mesh = M.box_mesh(n, n, n, coefficients=coeffs, surface_of_face=[0, 1, 2, 0, 1, 2])
+        sig = rng.uniform(-1, 1, 64)
+        src = mesh.compute_index(n // 2, n // 2, 3)              # three planes from a wall: reflections reach it within the run
+        recv = [mesh.compute_index(n // 2 + 1, n // 2, 4), mesh.compute_index(2, n // 2, n // 2)]
+        eng = E.Engine(mesh, precision=precision)
+        eng.set_source(E.SOURCE_SOFT, src, sig)
+        eng.set_receivers(recv)
+        assert eng.run_steps(11) == (11, 0)
+        eng.checkpoint()
+
+        def rest(steps):
+            assert eng.run_steps(steps) == (steps, 0)
+            return (eng.step_count(), eng.read_field(E.BUF_CURRENT).tobytes(), eng.read_field(E.BUF_PREVIOUS).tobytes(),
+                    [eng.read_boundary_data(d).tobytes() for d in (1, 2, 3)], eng.fetch_receivers(0, 11 + steps).tobytes())
+
+        first = rest(24)
+        if n >= 160 and not tuning:
+            assert eng.query(0) > 0                               # WV_QUERY_PASSES: the abandoned steps were two-step passes
+        eng.rollback()
+        assert eng.step_count() == 11
+        assert rest(24) == first
+        eng.rollback()
+        part = rest(7)                                            # an odd count: the fields end in the other roles
+        assert eng.run_steps(17) == (17, 0)
+        assert eng.read_field(E.BUF_CURRENT).tobytes() == first[1] and eng.fetch_receivers(0, 35).tobytes() == first[4]
+        assert part[0] == 18
+        eng.drop_checkpoint()
+        with pytest.raises(Exception):
+            eng.rollback()
+        eng.close()
+    finally:
+        set_tuning()

@@ -156,6 +156,18 @@ int wv_device_buffer(wv_engine* e, int buffer, void** p) {
     WV_NEED(e);
     return e->device_buffer(buffer, p);
 }
+int wv_checkpoint(wv_engine* e) {
+    WV_NEED(e);
+    return e->checkpoint(0);
+}
+int wv_rollback(wv_engine* e) {
+    WV_NEED(e);
+    return e->checkpoint(1);
+}
+int wv_drop_checkpoint(wv_engine* e) {
+    WV_NEED(e);
+    return e->checkpoint(2);
+}
 int wv_step(wv_engine* e, int32_t* flag) {
     WV_NEED(e);
     return e->step(flag);

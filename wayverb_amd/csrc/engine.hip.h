@@ -120,6 +120,7 @@ public:
     int boundary_data(int dim, wv_boundary_data* host, bool to_device) override;
     int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) override;
     int device_buffer(int buffer_id, void** p) override;
+    int checkpoint(int op) override;
     // ---- engine_batch.hip.h
     int kernel_time(double* mean_ms, uint64_t* launches, uint64_t* steps) override;
     int synchronize() override;
@@ -261,6 +262,17 @@ private:
     std::vector<Real> recv_stage_;
     std::vector<double> recv_log_;
     std::unique_ptr<wv::SlabComm> comm_;
+    // wv_checkpoint / wv_rollback (engine_io.hip.h): device copies of the two live fields and the filter memories, and the
+    // host-side position that goes with them
+    struct Checkpoint {
+        Real* field[2] = {nullptr, nullptr};  // [0] current, [1] previous at the time of the save
+        double* fmem = nullptr;
+        bool valid = false;
+        uint64_t steps_done = 0, signal_pos = 0, recv_first_step = 0;
+        size_t recv_log_size = 0;
+        uint32_t n_recv = 0;
+        int outside_dirty = 0;
+    } ckpt_;
 };
 
 }  // namespace wv

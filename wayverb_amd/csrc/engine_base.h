@@ -80,6 +80,7 @@ struct wv_engine {
     virtual int boundary_data(int dim, wv_boundary_data* host, bool to_device) = 0;
     virtual int set_coefficients(const wv_coefficients_canonical* c, uint32_t n) = 0;
     virtual int device_buffer(int buffer, void** p) = 0;
+    virtual int checkpoint(int op) = 0;  // 0 save, 1 restore, 2 drop (wv_checkpoint / wv_rollback / wv_drop_checkpoint)
     virtual int step(int32_t* flag) = 0;
     virtual int swap() = 0;
     virtual int set_source(int kind, uint64_t node, const double* signal, uint64_t n) = 0;

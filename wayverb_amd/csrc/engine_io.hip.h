@@ -297,4 +297,71 @@ int Engine<Real>::device_buffer(int buffer_id, void** p) {
     return WV_OK;
 }
 
+// wv_checkpoint / wv_rollback / wv_drop_checkpoint: the state `run` carries from one loop iteration to the next (waveguide.h:80-123:
+// the two pressure buffers and the boundary filter memories) copied aside on the device, and put back.  What a caller that runs
+// batches of steps ahead of its per-step observers needs to hand an observer the field of a step the batch has already passed
+// (include/wayverb_amd/waveguide.h, canonical_impl).
+template <typename Real>
+int Engine<Real>::checkpoint(int op) {
+    DeviceGuard guard(device_);
+    const size_t fmem_bytes = std::max<size_t>(n_slots_, 1) * 6 * sizeof(double);
+    if (op == 2) {
+        WV_HIP(hipStreamSynchronize(stream_));
+        for (auto& f : ckpt_.field) {
+            if (f) (void)hipFree(f);
+            f = nullptr;
+        }
+        if (ckpt_.fmem) (void)hipFree(ckpt_.fmem);
+        ckpt_ = Checkpoint{};
+        return WV_OK;
+    }
+    if (op == 0) {
+        ckpt_.valid = false;
+        for (auto& f : ckpt_.field)
+            if (!f) {
+                const hipError_t rc = hipMalloc((void**)&f, field_bytes_ + 256);
+                if (rc != hipSuccess) {
+                    f = nullptr;
+                    (void)hipGetLastError();  // nothing sticky: the engine itself is untouched and goes on without a checkpoint
+                    return fail(WV_E_HIP, std::string("wv_checkpoint: no room for a copy of the fields: ") + hipGetErrorString(rc));
+                }
+            }
+        if (!ckpt_.fmem) {
+            const hipError_t rc = hipMalloc((void**)&ckpt_.fmem, fmem_bytes);
+            if (rc != hipSuccess) {
+                ckpt_.fmem = nullptr;
+                (void)hipGetLastError();
+                return fail(WV_E_HIP, std::string("wv_checkpoint: no room for a copy of the filter memories: ") + hipGetErrorString(rc));
+            }
+        }
+        WV_HIP(hipMemcpyAsync(ckpt_.field[0], field_[cur_], field_bytes_, hipMemcpyDeviceToDevice, stream_));
+        WV_HIP(hipMemcpyAsync(ckpt_.field[1], field_[prv_], field_bytes_, hipMemcpyDeviceToDevice, stream_));
+        WV_HIP(hipMemcpyAsync(ckpt_.fmem, fmem_, fmem_bytes, hipMemcpyDeviceToDevice, stream_));
+        ckpt_.steps_done = steps_done;
+        ckpt_.signal_pos = signal_pos_;
+        ckpt_.recv_first_step = recv_first_step_;
+        ckpt_.recv_log_size = recv_log_.size();
+        ckpt_.n_recv = n_recv_;
+        ckpt_.outside_dirty = outside_dirty_;
+        ckpt_.valid = true;
+        return WV_OK;
+    }
+    if (op != 1) return fail(WV_E_INVALID_ARGUMENT, "unknown checkpoint operation");
+    if (!ckpt_.valid) return fail(WV_E_STATE, "wv_rollback: no checkpoint has been taken");
+    if (ckpt_.recv_first_step != recv_first_step_ || ckpt_.n_recv != n_recv_ || recv_log_.size() < ckpt_.recv_log_size)
+        return fail(WV_E_STATE, "wv_rollback: the receivers were changed after the checkpoint");
+    if (signal_pos_ < ckpt_.signal_pos)
+        return fail(WV_E_STATE, "wv_rollback: the source was changed after the checkpoint");
+    WV_HIP(hipMemcpyAsync(field_[cur_], ckpt_.field[0], field_bytes_, hipMemcpyDeviceToDevice, stream_));
+    WV_HIP(hipMemcpyAsync(field_[prv_], ckpt_.field[1], field_bytes_, hipMemcpyDeviceToDevice, stream_));
+    WV_HIP(hipMemcpyAsync(fmem_, ckpt_.fmem, fmem_bytes, hipMemcpyDeviceToDevice, stream_));
+    steps_done = ckpt_.steps_done;
+    signal_pos_ = ckpt_.signal_pos;
+    recv_log_.resize(ckpt_.recv_log_size);
+    outside_dirty_ = std::max(outside_dirty_, ckpt_.outside_dirty);  // (steps taken since may have cleaned the outside nodes: the copies have not)
+    xw_valid_ = false;  // the x-facing walls' compact copies hold the abandoned steps' values
+    pre_post_done_ = pair_mid_done_ = pair_list_done_ = false;
+    return WV_OK;
+}
+
 }  // namespace wv

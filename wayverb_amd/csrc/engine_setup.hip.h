@@ -537,6 +537,9 @@ void Engine<Real>::release() {
     for (int i = 0; i < 4; ++i)
         if (field_[i]) (void)hipFree(field_[i]);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    for (auto& f : ckpt_.field)
+        if (f) (void)hipFree(f);
+    if (ckpt_.fmem) (void)hipFree(ckpt_.fmem);
     void* ptrs[] = {pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, xw_nbr_, xw_val_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                     status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
     for (void* p : ptrs)

@@ -33,7 +33,7 @@ EXPORTS = [
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
     "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_hrtf_attenuation", "wv_hrtf_ear_position",
     "wv_attenuate_hrtf", "wv_multiband_filter_and_mixdown", "wv_postprocess_waveguide_hrtf", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
-    "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy",
+    "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy", "wv_checkpoint", "wv_rollback", "wv_drop_checkpoint",
 ]
 
 
@@ -138,6 +138,9 @@ def load_library():
     lib.wv_set_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.wv_device_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.wv_step.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.wv_checkpoint.argtypes = [C.c_void_p]
+    lib.wv_rollback.argtypes = [C.c_void_p]
+    lib.wv_drop_checkpoint.argtypes = [C.c_void_p]
     lib.wv_swap.argtypes = [C.c_void_p]
     lib.wv_set_source.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]
     lib.wv_set_receivers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -405,6 +408,17 @@ class Engine:
         return p.value
 
     # ---- stepping ---------------------------------------------------------------------------
+    def checkpoint(self):
+        """wv_checkpoint: the fields, filter memories and the position in the run copied aside on the device."""
+        _check(self.lib.wv_checkpoint(self.h))
+
+    def rollback(self):
+        """wv_rollback: back to the last checkpoint (the engine then reproduces the abandoned steps bit for bit)."""
+        _check(self.lib.wv_rollback(self.h))
+
+    def drop_checkpoint(self):
+        _check(self.lib.wv_drop_checkpoint(self.h))
+
     def step(self):
         flag = C.c_int32()
         _check(self.lib.wv_step(self.h, C.byref(flag)))
