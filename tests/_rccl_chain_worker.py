@@ -4,7 +4,7 @@ communicator from wv_comm_init (the RCCL path of csrc/comm.cpp, NOT the in-proce
 its own thread with wv_run, all on one GPU; the result is compared with the single-domain engine bit for bit.
 
     python tests/_rccl_chain_worker.py <world> <room> <nx> <ny> <nz> <f32|f64> <steps> <seed> [<bad_step>] [--pair=0|1]
-                                       [--short-signal=K] [--rccl-library=PATH]
+                                       [--short-signal=K] [--rccl-library=PATH] [--tuning=k=v,...]
 """
 import sys
 import threading
@@ -28,7 +28,7 @@ def global_mesh(dims, room, rng):
 
 
 def main():
-    short_signal, library = None, None
+    short_signal, library, source_plane = None, None, None
     for a in [a for a in sys.argv if a.startswith("--")]:
         key, value = a[2:].split("=", 1)
         if key == "pair":             # stepping mode of every engine (wv_tuning::pair)
@@ -37,6 +37,10 @@ def main():
             short_signal = int(value)
         elif key == "rccl-library":   # wv_comm_use_library instead of LD_LIBRARY_PATH
             library = value
+        elif key == "source-plane":   # global plane of the source (default: the top owned plane of slab 0, a slab face)
+            source_plane = int(value)
+        elif key == "tuning":         # other wv_tuning fields, k=v,k=v
+            E.default_tuning.update({k: int(v) for k, v in (kv.split("=") for kv in value.split(","))})
         sys.argv.remove(a)
     world, room = int(sys.argv[1]), sys.argv[2]
     dims = tuple(int(a) for a in sys.argv[3:6])
@@ -62,7 +66,7 @@ def main():
     plane = dims[0] * dims[1]
     # the source on a slab face (top owned plane of slab 0), receivers on every slab and next to a cut
     L0 = SlabLayout(dims, 0, world)
-    on_face = inside[(inside // plane) == L0.z1 - 1]
+    on_face = inside[(inside // plane) == (L0.z1 - 1 if source_plane is None else source_plane)]
     source = int(on_face[len(on_face) // 2])
     receivers = [int(inside[len(inside) // 3]), int(inside[-5]), source]
     for r in range(world):
@@ -130,6 +134,7 @@ def main():
         for d in range(3):
             bd[d].append(e.read_boundary_data(d + 1))
     detail = [e.kernel_time_detail() for e in engines]
+    early_passes = [int(e.query(E.Engine.QUERY_EARLY_PASSES)) for e in engines]
     for e in engines:
         e.close()
     if trace.tobytes() != want["trace"].tobytes():
@@ -150,7 +155,7 @@ def main():
         print("FAILED", problems)
         sys.exit(4)
     two_step = all(steps_ > launches for _, launches, steps_ in detail if launches)
-    print("OK steps %d flag %d two_step_passes %s" % (want_done, want_flag, two_step))
+    print("OK steps %d flag %d two_step_passes %s early_passes %s" % (want_done, want_flag, two_step, early_passes))
 
 
 if __name__ == "__main__":
