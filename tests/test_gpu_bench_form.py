@@ -21,41 +21,58 @@ from wayverb_amd import mesh as M
 
 pytestmark = pytest.mark.gpu
 
-N, WORLD, PLANES = 1024, 2, 160
-NZG = WORLD * PLANES
-CUT = PLANES
+N = 1024
 S, W = 8, 3
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("source_at", ["next-to-the-cut", "mid-slab"])
-@pytest.mark.parametrize("tuning", [dict(slab_early=1), dict(slab_early=0, fuse_planes=0), dict(slab_early=1, pair_chunks=2), dict()],
-                         ids=["both-exchanges-under-the-march", "round-3-order", "early-two-rounds", "defaults"])
-def test_bench_width_fp64_passes_across_a_cut_against_the_oracle(oracle, built_library, tuning, source_at):
+_TUNINGS = {"both-exchanges-under-the-march": dict(slab_early=1), "round-3-order": dict(slab_early=0, fuse_planes=0),
+            "early-two-rounds": dict(slab_early=1, pair_chunks=2), "defaults": dict()}
+_FORMS = [(2, 160, t, s) for t in _TUNINGS for s in ("next-to-the-cut", "mid-slab")] + \
+         [(8, 32, "both-exchanges-under-the-march", "next-to-the-cut"), (8, 32, "both-exchanges-under-the-march", "mid-slab"),
+          (8, 32, "defaults", "next-to-the-cut")]     # (the oracle's windows around seven cuts take 17 s per case)
+
+
+@pytest.mark.parametrize("world,planes,tuning,source_at", _FORMS, ids=["%dx%d-planes-%s-%s" % f for f in _FORMS])
+def test_bench_width_fp64_passes_across_a_cut_against_the_oracle(oracle, built_library, world, planes, tuning, source_at):
+    """2 x 160 planes: the cut of a strong-scaling chain with thick slabs; 8 x 32 planes: what tools/slab_overhead.py used to
+    compare by sampling (eight thin slabs at bench width, every cut carrying noise)."""
+    WORLD, PLANES, tuning = world, planes, _TUNINGS[tuning]
+    NZG = WORLD * PLANES
+    CUT = PLANES * (WORLD // 2)                                  # the cut the source and the receiver sit at
     rng = np.random.default_rng(320)
     coeffs = M.bench_materials()
     signal = rng.uniform(-0.5, 0.5, S)
-    mid = CUT + PLANES // 2
-    bands = [(1, 1 + W, True), (NZG - 1 - W, NZG - 1, True), (CUT - W, CUT + W, False), (mid - W, mid + W, False)]
+    bands = [(1, 1 + W, True), (NZG - 1 - W, NZG - 1, True)] + [(k * PLANES - W, k * PLANES + W, False) for k in range(1, WORLD)]
+    # a source away from the cut: in the middle of the slab above it, inside a band of its own -- where slabs are thick enough for
+    # one (bands must stay 2 S + 1 planes apart for the windows to be exact); in a 32-plane slab three planes above the cut's
+    # first plane, i.e. just beyond the planes g, f, n that decide the order of that slab's passes
+    mid = CUT + PLANES // 2 if PLANES >= 100 else CUT + 3
+    if PLANES >= 100:
+        bands.append((mid - W, mid + W, False))
     # the source one plane above the cut's first plane: slab 1's plane n (g = CUT - 1 is its ghost, f = CUT its face)
     src = (CUT + 1, 300, 411) if source_at == "next-to-the-cut" else (mid, 300, 411)
-    rc = (CUT - 1, 500, 600)                                   # top owned plane of slab 0; its +z node belongs to slab 1
+    rc = (CUT - 1, 500, 600)                                   # top owned plane of the slab below the cut; its +z node belongs to the next
+    far = (CUT // 2, mid + W + S + 2) if PLANES >= 100 else (PLANES // 2, PLANES + PLANES // 2)   # planes no band reaches in S steps
     chain = BandedChain(N, WORLD, PLANES, S, bands, src, rc, extra_recv=[(src[0], src[1], src[2] + 2), (src[0] - 1, src[1], src[2])],
-                        noise_seed=2055, far_planes=(CUT // 2, mid + W + S + 2))
+                        noise_seed=2055, far_planes=far)
 
     def after_run(trace):
         assert np.any(trace[:, 6] != 0) and np.any(trace[:, 7] != 0)
     queries = chain.run_and_check(oracle, "f64", coeffs, tuning, False, signal, True, after_run)
     passes = [p for p, _ in queries]
     early = [e for _, e in queries]
-    assert passes == [3, 3], queries                           # written fields: two single sweeps first, then three passes
+    assert passes == [3] * WORLD, queries                      # written fields: two single sweeps first, then three passes
     want_early = tuning.get("slab_early", -1) == 1             # (-1: slabs that share a device keep round 3's order)
+    below, above = WORLD // 2 - 1, WORLD // 2                  # the slabs either side of the cut
     if not want_early:
-        assert early == [0, 0], queries
+        assert early == [0] * WORLD, queries
     elif source_at == "next-to-the-cut":
-        assert early == [3, 0], queries                        # slab 1 sees the source in its plane n: the older order, for it alone
+        # the slab above sees the source in its plane n: the older order, for it alone (the slab below does not hold plane CUT + 1)
+        assert early == [0 if r == above else 3 for r in range(WORLD)], queries
     else:
-        assert early == [3, 3], queries
+        assert early == [3] * WORLD, queries
+    assert below >= 0
 
 
 @pytest.fixture(scope="module")
@@ -77,8 +94,8 @@ def test_bench_width_fp64_passes_over_the_rccl_branch_equal_the_single_domain(mo
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env["WV_NO_TORCH_PRELOAD"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py"), "2", "box", str(N), str(N), str(NZG), "f64", "27", "77",
-                          "--pair=1", "--tuning=slab_early=%d" % early, "--source-plane=%d" % (CUT + PLANES // 2)], capture_output=True, text=True, env=env, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py"), "2", "box", str(N), str(N), "320", "f64", "27", "77",
+                          "--pair=1", "--tuning=slab_early=%d" % early, "--source-plane=240"], capture_output=True, text=True, env=env, timeout=900)
     last = (out.stdout.strip().splitlines() or [""])[-1]
     assert out.returncode == 0 and last.startswith("OK steps 27 flag 0 two_step_passes True"), (out.stdout[-1500:], out.stderr[-1500:])
     assert ("early_passes [12, 12]" if early else "early_passes [0, 0]") in last, last

@@ -260,6 +260,13 @@ def test_random_slab_chains_equal_the_single_domain(built_library, seed, _step_m
     assert_same(got, want, gmesh)
 
 
+@pytest.mark.parametrize("seed", range(200, 236))
+def test_more_random_slab_chains_equal_the_single_domain(built_library, seed, _step_mode):
+    """tools/extended_fuzz.py's slab-chain family with a fixed budget of fresh seeds (it found the soft-source-on-a-face race of
+    round 3 at about one chain in 1 500): the same check as above, in the three stepping modes."""
+    test_random_slab_chains_equal_the_single_domain(built_library, seed, _step_mode)
+
+
 def test_a_group_refuses_slabs_that_are_out_of_step():
     """Exchanges address the neighbour's field buffers by role: a slab that was stepped on its own (wv_step + wv_swap)
     before joining no longer has its buffers in the roles the others have, and wv_run_group says so instead of
