@@ -23,6 +23,14 @@ one launch advances every node by TWO time steps and moves 4 x 8 B per node, 16 
 at N > 1 over a slab's planes between its face planes, which are stepped separately around the two
 halo exchanges of a pass -- or, where the engine keeps single steps (small meshes, `--tuning pair=0`),
 the plane sweep (3 x 8 B per node-update).
+`roofline.frac` is the fraction of the 8 TB/s peak at the HBM traffic the PMC counters MEASURED for this kernel (profiles/traffic.json,
+quoted only for the very device code, kernel and workload it was measured on) when such a figure is on file, else at the
+algorithmic bytes; `frac_definition` says which, `frac_algorithmic` / `frac_measured_traffic` give both, and every fraction
+in the line can be recomputed from fields of the same line.  `roofline.boundary` = the two boundary launches of a pass (HIP
+events like the march): what stands between the dominant kernel's rate and the whole step's.  `windows`: three more windows of
+steps after the timed region (the driver's K may be a few dozen steps: 61 ms at K = 20), min / median / max.
+A run that cannot finish -- a peer rank died, a collective hangs -- ends with the JSON line carrying "error" and a non-zero exit
+status (the engine's watchdog, wv_options::comm_timeout_s; `--deadline` for everything else) instead of hanging.
 `cpu_baseline` is the reference's own kernel compiled for the host (oracle/_ref, kind "reference";
 the C restatement, kind "port", when that is absent) on the host's cores, N = 1 only, on the SAME
 mesh for a few steps.
@@ -62,6 +70,12 @@ def parse_args():
                                                 "(default: none -- the product's own choices)")
     p.add_argument("--no-reference-on-gpu", action="store_true",
                    help="skip running the reference's OpenCL kernel on this GPU (oracle/_ref/libwvref_cl.so)")
+    p.add_argument("--comm-timeout", type=int, default=180,
+                   help="N > 1: seconds a rank waits for a batch of steps before it gives up on its peers (wv_options::comm_timeout_s)")
+    p.add_argument("--deadline", type=float, default=1500.0,
+                   help="seconds after which the run is abandoned: rank 0 prints its JSON line with an \"error\" field instead of "
+                        "hanging (a stuck collective, a dead peer); 0 = none")
+    p.add_argument("--no-windows", action="store_true", help="skip the three extra timing windows after the timed region")
     return p.parse_args()
 
 
@@ -133,8 +147,58 @@ def cpu_baseline(args, elem):
                       % (nx, ny, nz, args.precision, steps, dt, threads, cores, what)}
 
 
+class _Guard:
+    """What keeps a run that cannot finish from hanging without a line: `phase` says where it is; fail() makes rank 0 print the
+    JSON line with an "error" field and ends the process WITHOUT running destructors (an engine whose streams are stuck in a
+    collective would wait for them for ever); a timer calls it when --deadline expires, SIGTERM (the launcher ending the job
+    because a peer rank died) calls it too."""
+
+    def __init__(self, args):
+        import signal
+        import threading
+        self.args, self.phase, self.done = args, "start", False
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.lock = threading.Lock()
+        if args.deadline > 0:
+            t = threading.Timer(args.deadline, lambda: self.fail("--deadline: the run did not finish within %.0f s" % args.deadline, 3))
+            t.daemon = True
+            t.start()
+        signal.signal(signal.SIGTERM, lambda *_: self.fail("terminated by the launcher (a peer rank failed or was killed)", 4))
+
+    def fail(self, message, status=1):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                a = self.args
+                print(json.dumps({"metric": "Gnode-updates/s, fp64 box mesh" if a.precision == "f64" else "Gnode-updates/s, fp32 box mesh",
+                                  "value": None, "unit": "Gnode-updates/s", "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup,
+                                  "ms_per_step": None, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+                                  "dtype": a.precision, "data": "synthetic",
+                                  "error": "%s [rank %d of %d, while: %s]" % (message, self.rank, self.world, self.phase)}), flush=True)
+            else:
+                print("bench.py rank %d: %s [while: %s]" % (self.rank, message, self.phase), file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(status)
+
+
 def main():
     args = parse_args()
+    guard = _Guard(args)
+    try:
+        run_bench(args, guard)
+    except SystemExit as e:
+        if e.code not in (None, 0):
+            guard.fail(str(e.code) if not isinstance(e.code, int) else "exit status %d" % e.code, 1)
+        raise
+    except BaseException as e:  # noqa: BLE001  (WV_E_COMM from the engine's watchdog lands here)
+        guard.fail("%s: %s" % (type(e).__name__, str(e)[:600]), 1)
+    guard.done = True
+
+
+def run_bench(args, guard):
     import torch
     import torch.distributed as dist
     from wayverb_amd import build
@@ -161,11 +225,14 @@ def main():
         raise SystemExit("%d ranks on %d GPU(s): RCCL needs one GPU per rank (tests: --rccl-library <stand-in>)" % (world, n_dev))
     if args.rccl_library:
         E.Engine.comm_use_library(args.rccl_library)
+    guard.phase = "torch.distributed rendezvous"
     if world > 1:
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=max(60, args.comm_timeout))
         if shared_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     coll_device = "cpu" if shared_gpu else "cuda"  # where the bookkeeping collectives' tensors live
     if rank == 0:
         build.build(verbose=False)
@@ -179,21 +246,25 @@ def main():
     nz_global = args.nz if args.scaling == "strong" else args.nz * world
     layout = SlabLayout((nx, ny, nz_global), rank, world)
     t_setup = time.perf_counter()
+    guard.phase = "mesh and engine set-up"
     mesh = box_slab_mesh(nx, ny, nz_global, layout, coefficients=M.bench_materials())
     eng = E.Engine(mesh, precision=args.precision, device=local_rank,
-                   ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi)
+                   ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi, comm_timeout_s=args.comm_timeout)
     mesh.nodes = None  # host copy no longer needed
     if world > 1:
         idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device=coll_device)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(E.Engine.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
+        guard.phase = "wv_comm_init (ncclCommInitRank of %d ranks)" % world
         eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
     t_setup = time.perf_counter() - t_setup
 
     # canonical pairing: calibrated hard-source impulse at the centre of the global mesh, one
     # receiver a few nodes away (canonical.h:55-81), both device resident
-    total_steps = args.warmup + args.steps
+    # three more windows after the timed region, each long enough for half a second or so (the driver's K may be 20 steps)
+    window_steps = 0 if args.no_windows else max(args.steps, min(400, 2 * int(0.25 * 360e9 / (nx * ny * args.nz)) + 2))
+    total_steps = args.warmup + args.steps + 3 * window_steps
     signal = np.zeros(total_steps)
     signal[0] = 1.0
     plane = nx * ny
@@ -214,14 +285,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    guard.phase = "warm-up (%d steps)" % args.warmup
     run(args.warmup)
     fence()
     eng.enable_kernel_timing(True)
     eng.kernel_time_ms()
+    guard.phase = "timed region (%d steps)" % args.steps
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    guard.phase = "after the timed region"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,14 +307,39 @@ def main():
         # work did not hide).  Read before kernel_time_detail, which resets the timing counters.
         Q = E.Engine
         waits = eng.query(Q.QUERY_HALO_WAITS)
-        halo = {"bytes_sent_per_step": round(eng.query(Q.QUERY_HALO_BYTES_SENT) / max(1, total_steps)),
-                "exchanges_per_step": round(eng.query(Q.QUERY_HALO_EXCHANGES) / max(1, total_steps), 3),
+        steps_so_far = max(1, args.warmup + args.steps)
+        halo = {"bytes_sent_per_step": round(eng.query(Q.QUERY_HALO_BYTES_SENT) / steps_so_far),
+                "exchanges_per_step": round(eng.query(Q.QUERY_HALO_EXCHANGES) / steps_so_far, 3),
                 "exposed_wait_us_per_wait": round(eng.query(Q.QUERY_HALO_WAIT_NS) / 1e3 / waits, 2) if waits else None,
                 "timed_waits": int(waits),
                 "passes_with_both_exchanges_under_the_march": int(eng.query(Q.QUERY_EARLY_PASSES)), "passes": int(eng.query(Q.QUERY_PASSES)),
                 "rank": rank}
+    # the two boundary launches of the timed passes (read before kernel_time_detail, which resets)
+    Q = E.Engine
+    b_n = eng.query(Q.QUERY_BOUNDARY_TIMED)
+    boundary_ms = [eng.query(Q.QUERY_BOUNDARY1_NS) / 1e6 / b_n, eng.query(Q.QUERY_BOUNDARY2_NS) / 1e6 / b_n] if b_n else None
     kernel_ms, launches, timed_steps = eng.kernel_time_detail()
     eng.enable_kernel_timing(False)
+    windows = None
+    if window_steps:
+        guard.phase = "extra timing windows (3 x %d steps)" % window_steps
+        rates = []
+        for _ in range(3):
+            fence()
+            tw = time.perf_counter()
+            run(window_steps)
+            fence()
+            dt = time.perf_counter() - tw
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            rates.append(nx * ny * nz_global * window_steps / dt / 1e9)
+        rates.sort()
+        windows = {"steps_each": window_steps, "gnode_per_s": [round(r, 2) for r in rates], "min": round(rates[0], 2),
+                   "median": round(rates[1], 2), "max": round(rates[2], 2),
+                   "note": "three more windows after the timed region, not part of `value` (which is the K timed steps above)"}
+    guard.phase = "bookkeeping"
 
     owned_nodes = nx * ny * (layout.z1 - layout.z0)
     total_nodes = nx * ny * nz_global
@@ -266,6 +365,7 @@ def main():
     # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
     # when it was measured on this very device code, this kernel and this workload
     traffic = None
+    boundary_traffic = None
     traffic_note = "no PMC measurement on file for this kernel / workload / device code"
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(prof):
@@ -274,9 +374,25 @@ def main():
             if (rec.get("workload") == "%dx%dx%d %s" % (nx, ny, args.nz, args.precision)
                     and rec.get("kernel") == kernel_name and rec.get("kernel_sources") == kernel_sources_hash()):
                 traffic = rec.get("hbm_bytes_per_launch")
+                boundary_traffic = rec.get("boundary_hbm_bytes_per_launch")   # [to t+1, to t+2]
                 traffic_note = "rocprofv3 --pmc passes of %s (profiles/%s)" % (rec.get("measured", "?"), rec.get("files", "traffic.json"))
         except Exception:
             traffic = None
+    # the boundary launches of a pass: one lane per boundary node; a 1-D node moves 168 B per level (own old value, six neighbours'
+    # lines as far as they are not shared, 6 x 8 B of filter memory in and out, its entry) -- DESIGN.md 4.3's figure; each further
+    # filter of a 2-D / 3-D node 104 B more
+    n_b = [int(mesh.bidx[d].shape[0]) for d in range(3)]
+    boundary_alg = 168 * n_b[0] + (168 + 104) * n_b[1] + (168 + 208) * n_b[2]
+    boundary = None
+    if boundary_ms:
+        boundary = {"launches_per_pass": 2, "ms": [round(boundary_ms[0], 4), round(boundary_ms[1], 4)], "timed_passes": int(b_n),
+                    "alg_bytes_per_launch": boundary_alg,
+                    "alg_bytes_definition": "168 B per 1-D boundary node and level (+ 104 B per further filter of a 2-D / 3-D node): %d / %d / %d nodes" % tuple(n_b),
+                    "achieved_gbs": [round(boundary_alg / (ms * 1e-3) / 1e9, 1) for ms in boundary_ms],
+                    "traffic": boundary_traffic,
+                    "share_of_a_pass": round(sum(boundary_ms) / (sum(boundary_ms) + kernel_ms), 4) if kernel_ms > 0 else None,
+                    "note": "the march holds every register of every CU, so these run behind it, not beside it: "
+                            "ms_per_step ~ (kernel_ms + ms[0] + ms[1]) / time_steps_per_launch"}
     triad = None
     if world == 1:
         try:
@@ -297,9 +413,17 @@ def main():
                    "halo_measured": halo,
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     # which bound `frac` is a fraction of: the dominant kernel's own algorithmic bytes (NOT SURVEY.md 8(d)'s
-                     # 24 B per node-update when the engine takes two-step passes -- that figure is below as
+                     # `frac`: at the MEASURED traffic when a PMC figure for this very kernel / workload / device code is on file
+                     # (what the memory system actually moved per launch / kernel_ms / peak), else at the algorithmic bytes
+                     "frac": round((traffic if traffic else alg_bytes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else 0.0,
+                     "frac_definition": ("traffic / kernel_ms / peak: HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                         "gfx950 corrections) of the same kernel, workload and device code" if traffic else
+                                         "alg_bytes_per_launch / kernel_ms / peak (no PMC figure on file for this device code)"),
+                     "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_measured_traffic": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_ms > 0 else None,
+                     "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
+                     # which bound the algorithmic figures are fractions of: the dominant kernel's own algorithmic bytes (NOT SURVEY.md
+                     # 8(d)'s 24 B per node-update when the engine takes two-step passes -- that figure is below as
                      # single_step_equivalent / whole_step_frac_at_24B_per_update)
                      "frac_bound": ("two-step pass, %d B per node-update (4 fields x %d B per node and launch)" % (2 * elem, elem)) if two_step
                                    else ("single-step sweep, %d B per node-update" % (3 * elem)),
@@ -316,10 +440,14 @@ def main():
                      "single_step_equivalent": {"bytes_per_node_update": 3 * elem, "achieved": round(per_update_equiv, 1),
                                                 "frac": round(per_update_equiv / HBM_PEAK_GBS, 4)},
                      "triad_gbs": triad,
+                     "boundary": boundary,
                      "whole_step_frac_at_24B_per_update": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    if windows:
+        out["windows"] = windows
     eng.close()
 
+    guard.phase = "side measurements"
     if world == 1 and rank == 0 and not args.no_small and (nx, ny, args.nz) == (1024, 1024, 1024):
         # side measurement: BASELINE configs[1] (256^3; the whole working set sits in the 256 MiB
         # Infinity Cache, so it is not an HBM roofline point)
@@ -357,6 +485,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    guard.phase = "shutdown"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,7 +113,8 @@ typedef struct wv_tuning {
     int32_t slab_early;       /* z-slabs, two-step passes: 1 = the faces AND the planes next to them are stepped ahead of the march, so that both
                                * halo exchanges of a pass (and the faces' second step, on the halo stream) run under it; 0 = the second exchange
                                * follows the march (the form of rounds 2 and 3); -1 (default) = 1 where a neighbour lives on another GPU (RCCL,
-                               * or a slab of this process on another device), 0 between slabs that share a device */
+                               * or a slab of this process on another device), 0 between slabs that share a device.  Read once, at
+                               * wv_create (the x-facing walls' compact copies leave out the planes an early pass steps ahead) */
     int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
     int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
     int32_t reserved_[4];
@@ -138,7 +139,11 @@ typedef struct wv_options {
     /* 1: wv_mesh::nodes is a device pointer on `device` (what wv_scene_mesh_create_engine passes);
      * the boundary index and coefficient arrays are host arrays either way */
     int32_t nodes_on_device;
-    int32_t reserved_[7];
+    /* z-slabs over RCCL: seconds a rank waits for a batch of steps (or for the ranks' agreement before one) before it gives up on
+     * its peers -- WV_E_COMM, wv_last_error naming the rank, its neighbours and the stream that had not drained; the communicator
+     * is aborted and the engine is good for wv_destroy only.  0 = 180 s, < 0 = wait for ever (plain hipStreamSynchronize). */
+    int32_t comm_timeout_s;
+    int32_t reserved_[6];
     /* HOW the engine does its work -- never what it computes: every setting gives bit-identical results
      * (tests/test_gpu_parity.py, test_gpu_pair.py run the golden cases under each).  wv_default_options
      * fills in the product's choices; the fields exist for measurement and for the tests.  The library
@@ -252,7 +257,10 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
  *   WV_QUERY_EARLY_PASSES    two-step passes of a slab that ran both exchanges under the march (wv_tuning::slab_early) */
 enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_QUERY_MARCH_LIVE_PERMILLE = 3,
        WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5, WV_QUERY_HALO_WAIT_NS = 6, WV_QUERY_HALO_WAITS = 7,
-       WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10 };
+       WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10,
+       /* kernel timing on: total time of the two boundary launches of the two-step passes whose march was timed (nodes to t+1 / to t+2),
+        * over that many passes; reset by wv_kernel_time */
+       WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

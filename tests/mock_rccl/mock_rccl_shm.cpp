@@ -14,6 +14,7 @@
 //
 //   hipcc -O2 -fPIC -shared tests/mock_rccl/mock_rccl_shm.cpp -o <dir>/libwvmockrccl.so -lrt
 #include <fcntl.h>
+#include <signal.h>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -22,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -31,7 +33,35 @@
 namespace {
 
 constexpr int kMaxRanks = 16, kMaxWords = 1024;
-constexpr double kTimeoutSeconds = 180.0;
+// how long a call waits for the peer's matching call (WV_MOCK_RCCL_TIMEOUT_S in the environment overrides)
+double timeout_seconds() {
+    static const double t = [] {
+        const char* v = std::getenv("WV_MOCK_RCCL_TIMEOUT_S");
+        return v ? std::atof(v) : 180.0;
+    }();
+    return t;
+}
+
+// WV_MOCK_RCCL_STALL=<rank>:<n>: that rank's n-th ncclAllReduce does nothing but put a kernel on the stream that spins (for at
+// most a minute) and returns -- what a real RCCL collective with a dead peer looks like from the host: the call returns, the
+// stream never drains.  For the engine's watchdog (csrc/comm.cpp, SlabComm::sync).
+// WV_MOCK_RCCL_DIE=<rank>:<n>: that rank's process is killed (SIGKILL) in its n-th ncclAllReduce: a rank that dies mid-run.
+__global__ void stall_kernel(volatile int* release, long long ticks) {
+    const long long t0 = wall_clock64();
+    while (!*release && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(100);
+}
+// 0: go on, 1: stall, 2: die -- decided per ncclAllReduce of `rank`
+int fate_now(int rank) {
+    static const char* stall = std::getenv("WV_MOCK_RCCL_STALL");
+    static const char* die = std::getenv("WV_MOCK_RCCL_DIE");
+    static std::atomic<int> calls{0};
+    if (!stall && !die) return 0;
+    const int mine = calls.fetch_add(1) + 1;
+    int r = -1, n = -1;
+    if (stall && std::sscanf(stall, "%d:%d", &r, &n) == 2 && r == rank && n == mine) return 1;
+    if (die && std::sscanf(die, "%d:%d", &r, &n) == 2 && r == rank && n == mine) return 2;
+    return 0;
+}
 
 struct Control {
     std::atomic<int> nranks;  // 0 until the first rank joins
@@ -84,7 +114,7 @@ bool wait_until(Ready ready) {
     int spins = 0;
     while (!ready()) {
         if (++spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
-        if (now() - t0 > kTimeoutSeconds) return false;
+        if (now() - t0 > timeout_seconds()) return false;
     }
     return true;
 }
@@ -197,6 +227,15 @@ int ncclCommDestroy(void* comm) {
     return 0;
 }
 
+int ncclCommAbort(void* comm) {  // what the engine's watchdog calls: nothing of this stand-in's runs on the device
+    Comm* c = static_cast<Comm*>(comm);
+    if (c) {
+        munmap(c->ctl, sizeof(Control));
+        delete c;
+    }
+    return 0;
+}
+
 int ncclGroupStart(void) {
     ++t_depth;
     return 0;
@@ -221,6 +260,17 @@ int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm, hipStream
 int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) {
     if (dtype != 5 || (op != 0 && op != 3) || count > (size_t)kMaxWords) return 4;  // ncclUint64; ncclSum / ncclMin
     Comm* c = static_cast<Comm*>(comm);
+    const int fate = fate_now(c->rank);
+    if (fate == 1) {
+        int* release = nullptr;
+        if (hipMalloc((void**)&release, sizeof(int)) != hipSuccess || hipMemset(release, 0, sizeof(int)) != hipSuccess) return 1;
+        hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, stream, release, 60ll * 100000000ll);  // (wall_clock64: 100 MHz)
+        return 0;
+    }
+    if (fate == 2) {
+        std::fflush(nullptr);
+        kill(getpid(), SIGKILL);
+    }
     Control& ctl = *c->ctl;
     const int b = c->bank;
     c->bank ^= 1;

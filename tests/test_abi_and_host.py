@@ -171,3 +171,18 @@ def test_no_kernel_of_the_engine_spills(built_library):
             assert waves >= 3, (name, waves)
             seen.add("boundary")
     assert seen == {"march", "boundary"}
+
+
+def test_bench_without_a_gpu_prints_an_error_line(built_library):
+    """bench.py's contract is ONE JSON line whatever happens: without a GPU the line carries "error" and the exit status is 1."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 1 and len(lines) == 1, (p.stdout, p.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "needs a GPU" in line["error"] and line["n_gpus"] == 1

@@ -73,3 +73,47 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
     fields = 4 if roof["time_steps_per_launch"] > 1.5 else 3
     assert roof["alg_bytes_per_launch"] == fields * 8 * nx * ny * (owned0 - 1)
     assert r["cpu_baseline"] is None
+
+
+def _run_failing_bench(world, shm_mock, env_extra, *extra, timeout=240):
+    import time
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rccl-library", shm_mock,
+           "--no-cpu-baseline", "--no-reference-on-gpu", "--nx", "256", "--ny", "96", "--nz", "48", "--steps", "8", "--warmup", "4",
+           "--no-windows"] + [str(a) for a in extra]
+    env = dict(os.environ)
+    env.update(env_extra)
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    took = time.perf_counter() - t0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, lines, took
+
+
+def test_a_collective_that_never_completes_ends_with_an_error_line_not_a_hang(shm_mock):
+    """Rank 1's third all-reduce returns but never completes on the device (WV_MOCK_RCCL_STALL: what a collective with a dead peer
+    looks like under the real RCCL).  Its engine's watchdog (SlabComm::sync, 4 s here) gives up with WV_E_COMM naming rank, peers and
+    stream; rank 0, left alone in the all-reduce, is let go by the stand-in's own time-out.  bench.py ends with ONE JSON line
+    carrying "error" and a non-zero status, within seconds -- the driver's timeout is not what ends it."""
+    out, lines, took = _run_failing_bench(2, shm_mock, {"WV_MOCK_RCCL_STALL": "1:3", "WV_MOCK_RCCL_TIMEOUT_S": "6"}, "--comm-timeout", "4")
+    assert out.returncode != 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "error" in line and line["n_gpus"] == 2, line
+    assert "rank 1 of 2" in out.stderr and "did not finish within 4 s" in out.stderr, out.stderr[-3000:]
+    assert took < 120, took
+
+
+def test_a_rank_killed_mid_run_ends_the_others_within_the_deadline(shm_mock):
+    """One of four ranks is killed (SIGKILL) in the middle of the run: the others do not wait for it for ever -- their exchanges
+    with it time out, or the launcher ends them (SIGTERM: bench.py's handler) -- and rank 0 still prints its line, with "error"."""
+    out, lines, took = _run_failing_bench(4, shm_mock, {"WV_MOCK_RCCL_DIE": "2:3", "WV_MOCK_RCCL_TIMEOUT_S": "6"}, "--comm-timeout", "4")
+    assert out.returncode != 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "error" in line and line["n_gpus"] == 4, line
+    assert took < 120, took
+
+
+def test_the_deadline_ends_a_run_that_takes_too_long(shm_mock):
+    """--deadline: whatever a run is stuck in, the line is printed (here: a deadline shorter than the set-up)."""
+    out, lines, took = _run_failing_bench(2, shm_mock, {}, "--deadline", "0.5")
+    assert out.returncode != 0 and len(lines) == 1 and "--deadline" in json.loads(lines[0])["error"], (out.stdout[-2000:], out.stderr[-2000:])

@@ -15,6 +15,38 @@ import os
 import sys
 
 
+def write_traffic_record(where, out, workload="1024x1024x1024 f64"):
+    """profiles/traffic.json (+ a copy beside the summary): the measured HBM bytes per launch of the dominant kernel and of the two
+    boundary launches of a pass, stamped with the device code they were measured on -- what bench.py quotes as roofline.traffic."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    total = lambda v: int(2 * v["FETCH_SIZE"]["mean_KiB"] * 1024 + v["WRITE_SIZE"]["mean_KiB"] * 1024)  # noqa: E731
+    march = [(k, v) for k, v in out.items() if k.startswith("pair_march_kernel<double") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    if not march:
+        return
+    k, v = march[0]
+    tag = os.path.basename(os.path.normpath(where))
+    rec = {"workload": workload, "kernel": "pair_march_kernel", "kernel_full_name": "wv::" + k, "kernel_sources": bench.kernel_sources_hash(),
+           "measured": tag, "files": "%s/pmc_summary.json" % tag,
+           "source": "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel trace only, "
+                     "launches of `bench.py --steps 30 --warmup 6`)" % tag,
+           "FETCH_SIZE_KiB_raw": v["FETCH_SIZE"]["mean_KiB"], "WRITE_SIZE_KiB_raw": v["WRITE_SIZE"]["mean_KiB"],
+           "corrections": "gfx950: FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads -> x2 (calibrated on the in-place triad "
+                          "in tools/stream_bench.hip: 2*FETCH_SIZE*1024 = bytes read, exactly); WRITE_SIZE*1024 = bytes written, exactly; "
+                          "Infinity-Cache hits are counted (fabric-side counter)",
+           "hbm_bytes_per_launch": total(v)}
+    # the two boundary launches of a pass: boundary_kernel<double, ..., false> steps the boundary nodes to t+1, <..., true> to t+2
+    level = {}
+    for name, c in out.items():
+        if name.startswith("boundary_kernel<double") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            level[1 if name.rstrip(">").rstrip().endswith("true") else 0] = total(c)
+    if len(level) == 2:
+        rec["boundary_hbm_bytes_per_launch"] = [level[0], level[1]]
+    for path in (os.path.join(where, "traffic.json"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")):
+        json.dump(rec, open(path, "w"), indent=1)
+    print("traffic record:", json.dumps({k: rec[k] for k in ("kernel_sources", "hbm_bytes_per_launch") if k in rec}), rec.get("boundary_hbm_bytes_per_launch"))
+
+
 def main():
     where = sys.argv[1]
     out = {}
@@ -27,6 +59,7 @@ def main():
             for k, v in agg.items():
                 out.setdefault(k, {})[c] = {"mean_KiB": sum(v) / len(v), "n": len(v)}
     json.dump(out, open(os.path.join(where, "pmc_summary.json"), "w"), indent=1)
+    write_traffic_record(where, out)
     for k, v in sorted(out.items()):
         if "boundary_kernel" in k or "pair_march" in k or "stream_sweep" in k:
             f, w = v.get("FETCH_SIZE", {}).get("mean_KiB", 0), v.get("WRITE_SIZE", {}).get("mean_KiB", 0)

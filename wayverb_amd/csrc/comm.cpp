@@ -3,9 +3,11 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 #include <initializer_list>
 #include <mutex>
+#include <thread>
 
 namespace wv {
 namespace {
@@ -17,6 +19,7 @@ struct UniqueId {
 typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
 typedef int (*CommDestroyFn)(void*);
+typedef int (*CommAbortFn)(void*);
 typedef int (*GroupFn)(void);
 typedef int (*SendFn)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*RecvFn)(void*, size_t, int, int, void*, hipStream_t);
@@ -28,6 +31,7 @@ struct Rccl {
     GetUniqueIdFn get_unique_id = nullptr;
     CommInitRankFn comm_init_rank = nullptr;
     CommDestroyFn comm_destroy = nullptr;
+    CommAbortFn comm_abort = nullptr;  // optional: the watchdog's way to end kernels in flight
     GroupFn group_start = nullptr, group_end = nullptr;
     SendFn send = nullptr;
     RecvFn recv = nullptr;
@@ -81,6 +85,7 @@ Rccl& rccl() {
         r.get_unique_id = (GetUniqueIdFn)dlsym(r.handle, "ncclGetUniqueId");
         r.comm_init_rank = (CommInitRankFn)dlsym(r.handle, "ncclCommInitRank");
         r.comm_destroy = (CommDestroyFn)dlsym(r.handle, "ncclCommDestroy");
+        r.comm_abort = (CommAbortFn)dlsym(r.handle, "ncclCommAbort");
         r.group_start = (GroupFn)dlsym(r.handle, "ncclGroupStart");
         r.group_end = (GroupFn)dlsym(r.handle, "ncclGroupEnd");
         r.send = (SendFn)dlsym(r.handle, "ncclSend");
@@ -243,6 +248,7 @@ void SlabComm::set_fields(void* const* fields, int n_fields, size_t plane_bytes,
 }
 
 SlabComm::~SlabComm() {
+    if (dead_) return;  // (its streams may never drain, and the watchdog has aborted the communicator: everything is left to the process's end)
     if (stream_) (void)hipStreamSynchronize(stream_);
     // local transport: a neighbour's push into this slab's ghost plane runs on the NEIGHBOUR's halo stream
     for (SlabComm* peer : {lo_, hi_})
@@ -269,6 +275,10 @@ SlabComm::~SlabComm() {
 }
 
 bool SlabComm::wait_ghosts(hipStream_t compute, int field, std::string* err) {
+    if (dead_) {
+        *err = "the communicator was aborted after a time-out (an earlier call says where)";
+        return false;
+    }
     if (local_) {
         // my ghost planes of THIS buffer are written by the neighbours' pushes into it -- and by no later ones: a
         // neighbour that is already a step (or half a pass) ahead in host order has pushed into another buffer since
@@ -326,6 +336,10 @@ bool SlabComm::join_halo(hipStream_t compute, std::string* err) {
 }
 
 bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err, bool on_halo_stream) {
+    if (dead_) {
+        *err = "the communicator was aborted after a time-out (an earlier call says where)";
+        return false;
+    }
     if (field < 0 || field >= n_fields_ || !fields_[field] || nz_ < 3) {
         *err = "exchange_faces: no such field buffer";
         return false;
@@ -337,6 +351,7 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err, 
         if (!hip_ok(hipEventRecord(faces_ready_, compute), "hipEventRecord", err)) return false;
         if (!hip_ok(hipStreamWaitEvent(stream_, faces_ready_, 0), "hipStreamWaitEvent", err)) return false;
     }
+    ++exchanges_;
     planes_sent_ += (loopback_ ? 2u : 0u) + (!loopback_ && has_lo_ ? 1u : 0u) + (!loopback_ && has_hi_ ? 1u : 0u);
     if (local_) {
         // push my face planes into the neighbours' ghost planes of the same buffer.  The neighbour
@@ -426,6 +441,10 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err, 
 // words[i] <- min over the ranks, on the halo stream like every other RCCL call of this communicator; host-synchronous
 // (the caller needs the answer to decide what to enqueue next).
 bool SlabComm::agree_min(hipStream_t stream, uint64_t* words, int n, std::string* err) {
+    if (dead_) {
+        *err = "the communicator was aborted after a time-out (an earlier call says where)";
+        return false;
+    }
     if (local_ || n <= 0) return true;
     if (n > kMaxFlags) {
         *err = "agree_min: too many words";
@@ -445,10 +464,52 @@ bool SlabComm::agree_min(hipStream_t stream, uint64_t* words, int n, std::string
     if (!hip_ok(hipStreamWaitEvent(stream, reduce_out_, 0), "hipStreamWaitEvent", err)) return false;
     if (!hip_ok(hipMemcpyAsync(words, spread_, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync", err))
         return false;
-    return hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize", err);
+    return sync(stream, "the ranks' agreement on the next batch of steps (an all-reduce every rank must enter)", err);
+}
+
+bool SlabComm::sync(hipStream_t stream, const std::string& what, std::string* err) {
+    if (dead_) {
+        *err = "the communicator was aborted after a time-out (an earlier call says where)";
+        return false;
+    }
+    if (local_ || timeout_s_ <= 0) return hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize", err);
+    if (!sync_ev_ && !hip_ok(hipEventCreateWithFlags(&sync_ev_, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    if (!hip_ok(hipEventRecord(sync_ev_, stream), "hipEventRecord", err)) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    int polls = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(sync_ev_);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) return hip_ok(q, "hipEventQuery", err);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > timeout_s_) break;
+        // (the first few hundred polls back to back: a batch that is nearly done costs no sleep; then 50 us naps, 1 ms after a second)
+        if (++polls > 400) std::this_thread::sleep_for(std::chrono::microseconds(waited > 1.0 ? 1000 : 50));
+    }
+    (void)hipGetLastError();
+    const bool halo_busy = stream_ && hipStreamQuery(stream_) == hipErrorNotReady;
+    (void)hipGetLastError();
+    std::string peers;
+    if (has_lo_) peers += "rank " + std::to_string(loopback_ ? rank_ : rank_ - 1);
+    if (has_hi_) peers += std::string(peers.empty() ? "" : " and ") + "rank " + std::to_string(loopback_ ? rank_ : rank_ + 1);
+    *err = "rank " + std::to_string(rank_) + " of " + std::to_string(nranks_) + ": " + what + " did not finish within " +
+           std::to_string((int)timeout_s_) + " s; " +
+           (halo_busy ? "the halo stream is still waiting in an exchange / all-reduce with " + (peers.empty() ? std::string("its peers") : peers)
+                      : std::string("the halo stream has drained, the compute stream has not")) +
+           " (a peer rank that died or never made the matching call, or the collective library itself); the communicator has been aborted";
+    dead_ = true;
+    // end what is in flight where the library can (RCCL: the send / receive kernels spinning on a peer that will not answer)
+    Rccl& r = rccl();
+    if (comm_ && r.comm_abort) (void)r.comm_abort(comm_);
+    comm_ = nullptr;
+    return false;
 }
 
 bool SlabComm::or_flags(hipStream_t stream, int* flags, int n, std::string* err) {
+    if (dead_) {
+        *err = "the communicator was aborted after a time-out (an earlier call says where)";
+        return false;
+    }
     if (local_ || n <= 0) return true;  // (a one-rank communicator reduces with itself: the loopback test runs this path)
     if (n > kMaxFlags || nranks_ >= (1 << kFlagField)) {
         *err = "or_flags: too many flag words or ranks";

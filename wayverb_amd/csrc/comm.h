@@ -59,6 +59,8 @@ public:
     bool join_halo(hipStream_t compute, std::string* err);
     // planes handed to neighbours so far (each plane_bytes() long)
     uint64_t planes_sent() const { return planes_sent_; }
+    // exchanges issued so far (single steps: one per step; two-step passes: two per pass)
+    uint64_t exchanges() const { return exchanges_; }
     size_t plane_bytes() const { return plane_bytes_; }
     // End of a step on `compute`: this slab has read the ghost planes of the step's `current` field
     // (the local transport may overwrite them once this has passed).
@@ -80,6 +82,19 @@ public:
     // local transport: everything this slab has pushed into its neighbours has landed
     hipStream_t halo_stream() const { return stream_; }
 
+    // ---- the watchdog (RCCL transport) -------------------------------------------------------------------------------------
+    // A peer that died, or a collective library that deadlocks, leaves this rank's streams waiting on the device for good:
+    // hipStreamSynchronize would never return and the caller would never hear why.  `sync` waits for `stream` like
+    // hipStreamSynchronize but gives up after the time-out (an event polled with hipEventQuery): it then says who was waiting
+    // for whom (*err: rank, neighbours, which of the two streams had not drained, `what`), aborts the communicator
+    // (ncclCommAbort, where the library has it: the kernels still in flight end) and marks this communicator dead -- every later
+    // call fails at once and nothing synchronises with its streams again (the process is expected to end).
+    // seconds <= 0: no time-out (plain hipStreamSynchronize).  The in-process transport has no peer that could die: plain, too.
+    void set_timeout(double seconds) { timeout_s_ = seconds; }
+    double timeout() const { return timeout_s_; }
+    bool sync(hipStream_t stream, const std::string& what, std::string* err);
+    bool dead() const { return dead_; }
+
     // Does any neighbour live on another GPU (RCCL: always; in-process: a linked slab on another device)?  What runs beside a
     // slab's march then needs a CU of THIS device while the march holds them all; slabs that share one device take turns anyway.
     bool peers_elsewhere() const {
@@ -100,7 +115,10 @@ private:
     hipEvent_t faces_ready_ = nullptr;
     hipEvent_t ghosts_ready_ = nullptr;
     hipEvent_t halo_joined_ = nullptr;
-    uint64_t planes_sent_ = 0;
+    uint64_t planes_sent_ = 0, exchanges_ = 0;
+    double timeout_s_ = 0;
+    bool dead_ = false;
+    hipEvent_t sync_ev_ = nullptr;
     hipEvent_t reduce_in_ = nullptr, reduce_out_ = nullptr;  // or_flags: compute stream -> halo stream -> compute stream
     bool pending_ = false;
     // field geometry

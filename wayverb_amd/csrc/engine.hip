@@ -16,6 +16,7 @@
 
 namespace {
 thread_local std::string g_last_error;
+thread_local hipError_t g_last_hip_error = hipSuccess;
 }  // namespace
 
 namespace wv {
@@ -23,6 +24,8 @@ int fail_with(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+void note_hip_error(hipError_t err) { g_last_hip_error = err; }
+hipError_t last_hip_error() { return g_last_hip_error; }
 }  // namespace wv
 
 using wv::DeviceGuard;

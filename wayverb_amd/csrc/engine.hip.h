@@ -76,6 +76,8 @@ public:
     bool slab_early_now() const;
     int begin_halo_wait_timing();
     int end_halo_wait_timing(int token);
+    int begin_part_timing(int part);
+    int end_part_timing(int part, int token);
     int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
     int batch_pair_eligible(int* eligible) override;
     int batch_pair_prepare(int* ready, int* singles_first) override;
@@ -223,7 +225,13 @@ private:
     int halo_ev_used_ = 0;
     unsigned halo_timing_calls_ = 0;
     double halo_wait_ms_ = 0;
-    uint64_t halo_wait_n_ = 0, halo_exchanges_ = 0, early_passes_ = 0;
+    uint64_t halo_wait_n_ = 0, early_passes_ = 0;
+    // kernel timing of a two-step pass's two boundary launches (part 0: nodes to t+1, part 1: to t+2), in the passes whose march is timed
+    std::vector<hipEvent_t> part_events_[2];
+    int part_ev_used_[2] = {0, 0};
+    double part_ms_[2] = {0, 0};
+    uint64_t part_n_[2] = {0, 0};
+    bool pass_timed_ = false;
     std::vector<uint32_t> plane_start_, plane_start_rest_;
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)

@@ -23,12 +23,17 @@ namespace wv {
 // the calling thread's most recent failure (wv_last_error); returns `code`
 int fail_with(int code, const std::string& msg);
 inline int fail(int code, const std::string& msg) { return fail_with(code, msg); }
+// the HIP status behind the calling thread's most recent WV_E_HIP (what tells "no memory for this" from a fault)
+void note_hip_error(hipError_t err);
+hipError_t last_hip_error();
 
 #define WV_HIP(expr)                                                                            \
     do {                                                                                          \
         hipError_t err__ = (expr);                                                                \
-        if (err__ != hipSuccess)                                                                  \
+        if (err__ != hipSuccess) {                                                                \
+            ::wv::note_hip_error(err__);                                                          \
             return ::wv::fail(WV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));    \
+        }                                                                                         \
     } while (0)
 
 constexpr int kRing = 1024;  // steps per device batch (flag words / receiver rows kept on device)

@@ -33,6 +33,46 @@ int Engine<Real>::drain_timing() {
         ++halo_wait_n_;
     }
     halo_ev_used_ = 0;
+    for (int p = 0; p < 2; ++p) {
+        for (int i = 0; i + 1 < part_ev_used_[p]; i += 2) {
+            float ms = 0;
+            WV_HIP(hipEventElapsedTime(&ms, part_events_[p][i], part_events_[p][i + 1]));
+            part_ms_[p] += ms;
+            ++part_n_[p];
+        }
+        part_ev_used_[p] = 0;
+    }
+    return WV_OK;
+}
+
+// Kernel timing of the boundary launches of a two-step pass whose march is timed (bench.py's roofline.boundary: what stands between
+// the dominant kernel's rate and the whole step's).
+template <typename Real>
+int Engine<Real>::begin_part_timing(int part) {
+    if (!timing || !pass_timed_) return -1;
+    auto& ev = part_events_[part];
+    if (ev.empty()) {
+        ev.resize(2 * 512);
+        for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                (void)hipGetLastError();
+                e = nullptr;
+            }
+    }
+    const int at = part_ev_used_[part];
+    if (at + 2 > (int)ev.size() || !ev[at] || !ev[at + 1]) return -1;
+    if (hipEventRecord(ev[at], stream_) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return at;
+}
+
+template <typename Real>
+int Engine<Real>::end_part_timing(int part, int token) {
+    if (token < 0) return WV_OK;
+    WV_HIP(hipEventRecord(part_events_[part][token + 1], stream_));
+    part_ev_used_[part] = token + 2;
     return WV_OK;
 }
 
@@ -148,7 +188,13 @@ int Engine<Real>::collect_batch(uint64_t batch) {
         WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real), hipMemcpyDeviceToHost,
                               stream_));
     }
-    WV_HIP(hipStreamSynchronize(stream_));
+    if (comm_ && !comm_->is_local()) {
+        // (a peer that died leaves this wait on the device for good: give up after wv_options::comm_timeout_s and say who waited)
+        if (!comm_->sync(stream_, "the batch of steps " + std::to_string(steps_done) + " .. " + std::to_string(steps_done + batch - 1), &cerr))
+            return fail(WV_E_COMM, cerr);
+    } else {
+        WV_HIP(hipStreamSynchronize(stream_));
+    }
     // in-process chain: the last step's face pushes run on the halo streams; wv_run_group collects every slab, so that on
     // its return no copy into anybody's ghost plane is still in flight (a read-back or a wv_destroy may follow)
     if (comm_ && comm_->is_local()) WV_HIP(hipStreamSynchronize(comm_stream_));
@@ -217,21 +263,19 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             int singles_first = -1;
             if (eligible) {
                 int ready = 0, mine = 0;
-                rc = batch_pair_prepare(&ready, &mine);
-                if (rc && chain) {
-                    // Whatever went wrong here (an allocation beside the spare fields, mostly) the other ranks are about to
-                    // enter the all-reduce below: a rank that returned now would leave them there for good.  The chain stays
-                    // with single steps instead -- which need nothing that was not there before -- and this rank does not ask
-                    // again (wv_last_error keeps what happened).
-                    pair_failed_ = true;
-                    ready = mine = 0;
-                    (void)hipGetLastError();
-                    rc = WV_OK;
-                }
-                if (rc) return rc;
-                if (chain) {  // min of (2 - singles) = the most single sweeps any rank needs first
-                    uint64_t words[2] = {(uint64_t)ready, (uint64_t)(2 - mine)};
-                    if (!comm_->agree_min(stream_, words, 2, &cerr)) return fail(WV_E_COMM, cerr);
+                // (no memory for four fields / the map / the lists is not an error: *ready = 0 and the chain stays with single steps)
+                const int prepared = batch_pair_prepare(&ready, &mine);
+                if (prepared && !chain) return prepared;
+                if (chain) {
+                    // A rank that FAILED here (a device fault, not a lack of memory) must not simply return: the others are about
+                    // to enter this all-reduce and would wait there for good.  It goes in with them and says so (third word);
+                    // every rank then returns an error from the same point, none of them left inside an exchange.
+                    // min of (2 - singles) = the most single sweeps any rank needs first
+                    uint64_t words[3] = {(uint64_t)(prepared ? 0 : ready), (uint64_t)(prepared ? 2 : 2 - mine), prepared ? 0ull : 1ull};
+                    if (!comm_->agree_min(stream_, words, 3, &cerr)) return fail(WV_E_COMM, cerr);
+                    if (prepared) return prepared;  // (wv_last_error still says what happened here)
+                    if (words[2] == 0)
+                        return fail(WV_E_COMM, "another rank of the chain failed while preparing two-step passes (its wv_last_error says why)");
                     ready = (int)words[0];
                     mine = 2 - (int)words[1];
                 }
@@ -275,6 +319,10 @@ int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* ste
     halo_wait_ms_ = 0;
     halo_wait_n_ = 0;
     halo_timing_calls_ = 0;
+    for (int p = 0; p < 2; ++p) {
+        part_ms_[p] = 0;
+        part_n_[p] = 0;
+    }
     return WV_OK;
 }
 
@@ -305,9 +353,12 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_SWEEP_LIVE_PERMILLE: *value = tile_list_ ? (uint64_t)(tile_active_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
         case WV_QUERY_HALO_WAIT_NS: *value = (uint64_t)(halo_wait_ms_ * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_HALO_WAITS: *value = halo_wait_n_; return WV_OK;
-        case WV_QUERY_HALO_EXCHANGES: *value = halo_exchanges_; return WV_OK;
+        case WV_QUERY_HALO_EXCHANGES: *value = comm_ ? comm_->exchanges() : 0; return WV_OK;
         case WV_QUERY_HALO_BYTES_SENT: *value = comm_ ? comm_->planes_sent() * (uint64_t)comm_->plane_bytes() : 0; return WV_OK;
         case WV_QUERY_EARLY_PASSES: *value = early_passes_; return WV_OK;
+        case WV_QUERY_BOUNDARY1_NS: *value = (uint64_t)(part_ms_[0] * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_BOUNDARY2_NS: *value = (uint64_t)(part_ms_[1] * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_BOUNDARY_TIMED: *value = std::min(part_n_[0], part_n_[1]); return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

@@ -560,7 +560,6 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
         if ((rc = launch_faces(A, B, flag1, O1, early ? 2 : 1))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
-        ++halo_exchanges_;
     }
     wv::PairArgs<Real> a{};
     a.prev = A;
@@ -614,6 +613,7 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
         ev_used_ += 2;
         timed_steps_ += 2;
     }
+    pass_timed_ = timed;
     if (comm_ && !comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     // boundary nodes, t+1: own old value from t-1, neighbours from t, result into the t+1 field
     pair_mid_done_ = pair_list_done_ = false;
@@ -640,10 +640,15 @@ int Engine<Real>::enqueue_pair_a(int slot, uint64_t signal_pos, bool source_live
             nx.pitch = pitch_;
             pair_list_done_ = true;
         }
+        const int token = begin_part_timing(0);
         if ((rc = launch_boundary(A, B, flag1, pair_z0_, pair_z1_, &nx, O1, false, true))) return rc;
+        if ((rc = end_part_timing(0, token))) return rc;
         pair_mid_done_ = true;
-    } else if ((rc = launch_boundary(A, B, flag1, early ? pair_s0_ : pair_z0_, early ? pair_s1_ : pair_z1_, nullptr, O1, false, true))) {
-        return rc;  // (early: the planes next to the faces have been to t+1 already)
+    } else {
+        const int token = begin_part_timing(0);
+        // (early: the planes next to the faces have been to t+1 already)
+        if ((rc = launch_boundary(A, B, flag1, early ? pair_s0_ : pair_z0_, early ? pair_s1_ : pair_z1_, nullptr, O1, false, true))) return rc;
+        if ((rc = end_part_timing(0, token))) return rc;
     }
     WV_HIP(hipGetLastError());
     return WV_OK;
@@ -679,6 +684,14 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     std::string cerr;
     const bool io_mid = !pair_mid_done_ && (n_recv_ || source_live);  // step t+1: source sample into t+1, receivers from it
     if (comm_ && pair_early_) {
+        // compute stream: only a slab with a source or receivers looks at the t+1 ghosts (a receiver's neighbours may lie there).
+        // Asked for BEFORE exchange #2 is enqueued: the wait then stands for exchange #1 alone ("ghosts ready" / this slab's
+        // latest push are re-recorded behind every exchange), not for the t+2 faces this step's source / receiver work has no use for.
+        if (io_mid) {
+            const int token = begin_halo_wait_timing();
+            if (!comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
+            if ((rc = end_halo_wait_timing(token))) return rc;
+        }
         // halo stream, behind exchange #1: ghost planes of t+1 in place -> the face planes to t+2, one more plain step of theirs
         // from t+1 at the ghost plane, the face and the plane next to it (all final since part A) -> exchange #2
         if (!comm_->wait_ghosts(comm_stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
@@ -688,9 +701,6 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
         if (rc) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[1], &cerr, true)) return fail(WV_E_COMM, cerr);
-        ++halo_exchanges_;
-        // compute stream: only a slab with a source or receivers looks at the t+1 ghosts (a receiver's neighbours may lie there)
-        if (io_mid && !comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
     } else if (comm_) {
         const int token = begin_halo_wait_timing();
         if (!comm_->wait_ghosts(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);  // ghost planes of t+1
@@ -706,11 +716,11 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
         if ((rc = launch_faces(B, O1, flag2, O2))) return rc;
         WV_HIP(hipGetLastError());
         if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
-        ++halo_exchanges_;
     }
     // t+2 of the nodes next to a boundary node / the source, from the complete t+1; then the boundary nodes
     // (most of them are faced by a boundary node and finished by its entry in the launch after this one)
     if (!pair_list_done_ && (rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+    const int part_token = begin_part_timing(1);
     if (fuse_next && n_entries_ && io_nodes_unfaced()) {
         // what follows reads its source / receiver nodes from the t+2 field: none of them is written by
         // this launch (no boundary node, no node an entry finishes)
@@ -721,6 +731,8 @@ int Engine<Real>::enqueue_pair_b(int slot, uint64_t signal_pos, bool source_live
     } else if ((rc = launch_boundary(B, O1, flag2, pair_z0_, pair_z1_, nullptr, O2, pair_inner_ok_ > 0, true))) {
         return rc;
     }
+    if ((rc = end_part_timing(1, part_token))) return rc;
+    pass_timed_ = false;
     WV_HIP(hipGetLastError());
     if (comm_ && !comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
     ++passes_taken_;
@@ -777,6 +789,13 @@ int Engine<Real>::batch_pair_prepare(int* ready, int* singles_first) {
     *ready = 0;
     *singles_first = 0;
     const int rc = ensure_pair();
+    if (rc == WV_E_HIP && wv::last_hip_error() == hipErrorOutOfMemory) {
+        // no room for the map / the lists / the walls' compact copies either: single steps need none of them (the spare fields go
+        // back with the veto that follows a batch without passes)
+        (void)hipGetLastError();
+        pair_failed_ = true;
+        return WV_OK;
+    }
     if (rc) return rc;
     if (!pair_failed_ && (opt_.tuning.pair > 0 || pair_sparse_ok_)) {
         *ready = 1;

@@ -527,6 +527,12 @@ int Engine<Real>::build_tile_lists(int z0, int z1) {
 template <typename Real>
 void Engine<Real>::release() {
     DeviceGuard guard(device_);
+    if (comm_ && comm_->dead()) {
+        // the watchdog gave up on this rank's peers: its streams may never drain, and hipStreamSynchronize / hipFree would wait for
+        // them.  Everything is left to the end of the process, which is what a caller does after WV_E_COMM.
+        comm_.release();
+        return;
+    }
     comm_.reset();
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& e : events_) (void)hipEventDestroy(e);
@@ -534,6 +540,11 @@ void Engine<Real>::release() {
     for (auto& e : halo_events_)
         if (e) (void)hipEventDestroy(e);
     halo_events_.clear();
+    for (auto& ev : part_events_) {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        ev.clear();
+    }
     for (int i = 0; i < 4; ++i)
         if (field_[i]) (void)hipFree(field_[i]);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);

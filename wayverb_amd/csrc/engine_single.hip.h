@@ -261,7 +261,11 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
     int rc;
     std::string cerr;
     // ghost planes of `cur` come from the exchange issued at the end of the previous step
-    if (comm_ && !comm_->wait_ghosts(stream_, cur_, &cerr)) return fail(WV_E_COMM, cerr);
+    if (comm_) {
+        const int token = begin_halo_wait_timing();
+        if (!comm_->wait_ghosts(stream_, cur_, &cerr)) return fail(WV_E_COMM, cerr);
+        if ((rc = end_halo_wait_timing(token))) return rc;
+    }
     // (the flag words of a batch are reset when it is planned: a slab without source or receivers has nothing to do here)
     if (!pre_post_done_ && !(batch_flags_reset_ && !n_recv_ && !(with_pre_post && source_live))) {
         const wv::PrePostArgs<Real> pp = pre_post_args(cur, slot, with_pre_post, signal_pos, source_live);

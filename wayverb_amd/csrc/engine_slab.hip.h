@@ -15,6 +15,7 @@ int Engine<Real>::comm_init(const void* id, int rank, int nranks) {
     std::string err;
     if (!c->init(id, rank, nranks, device_, comm_stream_, opt_.ghost_lo != 0, opt_.ghost_hi != 0, &err))
         return fail(WV_E_COMM, err);
+    c->set_timeout(opt_.comm_timeout_s == 0 ? 180.0 : (double)opt_.comm_timeout_s);
     return adopt_comm(std::move(c));
 }
 
@@ -40,6 +41,7 @@ int Engine<Real>::adopt_comm(std::unique_ptr<wv::SlabComm> c) {
 template <typename Real>
 int Engine<Real>::comm_destroy() {
     DeviceGuard guard(device_);
+    if (comm_ && comm_->dead()) return fail(WV_E_COMM, "the communicator was aborted after a time-out: the engine is good for wv_destroy only");
     comm_.reset();
     return WV_OK;
 }

@@ -58,7 +58,7 @@ class WvTuning(C.Structure):
 class WvOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
-                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("reserved_", C.c_int32 * 7),
+                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("comm_timeout_s", C.c_int32), ("reserved_", C.c_int32 * 6),
                 ("tuning", WvTuning)]
 
 
@@ -300,7 +300,7 @@ class Engine:
     """One `run` worth of device state: the buffers of waveguide.h:43-76."""
 
     def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
-                 flag_interval=0, stream_variant=2, all_tiles=False, tuning=None):
+                 flag_interval=0, stream_variant=2, all_tiles=False, tuning=None, comm_timeout_s=0):
         self.lib = load_library()
         self.mesh = mesh
         self.precision = precision
@@ -323,6 +323,7 @@ class Engine:
         opt.flag_interval = flag_interval
         opt.stream_variant = stream_variant
         opt.all_tiles = 1 if all_tiles else 0
+        opt.comm_timeout_s = int(comm_timeout_s)   # RCCL chains: seconds before a rank gives up on its peers (0: 180 s, < 0: never)
         apply_tuning(opt, tuning)
         handle = C.c_void_p()
         _check(self.lib.wv_create(C.byref(wm), C.byref(opt), C.byref(handle)))
@@ -477,6 +478,7 @@ class Engine:
 
     QUERY_PASSES, QUERY_XWALL_ENTRIES, QUERY_FIELDS, QUERY_MARCH_LIVE_PERMILLE, QUERY_SWEEP_LIVE_PERMILLE, QUERY_MARCH_ROUNDS = 0, 1, 2, 3, 4, 5
     QUERY_HALO_WAIT_NS, QUERY_HALO_WAITS, QUERY_HALO_EXCHANGES, QUERY_HALO_BYTES_SENT, QUERY_EARLY_PASSES = 6, 7, 8, 9, 10
+    QUERY_BOUNDARY1_NS, QUERY_BOUNDARY2_NS, QUERY_BOUNDARY_TIMED = 11, 12, 13
 
     def query(self, what):
         """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
