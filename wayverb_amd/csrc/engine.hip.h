@@ -267,7 +267,7 @@ private:
     Real* recv_out_ = nullptr;
     uint32_t n_recv_ = 0;
     uint64_t recv_first_step_ = 0;
-    std::vector<Real> recv_stage_;
+    Real* recv_stage_ = nullptr;  // pinned, kRing rows: a copy into pageable memory would make hipMemcpyAsync wait for the stream on the host
     std::vector<double> recv_log_;
     std::unique_ptr<wv::SlabComm> comm_;
     // wv_checkpoint / wv_rollback (engine_io.hip.h): device copies of the two live fields and the filter memories, and the

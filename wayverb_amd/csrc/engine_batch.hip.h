@@ -184,9 +184,7 @@ int Engine<Real>::collect_batch(uint64_t batch) {
     if (comm_ && !comm_->or_flags(stream_, flags_, (int)batch, &cerr)) return fail(WV_E_COMM, cerr);
     WV_HIP(hipMemcpyAsync(flags_host_, flags_, batch * sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (n_recv_) {
-        recv_stage_.resize((size_t)batch * n_recv_);
-        WV_HIP(hipMemcpyAsync(recv_stage_.data(), recv_out_, recv_stage_.size() * sizeof(Real), hipMemcpyDeviceToHost,
-                              stream_));
+        WV_HIP(hipMemcpyAsync(recv_stage_, recv_out_, (size_t)batch * n_recv_ * sizeof(Real), hipMemcpyDeviceToHost, stream_));
     }
     if (comm_ && !comm_->is_local()) {
         // (a peer that died leaves this wait on the device for good: give up after wv_options::comm_timeout_s and say who waited)

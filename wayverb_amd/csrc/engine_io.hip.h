@@ -51,16 +51,20 @@ int Engine<Real>::set_receivers(const uint64_t* nodes, uint32_t n) {
         if (nodes[i] != ~0ull && nodes[i] >= n_nodes_)
             return fail(WV_E_INVALID_ARGUMENT, "receiver node outside the mesh");
     ScopedDevice new_nodes, new_out;
+    Real* new_stage = nullptr;
     if (n) {
         std::vector<uint64_t> stored(n);
         for (uint32_t i = 0; i < n; ++i) stored[i] = nodes[i] == ~0ull ? ~0ull : stored_index(nodes[i]);
         WV_HIP(hipMalloc(&new_nodes.p, n * sizeof(uint64_t)));
         WV_HIP(hipMemcpy(new_nodes.p, stored.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
         WV_HIP(hipMalloc(&new_out.p, (size_t)kRing * n * sizeof(Real)));
+        WV_HIP(hipHostMalloc((void**)&new_stage, (size_t)kRing * n * sizeof(Real), hipHostMallocDefault));
     }
     WV_HIP(hipStreamSynchronize(stream_));  // nothing in flight reads the old buffers
     if (recv_nodes_) (void)hipFree(recv_nodes_);
     if (recv_out_) (void)hipFree(recv_out_);
+    if (recv_stage_) (void)hipHostFree(recv_stage_);
+    recv_stage_ = new_stage;
     recv_nodes_ = static_cast<uint64_t*>(new_nodes.p);
     recv_out_ = static_cast<Real*>(new_out.p);
     new_nodes.p = new_out.p = nullptr;

@@ -556,6 +556,7 @@ void Engine<Real>::release() {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (flags_host_) (void)hipHostFree(flags_host_);
+    if (recv_stage_) (void)hipHostFree(recv_stage_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }
