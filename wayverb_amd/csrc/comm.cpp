@@ -269,6 +269,7 @@ SlabComm::~SlabComm() {
                          pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
+    if (host_words_) (void)hipHostFree(host_words_);
     // a local chain is torn down as a whole (wv_comm_destroy on every engine); unlink anyway
     if (lo_ && lo_->hi_ == this) lo_->hi_ = nullptr;
     if (hi_ && hi_->lo_ == this) hi_->lo_ = nullptr;
@@ -453,8 +454,13 @@ bool SlabComm::agree_min(hipStream_t stream, uint64_t* words, int n, std::string
     if (!spread_ && !hip_ok(hipMalloc((void**)&spread_, kMaxFlags * sizeof(uint64_t)), "hipMalloc", err)) return false;
     for (hipEvent_t* e : {&reduce_in_, &reduce_out_})
         if (!*e && !hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    if (!host_words_ && !hip_ok(hipHostMalloc((void**)&host_words_, kMaxFlags * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc", err))
+        return false;
     // (`spread_` is also or_flags' scratch: both are issued from the engine's one host thread, in stream order)
-    if (!hip_ok(hipMemcpyAsync(spread_, words, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "hipMemcpyAsync", err))
+    // (through pinned memory: a device-to-host copy into pageable memory makes hipMemcpyAsync itself wait for the stream -- with a
+    // peer that never enters the all-reduce that is for ever, and the time-out in sync() below would never be reached)
+    std::memcpy(host_words_, words, (size_t)n * sizeof(uint64_t));
+    if (!hip_ok(hipMemcpyAsync(spread_, host_words_, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "hipMemcpyAsync", err))
         return false;
     if (!hip_ok(hipEventRecord(reduce_in_, stream), "hipEventRecord", err)) return false;
     if (!hip_ok(hipStreamWaitEvent(stream_, reduce_in_, 0), "hipStreamWaitEvent", err)) return false;
@@ -462,9 +468,11 @@ bool SlabComm::agree_min(hipStream_t stream, uint64_t* words, int n, std::string
         return false;
     if (!hip_ok(hipEventRecord(reduce_out_, stream_), "hipEventRecord", err)) return false;
     if (!hip_ok(hipStreamWaitEvent(stream, reduce_out_, 0), "hipStreamWaitEvent", err)) return false;
-    if (!hip_ok(hipMemcpyAsync(words, spread_, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync", err))
+    if (!hip_ok(hipMemcpyAsync(host_words_, spread_, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync", err))
         return false;
-    return sync(stream, "the ranks' agreement on the next batch of steps (an all-reduce every rank must enter)", err);
+    if (!sync(stream, "the ranks' agreement on the next batch of steps (an all-reduce every rank must enter)", err)) return false;
+    std::memcpy(words, host_words_, (size_t)n * sizeof(uint64_t));
+    return true;
 }
 
 bool SlabComm::sync(hipStream_t stream, const std::string& what, std::string* err) {

@@ -138,6 +138,7 @@ private:
     uint64_t steps_done_ = 0;
     // flag OR
     uint64_t* spread_ = nullptr;
+    uint64_t* host_words_ = nullptr;  // pinned: agree_min's way in and out (a pageable copy would wait for the stream on the host)
 };
 
 }  // namespace wv
