@@ -143,13 +143,22 @@ typedef struct wv_options {
      * its peers -- WV_E_COMM, wv_last_error naming the rank, its neighbours and the stream that had not drained; the communicator
      * is aborted and the engine is good for wv_destroy only.  0 = 180 s, < 0 = wait for ever (plain hipStreamSynchronize). */
     int32_t comm_timeout_s;
-    int32_t reserved_[6];
+    /* z-slabs, one rank per process (wv_comm_init): how the face planes reach the neighbouring ranks.
+     *   WV_TRANSPORT_RCCL (default)  grouped ncclSend / ncclRecv on the halo stream;
+     *   WV_TRANSPORT_IPC             copies into the neighbours' own fields, mapped with hipIpcOpenMemHandle (the handles travel
+     *                                through the communicator at wv_comm_init; a copy engine moves the planes, no send / receive
+     *                                kernel has to find CUs beside the march); the ranks' agreements and the flag OR stay on RCCL.
+     *                                All ranks of a chain choose the same.  The engine then holds its four fields from wv_comm_init on. */
+    int32_t transport;
+    int32_t reserved_[5];
     /* HOW the engine does its work -- never what it computes: every setting gives bit-identical results
      * (tests/test_gpu_parity.py, test_gpu_pair.py run the golden cases under each).  wv_default_options
      * fills in the product's choices; the fields exist for measurement and for the tests.  The library
      * reads no environment variables (built with -DWV_DEBUG_ENV, WV_<FIELD> overrides a field: tools only). */
     wv_tuning tuning;
 } wv_options;
+
+enum { WV_TRANSPORT_RCCL = 0, WV_TRANSPORT_IPC = 1 };
 
 typedef struct wv_engine wv_engine;
 

@@ -28,7 +28,7 @@ def global_mesh(dims, room, rng):
 
 
 def main():
-    short_signal, library, source_plane = None, None, None
+    short_signal, library, source_plane, transport = None, None, None, "rccl"
     for a in [a for a in sys.argv if a.startswith("--")]:
         key, value = a[2:].split("=", 1)
         if key == "pair":             # stepping mode of every engine (wv_tuning::pair)
@@ -37,6 +37,8 @@ def main():
             short_signal = int(value)
         elif key == "rccl-library":   # wv_comm_use_library instead of LD_LIBRARY_PATH
             library = value
+        elif key == "transport":      # rccl (default) or ipc (wv_options::transport)
+            transport = value
         elif key == "source-plane":   # global plane of the source (default: the top owned plane of slab 0, a slab face)
             source_plane = int(value)
         elif key == "tuning":         # other wv_tuning fields, k=v,k=v
@@ -92,7 +94,7 @@ def main():
 
     for r in range(world):                      # engines one after the other; the collective part in threads
         L = SlabLayout(dims, r, world)
-        e = E.Engine(slab_mesh(gmesh, L), precision=precision, ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi)
+        e = E.Engine(slab_mesh(gmesh, L), precision=precision, ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi, transport=transport, comm_timeout_s=60)
         e.write_field(gprev[L.zl0 * plane:L.zl1 * plane], E.BUF_PREVIOUS)
         e.write_field(gcur[L.zl0 * plane:L.zl1 * plane], E.BUF_CURRENT)
         src_local, mine = place_source_and_receivers(L, source, receivers)

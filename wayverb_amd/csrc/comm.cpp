@@ -2,6 +2,7 @@
 #include "comm.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstring>
@@ -124,6 +125,43 @@ __global__ void flag_spread_kernel(const int* flags, uint64_t* out, int n) {
         if ((flags[i] >> b) & 1) v |= 1ull << (kFlagField * b);
     out[i] = v;
 }
+
+// ---- IPC transport: counters in the neighbours' mailboxes ---------------------------------------------------------------------
+// (one thread each; on the stream behind the copies whose landing they announce / in front of the work that needs the planes)
+struct IpcFlags {
+    uint64_t* flag[2];
+    uint64_t value[2];
+    int n;
+};
+__global__ void ipc_post_kernel(IpcFlags f) {
+    __threadfence_system();  // the copies before this kernel in stream order are visible to whoever sees the counter
+    for (int i = 0; i < f.n; ++i) __hip_atomic_store(f.flag[i], f.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Waits until every counter has reached its value; gives up after `ticks` of the 100 MHz wall clock and says so in *status
+// (bit `code`): the batch then ends with WV_E_COMM instead of a stream that never drains.
+__global__ void ipc_wait_kernel(IpcFlags f, long long ticks, int* status, int code) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < f.n; ++i) {
+        while (__hip_atomic_load(f.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < f.value[i]) {
+            if (ticks > 0 && wall_clock64() - t0 > ticks) {
+                __hip_atomic_fetch_or(status, code << (4 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
+// what a rank tells its neighbours about itself at set-up (travels through the communicator as bytes)
+struct IpcBlob {
+    int64_t pid;
+    uint64_t raw_field[4], raw_mailbox;  // addresses in the owner's process: used as they are by a neighbour in the SAME process
+    hipIpcMemHandle_t field[4], mailbox;
+    int32_t has_field[4];
+    int32_t nz;
+    uint32_t device_uuid_lo;
+    uint64_t plane_bytes;
+};
 
 __global__ void flag_gather_kernel(const uint64_t* in, int* flags, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +298,12 @@ SlabComm::~SlabComm() {
             if (peer->device_ != before) (void)hipSetDevice(before);
         }
     if (comm_) (void)rccl().comm_destroy(comm_);
+    for (int side = 0; side < 2; ++side)
+        for (void* p : peer_opened_[side])
+            if (p) (void)hipIpcCloseMemHandle(p);
+    if (mailbox_) (void)hipFree(mailbox_);
+    if (ipc_status_) (void)hipHostFree(ipc_status_);
+    if (own_push_) (void)hipEventDestroy(own_push_);
     if (local_) {
         std::lock_guard<std::mutex> lock(g_turn_mutex);
         DeviceTurn& t = g_turn[device_];
@@ -301,11 +345,154 @@ bool SlabComm::wait_ghosts(hipStream_t compute, int field, std::string* err) {
         if (last_own_push_ && !hip_ok(hipStreamWaitEvent(compute, last_own_push_, 0), "hipStreamWaitEvent", err)) return false;
         return true;
     }
+    if (ipc_) {
+        // the neighbours' planes of THIS buffer: each neighbour takes the same steps as this rank, so its latest exchange of the
+        // buffer has the number of this rank's own latest one
+        if (field < 0 || field >= 4) {
+            *err = "wait_ghosts: no such field buffer";
+            return false;
+        }
+        if (pushes_[field]) {
+            const uint64_t* flags[2];
+            uint64_t values[2];
+            int n = 0;
+            for (int side = 0; side < 2; ++side)
+                if (side == 0 ? has_lo_ : has_hi_) {
+                    flags[n] = mailbox_ + side * 4 + field;
+                    values[n++] = pushes_[field];
+                }
+            if (n && !ipc_wait(compute, n, flags, values, 1, err)) return false;
+        }
+        // ... and this rank's own copies have read its face planes (see the local transport above)
+        if (own_push_set_ && compute != stream_ && !hip_ok(hipStreamWaitEvent(compute, own_push_, 0), "hipStreamWaitEvent", err)) return false;
+        return true;
+    }
     if (!pending_) return true;
     return hip_ok(hipStreamWaitEvent(compute, ghosts_ready_, 0), "hipStreamWaitEvent", err);
 }
 
+bool SlabComm::ipc_wait(hipStream_t stream, int n, const uint64_t* const* flags, const uint64_t* values, int code, std::string* err) {
+    IpcFlags f{};
+    f.n = n;
+    for (int i = 0; i < n; ++i) {
+        f.flag[i] = const_cast<uint64_t*>(flags[i]);
+        f.value[i] = values[i];
+    }
+    const long long ticks = timeout_s_ > 0 ? (long long)(timeout_s_ * 1e8) : 0;
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(1), 0, stream, f, ticks, ipc_status_, code);
+    return hip_ok(hipGetLastError(), "ipc_wait_kernel", err);
+}
+
+bool SlabComm::ipc_post(hipStream_t stream, int n, uint64_t* const* flags, const uint64_t* values, std::string* err) {
+    IpcFlags f{};
+    f.n = n;
+    for (int i = 0; i < n; ++i) {
+        f.flag[i] = flags[i];
+        f.value[i] = values[i];
+    }
+    hipLaunchKernelGGL(ipc_post_kernel, dim3(1), dim3(1), 0, stream, f);
+    return hip_ok(hipGetLastError(), "ipc_post_kernel", err);
+}
+
+// Handles of this rank's fields and mailbox to its neighbours, theirs back, through the communicator (grouped send / receive of
+// bytes, like the planes of the RCCL transport); then the neighbours' memory is mapped (hipIpcOpenMemHandle) -- or taken as it
+// is where the neighbour lives in this very process (ranks as threads: the tests' stand-in; a rank that is its own neighbour).
+bool SlabComm::init_ipc(std::string* err) {
+    if (local_ || !comm_) {
+        *err = "the IPC transport rides on an RCCL communicator (wv_comm_init), not on the in-process one";
+        return false;
+    }
+    Rccl& r = rccl();
+    // the mailbox: uncached, so that a counter written from another process / GPU is what the next load sees
+    if (hipExtMallocWithFlags((void**)&mailbox_, kMailboxWords * sizeof(uint64_t), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (!hip_ok(hipExtMallocWithFlags((void**)&mailbox_, kMailboxWords * sizeof(uint64_t), hipDeviceMallocFinegrained),
+                    "hipExtMallocWithFlags (mailbox)", err))
+            return false;
+    }
+    if (!hip_ok(hipMemset(mailbox_, 0, kMailboxWords * sizeof(uint64_t)), "hipMemset", err)) return false;
+    if (!hip_ok(hipHostMalloc((void**)&ipc_status_, sizeof(int), hipHostMallocDefault), "hipHostMalloc", err)) return false;
+    *ipc_status_ = 0;
+    if (!hip_ok(hipEventCreateWithFlags(&own_push_, hipEventDisableTiming), "hipEventCreate", err)) return false;
+    IpcBlob mine{};
+    mine.pid = (int64_t)getpid();
+    mine.raw_mailbox = (uint64_t)(uintptr_t)mailbox_;
+    mine.nz = nz_;
+    mine.plane_bytes = plane_bytes_;
+    bool need_handles = !loopback_;
+    for (int i = 0; i < 4; ++i) {
+        mine.has_field[i] = i < n_fields_ && fields_[i] != nullptr;
+        mine.raw_field[i] = (uint64_t)(uintptr_t)fields_[i];
+        if (mine.has_field[i] && need_handles && !hip_ok(hipIpcGetMemHandle(&mine.field[i], fields_[i]), "hipIpcGetMemHandle (field)", err))
+            return false;
+    }
+    if (need_handles && !hip_ok(hipIpcGetMemHandle(&mine.mailbox, mailbox_), "hipIpcGetMemHandle (mailbox)", err)) return false;
+    IpcBlob theirs[2] = {};
+    if (loopback_) {
+        theirs[0] = theirs[1] = mine;
+    } else {
+        IpcBlob* dev = nullptr;  // [0] mine, [1] from rank - 1, [2] from rank + 1
+        if (!hip_ok(hipMalloc((void**)&dev, 3 * sizeof(IpcBlob)), "hipMalloc", err)) return false;
+        bool ok = hip_ok(hipMemcpy(dev, &mine, sizeof(IpcBlob), hipMemcpyHostToDevice), "hipMemcpy", err);
+        ok = ok && nccl_ok(r.group_start(), "ncclGroupStart", err);
+        if (ok && has_lo_)
+            ok = nccl_ok(r.send(dev, sizeof(IpcBlob), kNcclInt8, rank_ - 1, comm_, stream_), "ncclSend", err) &&
+                 nccl_ok(r.recv(dev + 1, sizeof(IpcBlob), kNcclInt8, rank_ - 1, comm_, stream_), "ncclRecv", err);
+        if (ok && has_hi_)
+            ok = nccl_ok(r.send(dev, sizeof(IpcBlob), kNcclInt8, rank_ + 1, comm_, stream_), "ncclSend", err) &&
+                 nccl_ok(r.recv(dev + 2, sizeof(IpcBlob), kNcclInt8, rank_ + 1, comm_, stream_), "ncclRecv", err);
+        ok = ok && nccl_ok(r.group_end(), "ncclGroupEnd", err);
+        ok = ok && sync(stream_, "the exchange of IPC handles with the neighbouring ranks", err);
+        ok = ok && hip_ok(hipMemcpy(theirs, dev + 1, 2 * sizeof(IpcBlob), hipMemcpyDeviceToHost), "hipMemcpy", err);
+        (void)hipFree(dev);
+        if (!ok) return false;
+    }
+    for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? has_lo_ : has_hi_)) continue;
+        const IpcBlob& b = theirs[side];
+        if (b.plane_bytes != plane_bytes_) {
+            *err = "neighbouring slabs disagree about the plane size";
+            return false;
+        }
+        peer_nz_[side] = b.nz;
+        const bool same_process = b.pid == mine.pid;
+        for (int i = 0; i < 4; ++i) {
+            if (!b.has_field[i]) continue;
+            if (same_process) {
+                peer_field_[side][i] = (char*)(uintptr_t)b.raw_field[i];
+            } else {
+                void* p = nullptr;
+                if (!hip_ok(hipIpcOpenMemHandle(&p, b.field[i], hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle (a neighbour's field)", err)) return false;
+                peer_opened_[side][i] = p;
+                peer_field_[side][i] = static_cast<char*>(p);
+            }
+        }
+        if (same_process) {
+            peer_mailbox_[side] = (uint64_t*)(uintptr_t)b.raw_mailbox;
+        } else {
+            void* p = nullptr;
+            if (!hip_ok(hipIpcOpenMemHandle(&p, b.mailbox, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle (a neighbour's mailbox)", err)) return false;
+            peer_opened_[side][4] = p;
+            peer_mailbox_[side] = static_cast<uint64_t*>(p);
+        }
+    }
+    ipc_ = true;
+    return true;
+}
+
 bool SlabComm::step_done(hipStream_t compute, std::string* err) {
+    if (ipc_) {  // tell the neighbours: their next copy into my ghost planes may come
+        ++steps_done_;
+        uint64_t* flags[2];
+        uint64_t values[2];
+        int n = 0;
+        for (int side = 0; side < 2; ++side)
+            if (side == 0 ? has_lo_ : has_hi_) {
+                flags[n] = peer_mailbox_[side] + 8 + (1 - side);  // (I am that neighbour's neighbour on its other side)
+                values[n++] = steps_done_;
+            }
+        return n == 0 || ipc_post(compute, n, flags, values, err);
+    }
     if (!local_) return true;  // RCCL: the matching ncclRecv is issued by this rank itself, in stream order
     const int which = (int)(steps_done_ & 1u);
     ++steps_done_;
@@ -405,6 +592,47 @@ bool SlabComm::exchange_faces(hipStream_t compute, int field, std::string* err, 
         }
         return true;
     }
+    if (ipc_) {
+        if (field >= 4 || (has_lo_ && !peer_field_[0][field]) || (has_hi_ && !peer_field_[1][field])) {
+            *err = "exchange_faces: a neighbour has not shared this field buffer (slabs of a chain must take the same steps)";
+            return false;
+        }
+        const uint64_t k = ++pushes_[field];
+        // the neighbours have finished the step (or pass) in which they read the ghost planes these copies overwrite
+        if (steps_done_ > 0) {
+            const uint64_t* flags[2];
+            uint64_t values[2];
+            int n = 0;
+            for (int side = 0; side < 2; ++side)
+                if (side == 0 ? has_lo_ : has_hi_) {
+                    flags[n] = mailbox_ + 8 + side;
+                    values[n++] = steps_done_;
+                }
+            if (n && !ipc_wait(stream_, n, flags, values, 2, err)) return false;
+        }
+        uint64_t* posts[2];
+        uint64_t values[2];
+        int n = 0;
+        if (has_lo_) {  // my first owned plane -> the lower neighbour's top ghost plane
+            char* dst = peer_field_[0][field] + (size_t)(peer_nz_[0] - 1) * plane_bytes;
+            if (!hip_ok(hipMemcpyAsync(dst, base + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync (plane to rank - 1)", err))
+                return false;
+            posts[n] = peer_mailbox_[0] + 1 * 4 + field;  // (I am its upper neighbour: side 1 over there)
+            values[n++] = k;
+        }
+        if (has_hi_) {  // my last owned plane -> the upper neighbour's bottom ghost plane
+            char* dst = peer_field_[1][field];
+            if (!hip_ok(hipMemcpyAsync(dst, base + (size_t)(nz - 2) * plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, stream_),
+                        "hipMemcpyAsync (plane to rank + 1)", err))
+                return false;
+            posts[n] = peer_mailbox_[1] + 0 * 4 + field;
+            values[n++] = k;
+        }
+        if (n && !ipc_post(stream_, n, posts, values, err)) return false;
+        if (!hip_ok(hipEventRecord(own_push_, stream_), "hipEventRecord", err)) return false;
+        own_push_set_ = true;
+        return true;
+    }
     Rccl& r = rccl();
     if (loopback_) {
         // sends and receives to the same peer pair up in issue order
@@ -487,7 +715,17 @@ bool SlabComm::sync(hipStream_t stream, const std::string& what, std::string* er
     int polls = 0;
     for (;;) {
         const hipError_t q = hipEventQuery(sync_ev_);
-        if (q == hipSuccess) return true;
+        if (q == hipSuccess) {
+            if (ipc_status_ && *ipc_status_) {
+                const int st = *ipc_status_;
+                *err = "rank " + std::to_string(rank_) + " of " + std::to_string(nranks_) + ": " + what + ": a wait for " +
+                       ((st & 0x11) ? "ghost planes from" : "the end of a step on") + " a neighbouring rank timed out on the device after " +
+                       std::to_string((int)timeout_s_) + " s (status " + std::to_string(st) + "): the fields are no longer meaningful";
+                dead_ = true;
+                return false;
+            }
+            return true;
+        }
         if (q != hipErrorNotReady) return hip_ok(q, "hipEventQuery", err);
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited > timeout_s_) break;

@@ -7,10 +7,16 @@
 // while the interior planes are still being updated on the compute stream.  Slab chain = nearest
 // neighbour only: at most 2 of a GPU's 7 xGMI links.
 //
-// Two transports behind the same calls (the engine's step is the same code for both):
+// Three transports behind the same calls (the engine's step is the same code for all):
 //   RCCL   one rank per process / GPU: grouped ncclSend/ncclRecv over xGMI.  RCCL is resolved at
 //          run time (dlopen) so that a process that already loaded a librccl (e.g. through
 //          torch.distributed) shares that copy.
+//   IPC    one rank per process / GPU like RCCL, and an RCCL communicator all the same (the ranks' agreements and the flag OR go
+//          through it, and so do the handles at set-up) -- but the PLANES travel by copies into the neighbour's own fields,
+//          mapped into this process with hipIpcOpenMemHandle: a copy engine moves them (hipMemcpyAsync; a peer copy between
+//          GPUs), not a send / receive kernel that has to find CUs beside a march that holds every register of the chip.
+//          Ordering between the ranks: counters in a small mailbox of uncached device memory per rank, written by the
+//          neighbours (one-thread kernels behind their copies), waited for by one-thread kernels with a time-out.
 //   local  all slabs of the chain are engines of THIS process (wv_comm_init_local): device-to-device
 //          copies into the neighbour's ghost plane, ordered with events.  The engines must then be
 //          stepped in lockstep from one host thread (wv_run_group), which is what makes every
@@ -40,6 +46,10 @@ public:
               bool has_lo, bool has_hi, std::string* err);
     bool init_local(int rank, int nranks, int device, hipStream_t comm_stream, bool has_lo, bool has_hi,
                     std::string* err);
+    // IPC transport: after init() and set_fields() (ALL the fields the engine will ever exchange: the handles travel once), a
+    // collective among neighbours -- handles of the fields and of the mailbox go to rank - 1 / rank + 1 through the communicator.
+    bool init_ipc(std::string* err);
+    bool is_ipc() const { return ipc_; }
     // local transport: the neighbouring slabs' communicators (null at the ends of the chain)
     // (slabs on different GPUs of this process: peer access is switched on where the devices offer it)
     void link_local(SlabComm* lo, SlabComm* hi);
@@ -136,6 +146,22 @@ private:
     hipEvent_t step_done_[2] = {nullptr, nullptr};
     hipEvent_t bulk_done_ = nullptr;
     uint64_t steps_done_ = 0;
+    // IPC transport.  Mailbox words (uint64, uncached device memory, written by the NEIGHBOURS): [side * 4 + field] = exchanges of
+    // field buffer `field` whose plane has landed in my ghost plane on that side (side 0: from rank - 1, 1: from rank + 1);
+    // [8 + side] = steps / passes that neighbour has finished (it no longer reads the ghost planes I am about to overwrite).
+    static constexpr int kMailboxWords = 16;
+    bool ipc_ = false;
+    bool ipc_wait(hipStream_t stream, int n, const uint64_t* const* flags, const uint64_t* values, int code, std::string* err);
+    bool ipc_post(hipStream_t stream, int n, uint64_t* const* flags, const uint64_t* values, std::string* err);
+    uint64_t* mailbox_ = nullptr;
+    uint64_t* peer_mailbox_[2] = {nullptr, nullptr};
+    char* peer_field_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    void* peer_opened_[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+    int peer_nz_[2] = {0, 0};
+    uint64_t pushes_[4] = {0, 0, 0, 0};
+    int* ipc_status_ = nullptr;  // pinned: set by a wait that timed out on the device (which side, which kind)
+    hipEvent_t own_push_ = nullptr;
+    bool own_push_set_ = false;
     // flag OR
     uint64_t* spread_ = nullptr;
     uint64_t* host_words_ = nullptr;  // pinned: agree_min's way in and out (a pageable copy would wait for the stream on the host)

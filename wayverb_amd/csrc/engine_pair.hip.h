@@ -811,6 +811,7 @@ int Engine<Real>::batch_pair_vetoed() {
     bool any = false;
     for (int i = 0; i < 2; ++i) any = any || field_[spare_[i]] != nullptr;
     if (!any) return WV_OK;
+    if (comm_ && comm_->is_ipc()) return WV_OK;  // (the neighbours have these fields mapped: they stay)
     WV_HIP(hipStreamSynchronize(stream_));
     WV_HIP(hipStreamSynchronize(comm_stream_));
     for (int i = 0; i < 2; ++i) {

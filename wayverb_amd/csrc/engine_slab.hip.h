@@ -16,6 +16,34 @@ int Engine<Real>::comm_init(const void* id, int rank, int nranks) {
     if (!c->init(id, rank, nranks, device_, comm_stream_, opt_.ghost_lo != 0, opt_.ghost_hi != 0, &err))
         return fail(WV_E_COMM, err);
     c->set_timeout(opt_.comm_timeout_s == 0 ? 180.0 : (double)opt_.comm_timeout_s);
+    if (opt_.transport == WV_TRANSPORT_IPC) {
+        // the neighbours map this rank's fields once, now: the two fields a two-step pass writes have to exist already
+        // (no room for them: this rank says "no" whenever the chain asks about passes, and it stays with single steps)
+        if (opt_.tuning.pair != 0 && !pair_failed_)
+            for (int i = 0; i < 2; ++i) {
+                Real*& f = field_[spare_[i]];
+                if (f) continue;
+                if (hipMalloc((void**)&f, field_bytes_ + 256) != hipSuccess) {
+                    (void)hipGetLastError();
+                    f = nullptr;
+                    pair_failed_ = true;
+                    break;
+                }
+                WV_HIP(hipMemsetAsync(f, 0, field_bytes_ + 256, stream_));
+            }
+        if (pair_failed_)
+            for (int i = 0; i < 2; ++i) {
+                Real*& f = field_[spare_[i]];
+                if (f) (void)hipFree(f);
+                f = nullptr;
+            }
+        WV_HIP(hipStreamSynchronize(stream_));
+        void* fields[4] = {field_[0], field_[1], field_[2], field_[3]};
+        c->set_fields(fields, 4, (size_t)pitch_ * ny_ * sizeof(Real), nz_);
+        if (!c->init_ipc(&err)) return fail(WV_E_COMM, err);
+        comm_ = std::move(c);
+        return WV_OK;
+    }
     return adopt_comm(std::move(c));
 }
 

@@ -58,7 +58,7 @@ class WvTuning(C.Structure):
 class WvOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32), ("flag_interval", C.c_int32),
-                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("comm_timeout_s", C.c_int32), ("reserved_", C.c_int32 * 6),
+                ("stream_variant", C.c_int32), ("all_tiles", C.c_int32), ("nodes_on_device", C.c_int32), ("comm_timeout_s", C.c_int32), ("transport", C.c_int32), ("reserved_", C.c_int32 * 5),
                 ("tuning", WvTuning)]
 
 
@@ -300,7 +300,7 @@ class Engine:
     """One `run` worth of device state: the buffers of waveguide.h:43-76."""
 
     def __init__(self, mesh, precision="f64", device=-1, ghost_lo=False, ghost_hi=False,
-                 flag_interval=0, stream_variant=2, all_tiles=False, tuning=None, comm_timeout_s=0):
+                 flag_interval=0, stream_variant=2, all_tiles=False, tuning=None, comm_timeout_s=0, transport="rccl"):
         self.lib = load_library()
         self.mesh = mesh
         self.precision = precision
@@ -323,6 +323,7 @@ class Engine:
         opt.flag_interval = flag_interval
         opt.stream_variant = stream_variant
         opt.all_tiles = 1 if all_tiles else 0
+        opt.transport = {"rccl": 0, "ipc": 1}[transport]   # wv_comm_init chains: how the face planes travel (WV_TRANSPORT_*)
         opt.comm_timeout_s = int(comm_timeout_s)   # RCCL chains: seconds before a rank gives up on its peers (0: 180 s, < 0: never)
         apply_tuning(opt, tuning)
         handle = C.c_void_p()
