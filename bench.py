@@ -70,6 +70,9 @@ def parse_args():
                                                 "(default: none -- the product's own choices)")
     p.add_argument("--no-reference-on-gpu", action="store_true",
                    help="skip running the reference's OpenCL kernel on this GPU (oracle/_ref/libwvref_cl.so)")
+    p.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
+                   help="N > 1: how the face planes reach the neighbouring ranks (wv_options::transport): grouped ncclSend / ncclRecv, or copies "
+                        "into the neighbours' IPC-mapped fields ordered by mailbox counters (RCCL then carries the agreements only)")
     p.add_argument("--comm-timeout", type=int, default=180,
                    help="N > 1: seconds a rank waits for a batch of steps before it gives up on its peers (wv_options::comm_timeout_s)")
     p.add_argument("--deadline", type=float, default=1500.0,
@@ -249,7 +252,7 @@ def run_bench(args, guard):
     guard.phase = "mesh and engine set-up"
     mesh = box_slab_mesh(nx, ny, nz_global, layout, coefficients=M.bench_materials())
     eng = E.Engine(mesh, precision=args.precision, device=local_rank,
-                   ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi, comm_timeout_s=args.comm_timeout)
+                   ghost_lo=layout.ghost_lo, ghost_hi=layout.ghost_hi, comm_timeout_s=args.comm_timeout, transport=args.transport)
     mesh.nodes = None  # host copy no longer needed
     if world > 1:
         idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device=coll_device)
@@ -411,7 +414,10 @@ def run_bench(args, guard):
         "config": {"workload": "%dx%dx%d box mesh, %s pressures, walls of 4 mixed materials (2 flat, 2 frequency-dependent order-6 IIR), hard-source impulse + 1 receiver"
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
                    "per_gpu": "%dx%dx%d z-slab" % (nx, ny, layout.z1 - layout.z0), "decomposition": "z-slabs x%d" % world,
-                   "halo": "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass, both under the march: the faces' second step runs on that stream between them)" if world > 1 else "none",
+                   "halo": ("none" if world == 1 else
+                            "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass, both under the march: the faces' second step runs on that stream between them)"
+                            if args.transport == "rccl" else
+                            "face planes copied into the neighbours' IPC-mapped fields on a second stream, ordered by mailbox counters (two exchanges per two-step pass, both under the march); RCCL for the ranks' agreements and the flag OR only"),
                    "halo_measured": halo,
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

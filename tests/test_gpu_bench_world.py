@@ -60,6 +60,9 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
     assert r["unit"] == "Gnode-updates/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f64"
     assert r["config"]["workload"].startswith("%dx%dx%d box mesh" % (nx, ny, nz_global))
     assert r["config"]["decomposition"] == "z-slabs x%d" % world and "RCCL" in r["config"]["halo"]
+    if world == 4:   # the same chain with the planes on the IPC transport (processes sharing the GPU map each other's fields)
+        r2 = run_bench(world, shm_mock, *(extra + ["--transport", "ipc"]))
+        assert "IPC-mapped" in r2["config"]["halo"] and r2["roofline"]["launches"] > 0 and r2["value"] > 0
     # value is the whole job: all nodes of all ranks x steps / (max-over-ranks) time
     assert r["value"] == pytest.approx(nx * ny * nz_global * steps / (r["ms_per_step"] * 1e-3 * steps) / 1e9, rel=1e-2)
     roof = r["roofline"]

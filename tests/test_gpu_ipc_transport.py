@@ -119,7 +119,7 @@ def test_a_rank_that_is_its_own_neighbour(built_library):
     bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1) for d in range(3)]
     results = {}
     for transport in ("rccl", "ipc"):
-        e = E.Engine(M.Mesh((n, n, nz), nodes, coeffs, *bidx), precision="f64", ghost_lo=True, ghost_hi=True, transport=transport)
+        e = E.Engine(M.Mesh((n, n, nz), nodes, coeffs, *bidx), precision="f64", ghost_lo=True, ghost_hi=True, transport=transport, tuning=dict(pair=1))
         try:
             e.comm_init(E.Engine.comm_unique_id(), 0, 1)
             sig = np.zeros(40)

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--ny", type=int, default=0, help="rows (default: --n); 992 rows are 248 strips: the march leaves one CU of every XCD free")
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--precision", default="f64")
+    ap.add_argument("--transport", default="rccl,ipc", help="comma list of rccl / ipc (wv_options::transport): the planes by ncclSend / ncclRecv "
+                                                            "kernels, or by copies ordered with mailbox counters (no kernel of RCCL's in the rank's timeline)")
     args = ap.parse_args()
     n, planes, ranks, steps = args.n, args.planes, args.ranks, args.steps
     ny = args.ny or n
@@ -68,12 +70,14 @@ def main():
     bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1) for d in range(3)]
     mesh = M.Mesh((n, ny, nz), nodes, coeffs, *bidx)
     src = (nz // 2) * n * ny + (ny // 2) * n + n // 2
-    for name, tuning in (("both exchanges under the march", dict(pair=1, slab_early=1)),
-                         ("... march in one round", dict(pair=1, slab_early=1, pair_chunks=1)),
-                         ("second exchange after the march (round 3)", dict(pair=1, slab_early=0)),
-                         ("... march in one round", dict(pair=1, slab_early=0, pair_chunks=1)),
-                         ("single steps", dict(pair=0))):
-        eng = E.Engine(mesh, precision=args.precision, ghost_lo=True, ghost_hi=True, tuning=tuning)
+    forms = (("both exchanges under the march", dict(pair=1, slab_early=1)),
+             ("... march in one round", dict(pair=1, slab_early=1, pair_chunks=1)),
+             ("second exchange after the march (round 3)", dict(pair=1, slab_early=0)),
+             ("... march in one round", dict(pair=1, slab_early=0, pair_chunks=1)),
+             ("single steps", dict(pair=0)))
+    for transport, (name, tuning) in [(t, f) for t in args.transport.split(",") for f in forms]:
+        name = "[%s] %s" % (transport, name)
+        eng = E.Engine(mesh, precision=args.precision, ghost_lo=True, ghost_hi=True, tuning=tuning, transport=transport)
         eng.comm_init(E.Engine.comm_unique_id(), 0, 1)
         eng.set_source(E.SOURCE_HARD, src, sig)
         eng.enable_kernel_timing(True)
@@ -83,7 +87,7 @@ def main():
         march_ms, launches, tsteps = eng.kernel_time_detail()
         early, passes, rounds = eng.query(E.Engine.QUERY_EARLY_PASSES), eng.query(E.Engine.QUERY_PASSES), eng.query(E.Engine.QUERY_MARCH_ROUNDS)
         eng.close()
-        print("  %-44s %.1f us/step -> at most %.2f x at %d ranks before the links; march %.1f us (%d round(s)), compute stream waits %.1f us "
+        print("  %-51s %.1f us/step -> at most %.2f x at %d ranks before the links; march %.1f us (%d round(s)), compute stream waits %.1f us "
               "for ghosts per timed wait; %d of %d passes with the faces' second step on the halo stream"
               % (name, t * 1e3, t_single / t, ranks, march_ms * 1e3, rounds, wait_us, early, passes))
 
