@@ -374,8 +374,9 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
 // (BoundaryArgs::fix_z0 / fix_z1).
 // (`block` of `blocks`: this workgroup's place among the boundary workgroups of the launch -- all of it for boundary_kernel, the
 // tail of the grid for plane_step_kernel.)
+// (boundary_entries: the entries' share of a workgroup, without whatever may ride behind them -- what resident_kernels.hip.h runs)
 template <typename Real, bool LDSC, bool FIX>
-__device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
+__device__ __forceinline__ void boundary_entries(const BoundaryArgs<Real>& a, uint32_t block) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
         for (uint32_t w = threadIdx.x; w < a.n_coeffs * 14u; w += 256) s_coeffs[w] = a.coeffs[w];
@@ -400,6 +401,11 @@ __device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const
         boundary_entry<Real, FIX>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
+}
+
+template <typename Real, bool LDSC, bool FIX>
+__device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
+    boundary_entries<Real, LDSC, FIX>(a, block);
     if (next.fused && block == blocks - 1) pre_post_body<Real>(next, threadIdx.x, 256);
 }
 
