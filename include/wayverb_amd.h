@@ -119,7 +119,8 @@ typedef struct wv_tuning {
     int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
     int32_t resident;         /* small meshes: batches of single steps in ONE launch of persistent workgroups whose units wait for the units
                                * around them only (resident_kernels.hip.h; the fields then live in uncached memory): -1 by mesh size, 1 / 0 force on / off */
-    int32_t reserved_[3];
+    int32_t resident_workgroups; /* measurement: workgroups of the resident form's launch (0 = as many as are resident at once, by occupancy) */
+    int32_t reserved_[2];
 } wv_tuning;
 
 typedef struct wv_options {

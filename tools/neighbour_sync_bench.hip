@@ -25,6 +25,7 @@
 
 // the same without agent-scope fences: for UNCACHED memory, whose stores go through to the memory side and whose loads do not
 // stop in a cache -- "my stores have been acknowledged" (s_waitcnt) is all the release there is, and relaxed atomics carry the counters
+template <int MODE>
 __global__ void __launch_bounds__(256) chain_nofence_kernel(double* buf, unsigned* counters, int iters, int n, unsigned* abort_flag) {
     const int w = blockIdx.x, G = gridDim.x;
     const int lo = (w + G - 1) % G, hi = (w + 1) % G;
@@ -41,12 +42,28 @@ __global__ void __launch_bounds__(256) chain_nofence_kernel(double* buf, unsigne
             }
         }
         __syncthreads();
+        if (MODE == 2) asm volatile("buffer_inv sc1" ::: "memory");
+        if (MODE == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const double* src = buf + (size_t)(it & 1) * G * n;
         double* dst = buf + (size_t)((it + 1) & 1) * G * n;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const double v = __builtin_nontemporal_load(src + (size_t)lo * n + i) + __builtin_nontemporal_load(src + (size_t)hi * n + i);
-            __builtin_nontemporal_store(v - 4096.0 * floor(v / 4096.0), dst + (size_t)w * n + i);
-        }
+        // all loads first, then all stores (the real units do the same): 16 or 64 values per lane
+        double v[64];
+        const int per = n / 256;
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            if (k < per) {
+                const int i = threadIdx.x + k * 256;
+                v[k] = MODE == 0 ? __builtin_nontemporal_load(src + (size_t)lo * n + i) + __builtin_nontemporal_load(src + (size_t)hi * n + i)
+                                 : src[(size_t)lo * n + i] + src[(size_t)hi * n + i];
+            }
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            if (k < per) {
+                const int i = threadIdx.x + k * 256;
+                const double o = v[k] - 4096.0 * floor(v[k] / 4096.0);
+                if (MODE == 0) __builtin_nontemporal_store(o, dst + (size_t)w * n + i);
+                else dst[(size_t)w * n + i] = o;
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(counters + 32 * w, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -84,14 +101,16 @@ __global__ void __launch_bounds__(256) chain_kernel(double* buf, unsigned* count
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
-    const char* kinds[5] = {"coarse-grained (hipMalloc)", "fine-grained", "uncached", "uncached, no fences", "coarse, no fences (WRONG?)"};
-    for (int kind = 0; kind < 5; ++kind) {
+    const char* kinds[8] = {"coarse-grained (hipMalloc)", "fine-grained", "uncached", "uncached, no fences, nt", "coarse, no fences (WRONG?)",
+                            "uncached, no fences, plain", "uncached, plain + buffer_inv sc1", "uncached, plain + acquire fence"};
+    for (int kind = 3; kind < 8; ++kind) {
         for (int G : {64, 128, 256}) {
             for (int n : {4096, 16384}) {
                 double* buf = nullptr;
                 unsigned *counters = nullptr, *abort_flag = nullptr;
                 const size_t bytes = (size_t)2 * G * n * sizeof(double);
                 if (kind == 0 || kind == 4) CK(hipMalloc((void**)&buf, bytes));
+                else if (kind >= 5) CK(hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocUncached));
                 else CK(hipExtMallocWithFlags((void**)&buf, bytes, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
                 if (kind >= 3) CK(hipExtMallocWithFlags((void**)&counters, 32 * G * sizeof(unsigned) + sizeof(unsigned), hipDeviceMallocUncached));
                 else CK(hipMalloc((void**)&counters, 32 * G * sizeof(unsigned) + sizeof(unsigned)));
@@ -108,7 +127,10 @@ int main(int argc, char** argv) {
                     CK(hipEventCreate(&e0));
                     CK(hipEventCreate(&e1));
                     CK(hipEventRecord(e0, 0));
-                    if (kind >= 3) hipLaunchKernelGGL(chain_nofence_kernel, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
+                    if (kind == 5) hipLaunchKernelGGL(chain_nofence_kernel<1>, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
+                    else if (kind == 6) hipLaunchKernelGGL(chain_nofence_kernel<2>, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
+                    else if (kind == 7) hipLaunchKernelGGL(chain_nofence_kernel<3>, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
+                    else if (kind >= 3) hipLaunchKernelGGL(chain_nofence_kernel<0>, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
                     else hipLaunchKernelGGL(chain_kernel, dim3(G), dim3(256), 0, 0, buf, counters, iters, n, abort_flag);
                     CK(hipEventRecord(e1, 0));
                     CK(hipEventSynchronize(e1));

@@ -291,8 +291,8 @@ private:
         int io_kind = 0;
         std::vector<uint64_t> io_recv;
     } res_;
-    bool fields_uncached_ = false, resident_failed_ = false;
-    uint64_t resident_max_nodes_ = 4ull << 20;  // stored nodes up to which the form is taken by default (above: two-step passes)
+    bool resident_failed_ = false;
+    uint64_t resident_max_bytes_ = 4ull << 20;  // both fields up to this size: the form is taken by default (one XCD's L2)
     uint64_t resident_steps_ = 0;
     // wv_checkpoint / wv_rollback (engine_io.hip.h): device copies of the two live fields and the filter memories, and the
     // host-side position that goes with them

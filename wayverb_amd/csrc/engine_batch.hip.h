@@ -254,7 +254,11 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
         // so that the two fields are back in their roles after every replay.
         const bool use_graph = opt_.tuning.graph != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
                                stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
-        const bool use_resident = !use_graph && resident_now(batch);
+        bool use_resident = !use_graph && resident_now(batch);
+        if (use_resident) {  // (tables, and whether the dispatcher deals workgroups as the form needs: once)
+            if ((rc = ensure_resident())) return rc;
+            use_resident = !resident_failed_;
+        }
         if (use_graph) {
             if ((rc = replay_batch(batch, batch_source_live_, batch_can_fuse_))) return rc;
         } else if (use_resident) {
@@ -301,8 +305,10 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
         if ((rc = collect_batch(batch))) return rc;
         if (use_resident) {
             int gave_up = 0;
+            uint32_t arrived = 0;
             WV_HIP(hipMemcpy(&gave_up, status_ + 2, sizeof(int), hipMemcpyDeviceToHost));
-            if (gave_up) {
+            WV_HIP(hipMemcpy(&arrived, res_.counter + std::max<size_t>(res_.n_units, 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (gave_up || arrived != res_.grid) {
                 resident_failed_ = true;
                 return fail(WV_E_HIP, "resident stepping: a unit's wait for the units around it ran into its bound (the fields are no longer meaningful)");
             }

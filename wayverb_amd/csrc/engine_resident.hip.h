@@ -8,18 +8,19 @@
 
 namespace wv {
 
-// May this engine step in the resident form at all?  (Decided once, at wv_create: the fields then live in uncached memory.)
+// May this engine step in the resident form at all?
 template <typename Real>
 bool Engine<Real>::resident_possible() const {
     if (opt_.tuning.resident == 0 || opt_.ghost_lo || opt_.ghost_hi) return false;
-    if (opt_.tuning.resident < 0 && stored_nodes_ > resident_max_nodes_) return false;
+    // by default: while both fields (pad columns included: they are swept like the rest) stay in the one XCD's L2 the form lives in
+    if (opt_.tuning.resident < 0 && 2 * stored_nodes_ * sizeof(Real) > resident_max_bytes_) return false;
     return stored_nodes_ <= (256ull << 20);  // (the host-side owner map is one word per stored node)
 }
 
 // ... and the batch being planned?
 template <typename Real>
 bool Engine<Real>::resident_now(uint64_t batch) {
-    if (!fields_uncached_ || comm_ || batch < 4 || timing) return false;
+    if (!resident_possible() || comm_ || batch < 4 || timing) return false;
     if (plan_.variant != 2 || plan_.ry != 4 || plan_.nwx != 1 || plan_.nwy != 4) return false;  // (the body the kernel instantiates)
     // (outside nodes a caller wrote to: every tile is visited and the masked sweep stores 0 into `none` nodes, program.cpp:485, like a
     // full sweep does)
@@ -127,14 +128,11 @@ int Engine<Real>::ensure_resident() {
         WV_HIP(hipMalloc((void**)&res_.dep_start, (size_t)(n_units + 1) * sizeof(uint32_t)));
         WV_HIP(hipMalloc((void**)&res_.dep, dep.size() * sizeof(uint32_t)));
         WV_HIP(hipMalloc((void**)&res_.io_start, (size_t)(n_units + 1) * sizeof(uint32_t)));
-        if (hipExtMallocWithFlags((void**)&res_.counter, std::max<size_t>(n_units, 1) * sizeof(uint32_t), hipDeviceMallocUncached) != hipSuccess) {
-            res_.counter = nullptr;
-            return fail(WV_E_HIP, "no uncached memory for the units' counters");
-        }
+        WV_HIP(hipMalloc((void**)&res_.counter, (std::max<size_t>(n_units, 1) + 1) * sizeof(uint32_t)));  // (+ the participants' count)
         WV_HIP(hipMemcpy(res_.sweep_block, sweep_block.data(), (size_t)n_sweep * sizeof(uint32_t), hipMemcpyHostToDevice));
         WV_HIP(hipMemcpy(res_.dep_start, dep_start.data(), dep_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         WV_HIP(hipMemcpy(res_.dep, dep.data(), dep.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        WV_HIP(hipMemset(res_.counter, 0, std::max<size_t>(n_units, 1) * sizeof(uint32_t)));
+        WV_HIP(hipMemset(res_.counter, 0, (std::max<size_t>(n_units, 1) + 1) * sizeof(uint32_t)));
         res_.base = 0;
         // all workgroups of the launch must be resident at once (they wait for each other)
         int per_cu = 0, cus = 0;
@@ -142,7 +140,19 @@ int Engine<Real>::ensure_resident() {
         if (lds) WV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wv::resident_kernel<Real, true>, 256, 0));
         else WV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wv::resident_kernel<Real, false>, 256, 0));
         WV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
-        res_.grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)n_units, (int64_t)std::max(1, per_cu) * (int64_t)std::max(1, cus)));
+        // ... and on ONE XCD (an eighth of the CUs): K of them; the launch has 8 K workgroups, dealt to the XCDs round-robin
+        res_.grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)n_units, (int64_t)std::max(1, per_cu) * (int64_t)std::max(1, cus / 8)));
+        if (opt_.tuning.resident_workgroups > 0) res_.grid = std::min<uint32_t>(res_.grid, (uint32_t)opt_.tuning.resident_workgroups);
+        // does a launch of 8 K workgroups put K of them on XCD 0?  (If the dispatcher deals them differently -- another partition
+        // mode, another driver -- the form is simply not taken.)
+        {
+            uint32_t* arrived = res_.counter + std::max<size_t>(n_units, 1);
+            hipLaunchKernelGGL(wv::resident_probe_kernel, dim3(8u * res_.grid), dim3(256), 0, stream_, arrived);
+            uint32_t got = 0;
+            WV_HIP(hipMemcpyAsync(&got, arrived, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            WV_HIP(hipStreamSynchronize(stream_));
+            if (got != res_.grid) resident_failed_ = true;
+        }
         res_.io_key_valid = false;
         res_.built = true;
     }
@@ -186,6 +196,7 @@ template <typename Real>
 int Engine<Real>::resident_batch(uint64_t batch, bool source_live) {
     int rc = ensure_resident();
     if (rc) return rc;
+    if (resident_failed_) return WV_E_STATE;  // (the caller takes per-step launches: nothing has been touched)
     Real* cur = field_[cur_];
     Real* prev = field_[prv_];
     // every step's flag word starts from the mesh-static bits (waveguide.h:82); receiver rows of unrecorded receivers hold 0
@@ -218,6 +229,9 @@ int Engine<Real>::resident_batch(uint64_t batch, bool source_live) {
     r.dep = res_.dep;
     r.counter = res_.counter;
     r.base = res_.base;
+    r.workgroups = res_.grid;
+    r.arrived = res_.counter + std::max<size_t>(res_.n_units, 1);
+    WV_HIP(hipMemsetAsync(r.arrived, 0, sizeof(uint32_t), stream_));
     r.io_start = res_.io_start;
     r.io = res_.io;
     r.signal = signal_;
@@ -232,8 +246,8 @@ int Engine<Real>::resident_batch(uint64_t batch, bool source_live) {
     WV_HIP(hipMemcpyAsync(res_.args, &r, sizeof(r), hipMemcpyHostToDevice, stream_));
     const auto* rp = static_cast<const wv::ResidentArgs<Real>*>(res_.args);
     const bool lds = n_coeffs_ <= wv::kMaxLdsCoefficientSets && opt_.tuning.boundary_lds != 0;
-    if (lds) hipLaunchKernelGGL((wv::resident_kernel<Real, true>), dim3(res_.grid), dim3(256), 0, stream_, rp);
-    else hipLaunchKernelGGL((wv::resident_kernel<Real, false>), dim3(res_.grid), dim3(256), 0, stream_, rp);
+    if (lds) hipLaunchKernelGGL((wv::resident_kernel<Real, true>), dim3(8u * res_.grid), dim3(256), 0, stream_, rp);
+    else hipLaunchKernelGGL((wv::resident_kernel<Real, false>), dim3(8u * res_.grid), dim3(256), 0, stream_, rp);
     WV_HIP(hipGetLastError());
     res_.base += (uint32_t)batch;
     resident_steps_ += batch;

@@ -42,26 +42,8 @@ int Engine<Real>::init(const wv_mesh& m, const wv_options& opt) {
 
     // ---- pressure fields (zeroed: make_zeroed_buffer, waveguide.h:47-56) -------------------
     field_bytes_ = stored_nodes_ * sizeof(Real);
-    // A mesh small enough to be stepped by persistent workgroups that hand planes to each other inside one launch
-    // (resident_kernels.hip.h) keeps its fields in UNCACHED memory: that hand-over needs stores that go through to the memory side
-    // and loads that do not stop in an XCD's L2.  (At these sizes a step is bound by launches, not bytes; the per-step kernels run
-    // on such fields too.)
-    if (resident_possible()) {
-        fields_uncached_ = true;
-        for (int i = 0; i < 2 && fields_uncached_; ++i)
-            if (hipExtMallocWithFlags((void**)&field_[i], field_bytes_ + 256, hipDeviceMallocUncached) != hipSuccess) {
-                (void)hipGetLastError();
-                field_[i] = nullptr;
-                fields_uncached_ = false;
-            }
-        if (!fields_uncached_)
-            for (int i = 0; i < 2; ++i) {
-                if (field_[i]) (void)hipFree(field_[i]);
-                field_[i] = nullptr;
-            }
-    }
     for (int i = 0; i < 2; ++i) {
-        if (!field_[i]) WV_HIP(hipMalloc((void**)&field_[i], field_bytes_ + 256));
+        WV_HIP(hipMalloc((void**)&field_[i], field_bytes_ + 256));
         WV_HIP(hipMemsetAsync(field_[i], 0, field_bytes_ + 256, stream_));
     }
     prv_ = 0;  // field_[0] = previous, field_[1] = current; [2], [3]: outputs of a two-step pass (ensure_pair)

@@ -1,26 +1,30 @@
-// resident_kernels.hip.h -- a whole batch of single steps of a SMALL mesh in ONE launch: persistent workgroups, each step's work cut
-// into units that wait for the units around them only.
+// resident_kernels.hip.h -- a whole batch of single steps of a SMALL mesh in ONE launch: persistent workgroups on ONE XCD, each step's
+// work cut into units that wait for the units around them only.
 //
-// Below about 160^3 a step is not bound by bytes but by launches: two dependent kernels of ~7 us each per step (sweep, boundary
-// nodes), however little they move (64^3: 13-20 us per step for 2 MB of field).  Rounds 2-4 priced the obvious ways
+// Below about 160^3 a step is not bound by bytes but by launches: two dependent kernels of ~6 us each per step (sweep, boundary
+// nodes), however little they move (32^3: 11 us per step for 0.5 MB of field).  Rounds 2-4 priced the obvious ways
 // out and all lost: a persistent kernel with a GRID-WIDE barrier per step (27 us for 256 workgroups: the arrivals serialise on one
 // counter), every sweep workgroup finishing the boundary nodes of its tile (a boundary node triples the life of its workgroup),
 // a second stream (22 us per fork / join), hipGraph replays (+6 %: the kernels' own dispatch latency stays).
 //
-// This kernel needs no barrier across the grid because the stencil does not: the step of a piece of the mesh needs the pieces
-// AROUND it one step back, nothing else.  A step's work is cut into UNITS -- the workgroup tiles of the plane sweep
-// (stream_sweep_body with masked stores: inside / outside nodes) and the 256-entry blocks of the boundary list (boundary_body) --
-// the very device code the per-step launches run, so the arithmetic cannot differ by a bit.  Unit u of step s waits until every
-// unit that writes a node u reads, or reads a node u writes, has finished step s - 1 (a counter per unit, the lists made once per
-// mesh on the host: engine_resident.hip.h), does its work, waits for its stores to be acknowledged and publishes its counter.
-// Workgroups are persistent (all of them resident: the grid is sized by occupancy) and take the units w, w + G, w + 2 G ... of every
-// step in that order, which makes the scheme deadlock-free: the earliest unfinished (step, unit) never waits for a later one.
-//
-// Coherence: the fields live in UNCACHED device memory in this mode (engine_setup.hip.h) -- stores go through to the memory side
-// (the 256 MB Infinity Cache), loads do not stop in an XCD's private L2 -- so "my stores have been acknowledged" (s_waitcnt
-// vmcnt(0)) is the release and a relaxed agent-scope load of the counter the acquire; with cacheable fields the same hand-over
-// needs an L2 write-back + invalidate per unit, which serialises per XCD (tools/neighbour_sync_bench.hip: 22-92 us per round
-// against 9 us, and that for a loop of dependent loads the real units do not have).
+// Two things make this form work where those did not (both measured first: tools/neighbour_sync_bench.hip, tools/xcd_sync_bench.hip,
+// profiles/r05/):
+//  * no barrier across the grid, because the stencil needs none: the step of a piece of the mesh needs the pieces AROUND it one step
+//    back, nothing else.  A step's work is cut into UNITS -- the workgroup tiles of the plane sweep (stream_sweep_body with masked
+//    stores: inside / outside nodes) and the 256-entry blocks of the boundary list (boundary_entries) -- the very device code the
+//    per-step launches run, so the arithmetic cannot differ by a bit.  Unit u of step s waits until every unit that writes a node u
+//    reads, or reads a node u writes, has finished step s - 1 (a counter per unit; the lists are made once per mesh on the host:
+//    engine_resident.hip.h), does its work, waits for its stores to be acknowledged and publishes its counter;
+//  * every workgroup that takes part sits on ONE XCD.  Between XCDs a hand-over of data costs the consumer an invalidate of its
+//    L2 (buffer_inv sc1), which serialises per XCD at 0.26 us per workgroup -- 10-24 us per step with a few hundred workgroups,
+//    more than the launches it was to save (and no kind of device memory, uncached or fine-grained, does without it).  The 32 CUs
+//    of one XCD share their L2: a store the L2 has acknowledged is what the next load of any of them sees, and a hand-over costs
+//    1.4 us including the data.  Workgroups are dealt to the XCDs round-robin, so the launch has 8 K workgroups of which the K that
+//    find themselves on XCD 0 (hardware register XCC_ID) stay; they count themselves in and start when all K are there (fewer:
+//    the launch gives up at once and the engine goes back to per-step launches for good).  A mesh of up to ~64^3 lives in that
+//    XCD's 4 MB of L2 for the whole batch.
+// Workgroup w of the K takes the units w, w + K, w + 2 K ... of every step, in that order, which makes the scheme deadlock-free:
+// the earliest unfinished (step, unit) never waits for a later one.
 //
 // Source and receivers (waveguide.h:80-123: `pre` injects into `current`, `post` observes it) ride with the units that own their
 // nodes: after unit u has stored the values of level s + 1 it puts the sample of step s + 1 into the source node if that is its
@@ -50,8 +54,10 @@ struct ResidentArgs {
     uint32_t boundary_blocks;          // = n_units - n_sweep
     const uint32_t* dep_start;         // [n_units + 1]
     const uint32_t* dep;               // units each unit waits for
-    uint32_t* counter;                 // [n_units], uncached: steps finished, counted from `base`
+    uint32_t* counter;                 // [n_units] steps finished, counted from `base`
     uint32_t base;
+    uint32_t workgroups;               // K: how many workgroups take part (the launch has 8 K)
+    uint32_t* arrived;                 // zeroed before the launch: the participants count themselves in
     const uint32_t* io_start;          // [n_units + 1]
     const ResidentIo* io;
     const double* signal;
@@ -61,18 +67,48 @@ struct ResidentArgs {
     int* gave_up;                      // set when a wait ran into its bound (a bug, not a state: the launch then ends anyhow)
 };
 
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
+}
+
+// How many workgroups of a launch of this size land on XCD 0?  (Once per engine, before the form is first taken: the K the real
+// launches wait for must be what the dispatcher delivers.)
+__global__ void __launch_bounds__(256) resident_probe_kernel(uint32_t* arrived) {
+    if (xcc_id() == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The argument block lives in device memory and is read where it is needed (the pointer is made opaque once per unit): held in
 // registers across the whole loop nest, two launches' worth of wave-uniform arguments leave the compiler nowhere but scratch for them.
 template <typename Real, bool LDSC>
 __global__ void __launch_bounds__(256) resident_kernel(const ResidentArgs<Real>* __restrict__ rp) {
-    const uint32_t G = gridDim.x, w = blockIdx.x, t = threadIdx.x;
+    const uint32_t t = threadIdx.x;
+    if (xcc_id() != 0) return;  // (seven of eight workgroups: the launch exists to put K of them on one XCD)
+    __shared__ uint32_t s_rank;
     __shared__ int s_abort;
-    if (t == 0) s_abort = 0;
+    const uint32_t K = rp->workgroups;
+    if (t == 0) {
+        s_abort = 0;
+        s_rank = __hip_atomic_fetch_add(rp->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // everybody has to be there before anybody waits for a unit somebody else is to run
+        uint32_t spins = 0;
+        while (__hip_atomic_load(rp->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < K) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 16) || __hip_atomic_load(rp->gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(rp->gave_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (2: not a single step was taken)
+                s_abort = 2;
+                break;
+            }
+        }
+    }
     __syncthreads();
+    const uint32_t w = s_rank;
+    if (s_abort == 2 || w >= K) return;
     const uint32_t steps = rp->steps, n_units = rp->n_units, n_sweep = rp->n_sweep, base = rp->base;
     for (uint32_t step = 0; step < steps; ++step) {
         const uint32_t need = base + step;  // every unit around has finished the step before this one
-        for (uint32_t u = w; u < n_units; u += G) {
+        for (uint32_t u = w; u < n_units; u += K) {
             const ResidentArgs<Real>* r = rp;
             asm volatile("" : "+s"(r));  // (opaque: what is read through it below is read now, not kept from an earlier unit)
             // ---- wait for the units around (one lane per unit waited for)
@@ -97,6 +133,7 @@ __global__ void __launch_bounds__(256) resident_kernel(const ResidentArgs<Real>*
                 }
             }
             __syncthreads();
+            asm volatile("buffer_inv sc0" ::: "memory");  // this CU's L1 may hold lines of a step ago; the XCD's L2 is what everybody shares
             Real* cur = (step & 1u) ? r->field[1] : r->field[0];
             Real* nxt = (step & 1u) ? r->field[0] : r->field[1];
             // ---- the unit's share of the step: the per-step launches' own device code
@@ -115,17 +152,18 @@ __global__ void __launch_bounds__(256) resident_kernel(const ResidentArgs<Real>*
                 b.flag = r->flags + step;
                 boundary_entries<Real, LDSC, false>(b, u - n_sweep);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the memory side
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged by the L2
             __syncthreads();                                  // ... and every wave's (and the bodies' LDS is free again)
             // ---- the next step's source sample / receiver samples at the nodes this unit has just finished
             const uint32_t i0 = r->io_start[u], i1 = r->io_start[u + 1];
             if (i0 != i1 && step + 1 < steps && t == 0) {
+                asm volatile("buffer_inv sc0" ::: "memory");
                 for (uint32_t i = i0; i < i1; ++i) {  // (a unit's source duty comes before its receiver duties)
                     const ResidentIo io = r->io[i];
                     if (io.kind) {
                         const Real sample = (Real)r->signal[r->signal_pos + step + 1];
                         nxt[io.node] = io.kind == 1 ? sample : (Real)(nxt[io.node] + sample);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
                     } else {
                         r->recv_out[(size_t)(step + 1) * r->n_recv + io.col] = nxt[io.node];
                     }
