@@ -143,14 +143,14 @@ __global__ void __launch_bounds__(256) resident_kernel(const ResidentArgs<Real>*
                 s.prev = nxt;
                 s.next = nxt;
                 s.flag = r->flags + step;
-                stream_sweep_body<Real, 4, 1, 4, ((X_SWEEP & ~X_STORE_ALL) | X_NO_LIST)>(s, r->sweep_block[u]);
+                stream_sweep_body<Real, 4, 1, 4, X_NO_LIST>(s, r->sweep_block[u]);  // (masked stores; no streaming hints: the L2 is home)
             } else {
                 BoundaryArgs<Real> b = r->b;
                 b.cur = cur;
                 b.prev = nxt;
                 b.next = nxt;
                 b.flag = r->flags + step;
-                boundary_entries<Real, LDSC, false>(b, u - n_sweep);
+                boundary_entries<Real, LDSC, false, false>(b, u - n_sweep);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged by the L2
             __syncthreads();                                  // ... and every wave's (and the bodies' LDS is free again)
@@ -160,12 +160,15 @@ __global__ void __launch_bounds__(256) resident_kernel(const ResidentArgs<Real>*
                 asm volatile("buffer_inv sc0" ::: "memory");
                 for (uint32_t i = i0; i < i1; ++i) {  // (a unit's source duty comes before its receiver duties)
                     const ResidentIo io = r->io[i];
+                    // (the field through agent-scope atomics: a plain load at a wave-uniform address may be a scalar load, whose cache
+                    // nobody invalidates here)
                     if (io.kind) {
                         const Real sample = (Real)r->signal[r->signal_pos + step + 1];
-                        nxt[io.node] = io.kind == 1 ? sample : (Real)(nxt[io.node] + sample);
-                        asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
+                        const Real old = __hip_atomic_load(nxt + io.node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(nxt + io.node, io.kind == 1 ? sample : (Real)(old + sample), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     } else {
-                        r->recv_out[(size_t)(step + 1) * r->n_recv + io.col] = nxt[io.node];
+                        r->recv_out[(size_t)(step + 1) * r->n_recv + io.col] = __hip_atomic_load(nxt + io.node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

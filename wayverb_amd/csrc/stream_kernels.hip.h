@@ -478,7 +478,7 @@ __device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, uns
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const bool live = y0 + r < y_hi;
-            pv[r] = live ? io.template prev_row<true>(y0 + r, z) : (V)(Real(0));
+            pv[r] = live ? io.template prev_row<(X & X_NT_PREV) != 0>(y0 + r, z) : (V)(Real(0));
             cl[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
         }
         mid_e = io.template edges<RY>(y0, z);
