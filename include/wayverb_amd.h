@@ -117,10 +117,7 @@ typedef struct wv_tuning {
                                * wv_create (the x-facing walls' compact copies leave out the planes an early pass steps ahead) */
     int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
     int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
-    int32_t resident;         /* small meshes: batches of single steps in ONE launch of persistent workgroups whose units wait for the units
-                               * around them only (resident_kernels.hip.h; the fields then live in uncached memory): -1 by mesh size, 1 / 0 force on / off */
-    int32_t resident_workgroups; /* measurement: workgroups of the resident form's launch (0 = as many as are resident at once, by occupancy) */
-    int32_t reserved_[2];
+    int32_t reserved_[4];
 } wv_tuning;
 
 typedef struct wv_options {
@@ -272,9 +269,7 @@ enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_
        WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10,
        /* kernel timing on: total time of the two boundary launches of the two-step passes whose march was timed (nodes to t+1 / to t+2),
         * over that many passes; reset by wv_kernel_time */
-       WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13,
-       /* steps taken in the resident form (wv_tuning::resident), and the workgroups / units of its launches (0 before the first) */
-       WV_QUERY_RESIDENT_STEPS = 14, WV_QUERY_RESIDENT_WORKGROUPS = 15, WV_QUERY_RESIDENT_UNITS = 16 };
+       WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

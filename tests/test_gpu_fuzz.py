@@ -14,8 +14,7 @@ from wayverb_amd import mesh as M
 pytestmark = pytest.mark.gpu
 
 MODES = {"default": {}, "passes": dict(pair=1), "passes-list-only": dict(pair=1, pair_inner_fix=0),
-         "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0),
-         "resident": dict(resident=1, pair=0)}     # a batch of single steps in one launch of persistent workgroups (resident_kernels.hip.h)
+         "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0)}
 
 
 def random_case(seed):

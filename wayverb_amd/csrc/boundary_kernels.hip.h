@@ -136,9 +136,7 @@ __device__ __forceinline__ Real faced_value(const Real (&fnb)[3][2], Real fprev)
 // node it faces needs.  Selection is by v_cndmask, not by branch: with the loads behind per-lane branches
 // (the first form of this kernel) every one of them was waited for on its own, and eight to ten memory
 // round trips in a row, not bytes, set the kernel's time.
-// (NT: the filter memories with the non-temporal hint -- read once and written once per launch, they should not displace field lines
-// in L2; the resident form, resident_kernels.hip.h, lives in an L2 and takes them without)
-template <typename Real, int D, bool FIX, bool NT = true>
+template <typename Real, int D, bool FIX>
 __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t k, uint32_t entry,
                                               uint32_t slot_base, uint32_t n_d, int& bad) {
     const uint32_t idx = a.bnode[entry];
@@ -178,8 +176,7 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
         cf[i] = coeffs + (size_t)a.cidx[slot[i]] * 14;
 #pragma unroll
         // filter memories are read once and written once per step: keep them from displacing field lines in L2
-        for (int j = 0; j < 6; ++j)
-            m[i][j] = NT ? __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + slot[i]) : a.fmem[(size_t)j * a.n_slots + slot[i]];
+        for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
     // two-step pass, second launch: the inside node a 1-D entry faces (boundary_kernel<.., FIX = true>) and the
     // seven values its update t+1 -> t+2 reads
@@ -215,10 +212,7 @@ __device__ __forceinline__ void boundary_node(const BoundaryArgs<Real>& a, const
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (NT) __builtin_nontemporal_store(m[i][j], a.fmem + (size_t)j * a.n_slots + slot[i]);
-            else a.fmem[(size_t)j * a.n_slots + slot[i]] = m[i][j];
-        }
+        for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(m[i][j], a.fmem + (size_t)j * a.n_slots + slot[i]);
     }
     bad |= bad_bits(next);
     a.next[idx] = next;
@@ -354,14 +348,14 @@ __device__ __forceinline__ void xwall_node(const BoundaryArgs<Real>& a, const do
 }
 
 // entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
-template <typename Real, bool FIX, bool NT = true>
+template <typename Real, bool FIX>
 __device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t e, int& bad) {
     if (e < a.n1) {
-        boundary_node<Real, 1, FIX, NT>(a, coeffs, e, e, 0u, a.n1, bad);
+        boundary_node<Real, 1, FIX>(a, coeffs, e, e, 0u, a.n1, bad);
     } else if (e < a.n1 + a.n2) {
-        boundary_node<Real, 2, FIX, NT>(a, coeffs, e - a.n1, e, a.n1, a.n2, bad);
+        boundary_node<Real, 2, FIX>(a, coeffs, e - a.n1, e, a.n1, a.n2, bad);
     } else if (e < a.n1 + a.n2 + a.n3) {
-        boundary_node<Real, 3, FIX, NT>(a, coeffs, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
+        boundary_node<Real, 3, FIX>(a, coeffs, e - a.n1 - a.n2, e, a.n1 + 2u * a.n2, a.n3, bad);
     }
 }
 
@@ -380,9 +374,8 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
 // (BoundaryArgs::fix_z0 / fix_z1).
 // (`block` of `blocks`: this workgroup's place among the boundary workgroups of the launch -- all of it for boundary_kernel, the
 // tail of the grid for plane_step_kernel.)
-// (boundary_entries: the entries' share of a workgroup, without whatever may ride behind them -- what resident_kernels.hip.h runs)
-template <typename Real, bool LDSC, bool FIX, bool NT = true>
-__device__ __forceinline__ void boundary_entries(const BoundaryArgs<Real>& a, uint32_t block) {
+template <typename Real, bool LDSC, bool FIX>
+__device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
         for (uint32_t w = threadIdx.x; w < a.n_coeffs * 14u; w += 256) s_coeffs[w] = a.coeffs[w];
@@ -397,21 +390,16 @@ __device__ __forceinline__ void boundary_entries(const BoundaryArgs<Real>& a, ui
         if (t < a.xw_pad) {
             if (t < a.xw_n) xwall_node<Real, FIX ? 2 : 1>(a, coeffs, t, bad);
         } else if (a.order) {
-            if (t - a.xw_pad < a.n_order) boundary_entry<Real, FIX, NT>(a, coeffs, a.order[t - a.xw_pad], bad);
+            if (t - a.xw_pad < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t - a.xw_pad], bad);
         } else {
-            boundary_entry<Real, FIX, NT>(a, coeffs, a.xw_n + (t - a.xw_pad), bad);
+            boundary_entry<Real, FIX>(a, coeffs, a.xw_n + (t - a.xw_pad), bad);
         }
     } else if (a.order) {
-        if (t < a.n_order) boundary_entry<Real, FIX, NT>(a, coeffs, a.order[t], bad);
+        if (t < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t], bad);
     } else {
-        boundary_entry<Real, FIX, NT>(a, coeffs, t, bad);
+        boundary_entry<Real, FIX>(a, coeffs, t, bad);
     }
     if (bad) atomicOr(a.flag, bad);
-}
-
-template <typename Real, bool LDSC, bool FIX>
-__device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
-    boundary_entries<Real, LDSC, FIX>(a, block);
     if (next.fused && block == blocks - 1) pre_post_body<Real>(next, threadIdx.x, 256);
 }
 

@@ -8,7 +8,6 @@
 //   engine_single.hip.h  one time step per pass: sweep + boundary launches, source / receiver launch, the slab form
 //                        (faces first, exchange, interior), hipGraph replay for small meshes
 //   engine_pair.hip.h    two time steps per pass: eligibility, pair map + fix-up lists, march geometry, parts A / B
-//   engine_resident.hip.h  small meshes: a batch of single steps in one launch of persistent workgroups (resident_kernels.hip.h)
 //   engine_batch.hip.h   wv_step / wv_run: batches of steps, flag words, kernel timing
 //   engine_io.hip.h      everything a caller reads or writes: values, fields, planes, filter memories, source,
 //                        receivers
@@ -21,7 +20,6 @@
 #include "pair_kernels.hip.h"
 #include "stream_kernels.hip.h"
 #include "plane_kernels.hip.h"
-#include "resident_kernels.hip.h"
 
 namespace wv {
 
@@ -87,12 +85,6 @@ public:
     uint64_t role_signature() const override {
         return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
     }
-    // ---- engine_resident.hip.h
-    bool resident_possible() const;
-    bool resident_now(uint64_t batch);
-    int ensure_resident();
-    int resident_batch(uint64_t batch, bool source_live);
-    void release_resident();
     // ---- engine_batch.hip.h
     bool time_this_launch();
     int drain_timing();
@@ -278,22 +270,6 @@ private:
     Real* recv_stage_ = nullptr;  // pinned, kRing rows: a copy into pageable memory would make hipMemcpyAsync wait for the stream on the host
     std::vector<double> recv_log_;
     std::unique_ptr<wv::SlabComm> comm_;
-    // small meshes, a batch of steps in one launch (engine_resident.hip.h)
-    struct ResidentTables {
-        bool built = false;
-        uint32_t n_sweep = 0, n_units = 0, grid = 0, base = 0;
-        uint32_t *sweep_block = nullptr, *dep_start = nullptr, *dep = nullptr, *counter = nullptr, *io_start = nullptr;
-        wv::ResidentIo* io = nullptr;
-        void* args = nullptr;  // the launch's argument block (device memory)
-        std::vector<uint32_t> unit_of_block, bunit_of_node;  // host: sweep workgroup -> unit; stored node -> the boundary unit that writes it
-        bool io_key_valid = false;
-        uint64_t io_source = 0;
-        int io_kind = 0;
-        std::vector<uint64_t> io_recv;
-    } res_;
-    bool resident_failed_ = false;
-    uint64_t resident_max_bytes_ = 4ull << 20;  // both fields up to this size: the form is taken by default (one XCD's L2)
-    uint64_t resident_steps_ = 0;
     // wv_checkpoint / wv_rollback (engine_io.hip.h): device copies of the two live fields and the filter memories, and the
     // host-side position that goes with them
     struct Checkpoint {

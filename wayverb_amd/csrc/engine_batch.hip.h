@@ -254,16 +254,8 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
         // so that the two fields are back in their roles after every replay.
         const bool use_graph = opt_.tuning.graph != 0 && !comm_ && !timing && (batch % 2) == 0 && batch >= 16 &&
                                stored_nodes_ <= graph_max_nodes_ && outside_dirty_ == 0;
-        bool use_resident = !use_graph && resident_now(batch);
-        if (use_resident) {  // (tables, and whether the dispatcher deals workgroups as the form needs: once)
-            if ((rc = ensure_resident())) return rc;
-            use_resident = !resident_failed_;
-        }
         if (use_graph) {
             if ((rc = replay_batch(batch, batch_source_live_, batch_can_fuse_))) return rc;
-        } else if (use_resident) {
-            if ((rc = batch_pair_vetoed())) return rc;
-            if ((rc = resident_batch(batch, batch_source_live_))) return rc;
         } else {
             // big meshes: two steps per pass over the fields wherever a batch has two left
             int singles_first = -1;
@@ -303,16 +295,6 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             }
         }
         if ((rc = collect_batch(batch))) return rc;
-        if (use_resident) {
-            int gave_up = 0;
-            uint32_t arrived = 0;
-            WV_HIP(hipMemcpy(&gave_up, status_ + 2, sizeof(int), hipMemcpyDeviceToHost));
-            WV_HIP(hipMemcpy(&arrived, res_.counter + std::max<size_t>(res_.n_units, 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
-            if (gave_up || arrived != res_.grid) {
-                resident_failed_ = true;
-                return fail(WV_E_HIP, "resident stepping: a unit's wait for the units around it ran into its bound (the fields are no longer meaningful)");
-            }
-        }
         uint64_t good = 0;
         if ((rc = commit_batch(batch, flags_host_, &good, &flag))) return rc;
         completed += good;
@@ -372,9 +354,6 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_HALO_EXCHANGES: *value = comm_ ? comm_->exchanges() : 0; return WV_OK;
         case WV_QUERY_HALO_BYTES_SENT: *value = comm_ ? comm_->planes_sent() * (uint64_t)comm_->plane_bytes() : 0; return WV_OK;
         case WV_QUERY_EARLY_PASSES: *value = early_passes_; return WV_OK;
-        case WV_QUERY_RESIDENT_STEPS: *value = resident_steps_; return WV_OK;
-        case WV_QUERY_RESIDENT_WORKGROUPS: *value = res_.built ? res_.grid : 0; return WV_OK;
-        case WV_QUERY_RESIDENT_UNITS: *value = res_.built ? res_.n_units : 0; return WV_OK;
         case WV_QUERY_BOUNDARY1_NS: *value = (uint64_t)(part_ms_[0] * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_BOUNDARY2_NS: *value = (uint64_t)(part_ms_[1] * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_BOUNDARY_TIMED: *value = std::min(part_n_[0], part_n_[1]); return WV_OK;

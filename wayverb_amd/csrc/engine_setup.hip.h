@@ -548,7 +548,6 @@ void Engine<Real>::release() {
     for (int i = 0; i < 4; ++i)
         if (field_[i]) (void)hipFree(field_[i]);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-    release_resident();
     for (auto& f : ckpt_.field)
         if (f) (void)hipFree(f);
     if (ckpt_.fmem) (void)hipFree(ckpt_.fmem);

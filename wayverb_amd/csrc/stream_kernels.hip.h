@@ -23,9 +23,7 @@ namespace wv {
 // to price a piece of the kernel; the nt ones are result-neutral cache hints.
 enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
              X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512,
-             X_STORE_ALL = 1024,   // boundary nodes get their old value written back: no masked stores
-             X_NO_LIST = 2048 };   // the caller never passes a work list (resident_kernels.hip.h): the list arm, which indexes an array of
-                                   // the argument block by a run-time value, is not compiled (a by-value copy of the block would go to scratch)
+             X_STORE_ALL = 1024 };  // boundary nodes get their old value written back: no masked stores
 // what the engine runs: `prev` and `next` are touched exactly once per step, so they carry the
 // non-temporal hint and do not displace the re-used `cur` lines from L2
 constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
@@ -430,7 +428,7 @@ __device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, uns
     int j = block >> 3;
     int tl, z, stripe;
     uint32_t mask = ~0u;  // which waves of this workgroup have something to update
-    if (!(X & X_NO_LIST) && a.tile_list) {
+    if (a.tile_list) {
         const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
         if ((uint32_t)j >= count) return;  // the whole workgroup leaves together
         const uint64_t e = a.tile_list[first + (uint32_t)j];
@@ -478,7 +476,7 @@ __device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, uns
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const bool live = y0 + r < y_hi;
-            pv[r] = live ? io.template prev_row<(X & X_NT_PREV) != 0>(y0 + r, z) : (V)(Real(0));
+            pv[r] = live ? io.template prev_row<true>(y0 + r, z) : (V)(Real(0));
             cl[r] = live ? io.cls_of_row(clw, y0 + r) : 0xAAu;
         }
         mid_e = io.template edges<RY>(y0, z);
