@@ -282,6 +282,76 @@ class RcclChain(Chain):
                 raise AssertionError("one exchange per step or half pass")
 
 
+class IpcChain(Chain):
+    """The engine code over the IPC transport (wv_options::transport = WV_TRANSPORT_IPC, comm.cpp): one process per slab like
+    RCCL, but the planes travel by copies into the neighbour's own (IPC-mapped) fields and the ranks order themselves with
+    COUNTERS in per-rank mailboxes instead of events -- a wait names the number it waits for, so it may be enqueued before the
+    thing it waits for exists (events cannot say that across processes):
+      wait_ghosts(buf)     the neighbours' copy number `pushes[buf]` of that buffer has landed (each rank takes the same steps,
+                           so a neighbour's latest exchange of a buffer has the number of this rank's own), + this rank's own
+                           latest copies have read its face planes (a local event);
+      exchange_faces(buf)  the neighbours have finished step number `steps_done` (they no longer read the ghost planes about to
+                           be overwritten); copy; post the copy's number into the neighbour's mailbox;
+      step_done            post the step's number into both neighbours' mailboxes.
+    Ranks enqueue independently; this model goes phase by phase like RcclChain, which keeps every waited-for operation ahead of
+    its waiter in the list (the check below needs that), and `lag` lets one rank's host run whole phases behind the others."""
+
+    def __init__(self, n, source=None, early=True, counters=True, own_pushes=True, war=True):
+        super().__init__(n, Rules(early=early, own_pushes=own_pushes), source)
+        self.counters, self.war = counters, war
+        self.pushes = [[0] * 4 for _ in range(n)]             # exchanges of buffer b issued by rank k
+        self.push_op = {}                                       # (rank, side, buffer, number) -> op
+        self.done_op = {}                                       # (rank, number) -> op
+
+    def wait_ghosts(self, k, buf, stream=None):
+        S = stream or ("S", k)
+        number = self.pushes[k][buf]
+        if number:
+            for nb, side in ((self.lo(k), "hi"), (self.hi(k), "lo")):
+                if nb is None:
+                    continue
+                # with counters: exactly that copy; without (what an event would give across processes): whatever copy of the
+                # buffer the neighbour happens to have enqueued so far, here: the one before
+                want = number if self.counters else number - 1
+                if want:
+                    self.wait_op(S, self.push_op[(nb, side, buf, want)])
+        if self.rules.own_pushes:
+            self.wait_op(S, self.last_own_push[k])
+
+    def exchange_faces(self, k, buf, on_halo=False):
+        S, H = ("S", k), ("H", k)
+        if not on_halo:
+            self.record(S, ("faces_ready", k))
+            self.wait(H, ("faces_ready", k))
+        self.pushes[k][buf] += 1
+        number = self.pushes[k][buf]
+        c = self.steps_done[k]
+        for nb, mine, theirs, side in ((self.lo(k), "face_lo", "ghost_hi", "lo"), (self.hi(k), "face_hi", "ghost_lo", "hi")):
+            if nb is None:
+                continue
+            if self.war and c > 0:
+                self.wait_op(H, self.done_op[(nb, c)])
+            i = self.op(H, "push %s of buffer %d to slab %d" % (mine, buf, nb), reads=self.planes(k, buf, [mine]), writes=self.planes(nb, buf, [theirs]))
+            self.push_op[(k, side, buf, number)] = i
+            self.last_own_push[k] = i
+
+    def step_done(self, k):
+        self.steps_done[k] += 1
+        self.done_op[(k, self.steps_done[k])] = self.op(("S", k), "post step %d done" % self.steps_done[k])
+
+    def bulk(self, k, name, reads, writes):
+        self.op(("S", k), name, reads, writes)
+
+    def enqueue_all(self, make):
+        runs = [make(k) for k in range(self.n)]
+        yielded = [next(r) for r in runs]                   # every rank up to its exchange
+        for k in range(self.n):
+            self.exchange_faces(k, yielded[k][0], yielded[k][1])
+        for r in runs:
+            for _ in r:
+                raise AssertionError("one exchange per step or half pass")
+
+
 def unordered_conflicts(chain):
     """Pairs of operations that touch the same plane of the same buffer, at least one writing, with no happens-before path
     between them (stream order + event waits, transitively)."""
@@ -400,3 +470,26 @@ def test_the_rccl_transport_orders_every_conflicting_access(n, kinds, source):
     for early in (True, False):
         assert not unordered_conflicts(RcclChain(n, source, early=early).run(kinds))
         assert unordered_conflicts(RcclChain(n, source, wait_for_ghosts=False, early=early).run(kinds))
+
+
+@pytest.mark.parametrize("n,source", CHAINS, ids=str)
+@pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
+def test_the_ipc_transport_orders_every_conflicting_access(n, kinds, source):
+    """Round 5: copies into the neighbours' IPC-mapped fields ordered by mailbox counters (comm.cpp, the ipc_ branches).  Every
+    conflicting pair of accesses is ordered, in both orders of a pass; what each ingredient is for shows when it is left out:
+    a wait that cannot name its number (an event's "latest record" seen from another process) lets a rank read ghost planes the
+    neighbour has not filled yet; without the wait for its own copies the faces' second step / a source on a face races with them."""
+    for early in (True, False):
+        assert not unordered_conflicts(IpcChain(n, source, early=early).run(kinds))
+        late = unordered_conflicts(IpcChain(n, source, early=early, counters=False).run(kinds))
+        assert late and any("push" in a or "push" in b for _, a, _, b, _ in late), late[:3]
+    if "pass" in kinds:
+        assert unordered_conflicts(IpcChain(n, source, own_pushes=False).run(kinds))
+
+
+@pytest.mark.parametrize("kinds", SEQUENCES, ids=lambda s: "".join(k[0] for k in s))
+def test_the_ipc_transports_wait_for_the_neighbours_step_end_is_a_safety_net_too(kinds):
+    """As in the in-process transport: a rank copies into a neighbour's ghost plane only after it has seen that neighbour's copy
+    of the same exchange, which follows everything the neighbour read before."""
+    for source in SOURCES[:3]:
+        assert not unordered_conflicts(IpcChain(3, source, war=False).run(kinds))
