@@ -13,7 +13,7 @@ def main():
     files = [where] if where.endswith(".csv") else glob.glob(os.path.join(where, "**", "*kernel_stats.csv"), recursive=True)
     for f in files:
         for r in csv.DictReader(open(f)):
-            name = r["Name"].replace("void wv::", "").replace("wv::", "")
+            name = r["Name"].replace("(anonymous namespace)::", "").replace("void wv::", "").replace("wv::", "")
             name = name.split("(")[0]
             if wanted and not any(w in name for w in wanted):
                 continue
