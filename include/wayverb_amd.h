@@ -195,6 +195,11 @@ int wv_read_boundary_data(wv_engine* e, int dimensionality, wv_boundary_data* ds
 int wv_write_boundary_data(wv_engine* e, int dimensionality, const wv_boundary_data* src);
 /* mesh::set_coefficients (src/waveguide/src/setup.cpp:38-50): n must equal num_coefficients */
 int wv_set_coefficients(wv_engine* e, const wv_coefficients_canonical* c, uint32_t n);
+/* Page-locks `bytes` of the caller's host memory at `p` for the device (hipHostRegister) / releases it: reads and writes of fields,
+ * planes and boundary data whose host side is registered memory go by DMA at the link's rate instead of through the runtime's staging
+ * buffers (what cl_mirror.h does with the staging area of its cl::Buffer mirror).  Optional; WV_E_HIP when the runtime refuses. */
+int wv_host_register(void* p, uint64_t bytes);
+int wv_host_unregister(void* p);
 /* Device addresses of the fields (element type per precision), for zero-copy wrappers.  Once a
  * pointer has been handed out the engine stops assuming that outside nodes hold zeros (see
  * wv_options::all_tiles) and keeps to one time step per pass over two fields, so that the pointers stay

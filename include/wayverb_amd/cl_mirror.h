@@ -68,10 +68,15 @@ public:
               buffer_{cc.context, CL_MEM_READ_WRITE, sizeof(cl_float) * nodes},
               nodes_{nodes} {
         // zeros until somebody wants the field (make_zeroed_buffer is what the reference's own field starts as, waveguide.h:47-56)
+#if defined(CL_VERSION_1_2)
+        queue_.enqueueFillBuffer(buffer_, cl_float{0}, 0, sizeof(cl_float) * nodes);
+        queue_.finish();
+#else
         const std::vector<float> zeros(std::min<size_t>(nodes, size_t{4} << 20), 0.0f);
         for (size_t at = 0; at < nodes; at += zeros.size())
             queue_.enqueueWriteBuffer(buffer_, CL_TRUE, sizeof(cl_float) * at, sizeof(cl_float) * std::min(zeros.size(), nodes - at),
                                       zeros.data());
+#endif
     }
     bool wanted_now() const {
         const auto& wanted = cl_mirror_wanted();
@@ -81,7 +86,10 @@ public:
     void invoke(Callback& callback, size_t step, size_t steps) {
         if (wanted_now()) {
             guard_->touch();  // the engine's PREVIOUS buffer now holds this step's pre-update `current` (waveguide.h:121-123)
-            if (staging_.size() != nodes_) staging_.assign(nodes_, 0.0f);  // (host memory for the field only once it is wanted)
+            if (staging_.size() != nodes_) {  // (host memory for the field only once it is wanted; page-locked: the copy down goes by DMA)
+                staging_.assign(nodes_, 0.0f);
+                registered_ = wv_host_register(staging_.data(), sizeof(float) * nodes_) == WV_OK;
+            }
             const size_t planes_total = nodes_ / plane_nodes_;
             const mirror_planes want = cl_mirror_planes();
             const size_t z0 = want.z_count < 0 ? 0 : std::min((size_t)std::max(want.z_begin, 0), planes_total);
@@ -97,6 +105,12 @@ public:
         callback(queue_, static_cast<const cl::Buffer&>(buffer_), step, steps);
     }
 
+    ~cl_mirror_bridge() {
+        if (registered_) (void)wv_host_unregister(staging_.data());
+    }
+    cl_mirror_bridge(const cl_mirror_bridge&) = delete;
+    cl_mirror_bridge& operator=(const cl_mirror_bridge&) = delete;
+
 private:
     wv_engine* engine_;
     field_guard* guard_;
@@ -105,6 +119,7 @@ private:
     cl::Buffer buffer_;
     size_t nodes_;
     std::vector<float> staging_;
+    bool registered_ = false;
 };
 
 // any context with a `.context` member that a cl::CommandQueue can be built from

@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_reference_contract():
     import subprocess
     import tempfile
     fields = ["struct_size", "precision", "device", "ghost_lo", "ghost_hi", "flag_interval", "stream_variant", "all_tiles",
-              "nodes_on_device", "tuning"]
+              "nodes_on_device", "comm_timeout_s", "transport", "tuning"]
     tfields = list(E.TUNING_FIELDS)
     prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"wayverb_amd.h\"\nint main(void){printf(\"%zu %zu\", sizeof(wv_options), sizeof(wv_tuning));" + \
         "".join('printf(" %%zu", offsetof(wv_options, %s));' % f for f in fields) + \

@@ -159,6 +159,19 @@ int wv_device_buffer(wv_engine* e, int buffer, void** p) {
     WV_NEED(e);
     return e->device_buffer(buffer, p);
 }
+int wv_host_register(void* p, uint64_t bytes) {
+    if (!p || !bytes) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(WV_E_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    WV_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+    return WV_OK;
+}
+int wv_host_unregister(void* p) {
+    if (!p) return fail(WV_E_INVALID_ARGUMENT, "null argument");
+    WV_HIP(hipHostUnregister(p));
+    return WV_OK;
+}
 int wv_checkpoint(wv_engine* e) {
     WV_NEED(e);
     return e->checkpoint(0);

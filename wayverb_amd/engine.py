@@ -33,7 +33,7 @@ EXPORTS = [
     "wv_reflectance_filter", "wv_impedance_coefficients", "wv_attenuate", "wv_adjust_sampling_rate",
     "wv_frequency_domain_filter", "wv_postprocess_waveguide", "wv_hrtf_attenuation", "wv_hrtf_ear_position",
     "wv_attenuate_hrtf", "wv_multiband_filter_and_mixdown", "wv_postprocess_waveguide_hrtf", "wv_scene_mesh_create", "wv_scene_mesh_fetch",
-    "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy", "wv_checkpoint", "wv_rollback", "wv_drop_checkpoint",
+    "wv_scene_mesh_create_engine", "wv_scene_mesh_destroy", "wv_checkpoint", "wv_rollback", "wv_drop_checkpoint", "wv_host_register", "wv_host_unregister",
 ]
 
 
