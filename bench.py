@@ -14,6 +14,8 @@ in HBM before the timed region.
           (configs[3] at N = 8), ghost planes exchanged each step over RCCL inside the engine;
           `--scaling strong`: the 1024^3 box of N = 1 cut into N slabs of 1024 / N planes (the north star's
           ">= 6x at 8 GPUs" read as a speed-up of configs[2]).
+          Before anything is timed the chain proves itself on the machine's own links: a small room stepped as N slabs over the
+          chosen transport against the single domain on rank 0, bit for bit (`config.halo_parity`).
   More ranks than GPUs (tests on a one-GPU box): torch.distributed falls back to gloo for the bookkeeping and
   `--rccl-library` must name a stand-in for librccl (tests/mock_rccl/mock_rccl_shm.cpp); never a measurement.
 
@@ -79,6 +81,7 @@ def parse_args():
                    help="seconds after which the run is abandoned: rank 0 prints its JSON line with an \"error\" field instead of "
                         "hanging (a stuck collective, a dead peer); 0 = none")
     p.add_argument("--no-windows", action="store_true", help="skip the three extra timing windows after the timed region")
+    p.add_argument("--no-parity-check", action="store_true", help="N > 1: skip the small chain-against-single-domain check before the timed run")
     return p.parse_args()
 
 
@@ -148,6 +151,99 @@ def cpu_baseline(args, elem):
             "per_core_mnode_per_s": round(rate * 1e3 / threads, 2),
             "sample": "the same %dx%dx%d %s box mesh, %d steps in %.1f s on %d threads (host has %d logical cores); %s"
                       % (nx, ny, nz, args.precision, steps, dt, threads, cores, what)}
+
+
+def chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch):
+    """N > 1: before anything is timed, the chain proves itself on THIS machine's links.  A small room (192 x 160 x 24 N nodes, four
+    wall materials, noise in the room, a soft source on a slab face, receivers on both sides of a cut) is stepped 26 times as N
+    slabs over the same transport the timed run will use, two-step passes forced, and by rank 0 alone as one domain: the owned
+    planes of both fields, the filter memories and the receiver rows must be the same bytes.  Returns what goes into the bench line
+    as config.halo_parity (never raises: a failure here is reported, not fatal to the measurement)."""
+    import hashlib
+    t0 = time.perf_counter()
+    try:
+        from wayverb_amd import engine as E
+        from wayverb_amd import mesh as M
+        from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
+        nx, ny, nz, steps = 192, 160, 24 * world, 26
+        rng = np.random.default_rng(2605)
+        coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 2),
+                                 np.array([M.flat_coefficients(0.2), M.rigid_coefficients()], dtype=M.coefficients_dtype)])
+        gmesh = M.box_mesh(nx, ny, nz, coefficients=coeffs, surface_of_face=[0, 1, 2, 3, 0, 1])
+        live = gmesh.nodes["boundary_type"] != 0
+        gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0)
+        gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0)
+        signal = rng.uniform(-0.1, 0.1, steps)
+        plane = nx * ny
+        L0 = SlabLayout((nx, ny, nz), 0, world)
+        source = (L0.z1 - 1) * plane + (ny // 2) * nx + nx // 2            # top owned plane of slab 0: its ghost copy injects too
+        receivers = [source + 3, source + plane, source - plane, (nz - 3) * plane + 5 * nx + 7]
+        tuning = dict(pair=1)
+        L = SlabLayout((nx, ny, nz), rank, world)
+        eng = E.Engine(slab_mesh(gmesh, L), precision="f64", device=local_rank, ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi, tuning=tuning,
+                       comm_timeout_s=args.comm_timeout, transport=args.transport)
+        eng.write_field(gprev[L.zl0 * plane:L.zl1 * plane], E.BUF_PREVIOUS)
+        eng.write_field(gcur[L.zl0 * plane:L.zl1 * plane], E.BUF_CURRENT)
+        src_local, mine = place_source_and_receivers(L, source, receivers)
+        if src_local is not None:
+            eng.set_source(E.SOURCE_SOFT, src_local, signal)
+        eng.set_receivers([idx for _, idx in mine])
+        idt = torch.zeros(E.UNIQUE_ID_BYTES, dtype=torch.uint8, device=coll_device)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(E.Engine.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        done, flag = eng.run_steps(steps)
+        lo, hi = L.owned_local_range()
+        h = hashlib.sha256()
+        h.update(eng.read_field(E.BUF_CURRENT)[lo:hi].tobytes())
+        h.update(eng.read_field(E.BUF_PREVIOUS)[lo:hi].tobytes())
+        for d in (1, 2, 3):
+            h.update(np.ascontiguousarray(eng.read_boundary_data(d)["filter_memory"]).tobytes())
+        got = eng.fetch_receivers(0, done)
+        mine_rows = {pos: got[:, col].tobytes() for col, (pos, _) in enumerate(mine)}
+        passes = int(eng.query(E.Engine.QUERY_PASSES))
+        eng.close()
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (done, flag, h.hexdigest(), mine_rows, passes))
+        if rank != 0:
+            return None
+        # the same room as one domain, on rank 0's GPU
+        single = E.Engine(gmesh, precision="f64", device=local_rank, tuning=tuning)
+        single.write_field(gprev, E.BUF_PREVIOUS)
+        single.write_field(gcur, E.BUF_CURRENT)
+        single.set_source(E.SOURCE_SOFT, source, signal)
+        single.set_receivers(receivers)
+        want_done, want_flag = single.run_steps(steps)
+        cur, prev = single.read_field(E.BUF_CURRENT), single.read_field(E.BUF_PREVIOUS)
+        bd = [single.read_boundary_data(d) for d in (1, 2, 3)]
+        want_rows = single.fetch_receivers(0, want_done)
+        single.close()
+        t = gmesh.nodes["boundary_type"]
+        pc = sum(((t >> bit) & 1) for bit in range(8))
+        is_b = (t & (M.ID_INSIDE | M.ID_REENTRANT)) == 0
+        zs = np.arange(gmesh.num_nodes) // plane
+        wrong = []
+        for r in range(world):
+            Lr = SlabLayout((nx, ny, nz), r, world)
+            hh = hashlib.sha256()
+            hh.update(cur[Lr.z0 * plane:Lr.z1 * plane].tobytes())
+            hh.update(prev[Lr.z0 * plane:Lr.z1 * plane].tobytes())
+            owned = (zs >= Lr.z0) & (zs < Lr.z1)
+            for d in (1, 2, 3):
+                rows = gmesh.nodes["boundary_index"][(pc == d) & is_b & owned]
+                hh.update(np.ascontiguousarray(bd[d - 1][rows]["filter_memory"]).tobytes())
+            r_done, r_flag, r_hash, r_rows, _ = everyone[r]
+            ok = (r_done, r_flag) == (want_done, want_flag) and r_hash == hh.hexdigest() and \
+                all(rows == want_rows[:, pos].tobytes() for pos, rows in r_rows.items())
+            if not ok:
+                wrong.append(r)
+        return {"bitwise_equal": not wrong, "ranks_that_differ": wrong, "mesh": "%dx%dx%d fp64" % (nx, ny, nz), "steps": steps,
+                "two_step_passes_per_rank": [e[4] for e in everyone], "transport": args.transport,
+                "seconds": round(time.perf_counter() - t0, 2),
+                "what": "fields, filter memories and receiver rows of the chain against the single domain on rank 0, before the timed run"}
+    except BaseException as e:  # noqa: BLE001
+        return {"bitwise_equal": None, "error": "%s: %s" % (type(e).__name__, str(e)[:300]), "seconds": round(time.perf_counter() - t0, 2)}
 
 
 class _Guard:
@@ -240,6 +336,12 @@ def run_bench(args, guard):
     if rank == 0:
         build.build(verbose=False)
     if world > 1:
+        dist.barrier()
+
+    halo_parity = None
+    if world > 1 and not args.no_parity_check:
+        guard.phase = "chain parity check on this machine's links"
+        halo_parity = chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch)
         dist.barrier()
 
     elem = 4 if args.precision == "f32" else 8
@@ -419,6 +521,7 @@ def run_bench(args, guard):
                             if args.transport == "rccl" else
                             "face planes copied into the neighbours' IPC-mapped fields on a second stream, ordered by mailbox counters (two exchanges per two-step pass, both under the march); RCCL for the ranks' agreements and the flag OR only"),
                    "halo_measured": halo,
+                   "halo_parity": halo_parity,
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      # `frac`: at the MEASURED traffic when a PMC figure for this very kernel / workload / device code is on file

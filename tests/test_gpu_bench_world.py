@@ -60,9 +60,12 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
     assert r["unit"] == "Gnode-updates/s" and r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f64"
     assert r["config"]["workload"].startswith("%dx%dx%d box mesh" % (nx, ny, nz_global))
     assert r["config"]["decomposition"] == "z-slabs x%d" % world and "RCCL" in r["config"]["halo"]
+    # the chain checked itself against the single domain before the timed run, over the transport of the run
+    assert r["config"]["halo_parity"]["bitwise_equal"] is True and r["config"]["halo_parity"]["two_step_passes_per_rank"] == [12] * world, r["config"]["halo_parity"]
     if world == 4:   # the same chain with the planes on the IPC transport (processes sharing the GPU map each other's fields)
         r2 = run_bench(world, shm_mock, *(extra + ["--transport", "ipc"]))
         assert "IPC-mapped" in r2["config"]["halo"] and r2["roofline"]["launches"] > 0 and r2["value"] > 0
+        assert r2["config"]["halo_parity"]["bitwise_equal"] is True and r2["config"]["halo_parity"]["transport"] == "ipc"
     # value is the whole job: all nodes of all ranks x steps / (max-over-ranks) time
     assert r["value"] == pytest.approx(nx * ny * nz_global * steps / (r["ms_per_step"] * 1e-3 * steps) / 1e9, rel=1e-2)
     roof = r["roofline"]
@@ -83,7 +86,7 @@ def _run_failing_bench(world, shm_mock, env_extra, *extra, timeout=240):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rccl-library", shm_mock,
            "--no-cpu-baseline", "--no-reference-on-gpu", "--nx", "256", "--ny", "96", "--nz", "48", "--steps", "8", "--warmup", "4",
-           "--no-windows"] + [str(a) for a in extra]
+           "--no-windows", "--no-parity-check"] + [str(a) for a in extra]
     env = dict(os.environ)
     env.update(env_extra)
     t0 = time.perf_counter()
