@@ -765,7 +765,10 @@ void fire(Bridge&, Callback& callback, size_t step, size_t steps, std::false_typ
 /// copied aside on the device (wv_checkpoint: 2 fields + filter memories, about the traffic of one step); a look at step i
 /// of the batch rolls the engine back and re-runs i + 1 steps (bit-identical: the engine is deterministic), the rest of
 /// the batch is abandoned and run again later, and the run proceeds one step at a time until `hold_steps` steps have
-/// gone by unobserved.  `wanted_now()` (the bridge knows a reader is attached) keeps it at one step per batch too.
+/// gone by unobserved.  An observer that looks at regular intervals (a visualiser that takes every k-th step) is met half way: the
+/// interval between its last two looks is the guess for the next, and batches are cut so that the step it is expected to look at is
+/// the LAST of its batch -- whose field is on the device as it is: no rollback, nothing run twice; a look elsewhere falls back to the above.
+/// `wanted_now()` (the bridge knows a reader is attached) keeps it at one step per batch too.
 /// Without room for the checkpoint the run simply stays at one step per batch, like the reference's loop.
 template <typename Context, typename Mesh, typename It, typename MakeBridge, typename WantedNow, typename Observe>
 size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
@@ -784,6 +787,9 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
     const size_t n_recv = receivers.size();
     size_t done_total = 0, batch = 1, hold = 0;
     bool can_speculate = max_batch > 1;
+    constexpr size_t never = ~size_t{0};
+    size_t last_look = never, period = 0;  // the step last looked at; the interval between the last two looks
+    bool periodic = false;                 // the next look is expected at last_look + period
     std::vector<double> samples;
     const auto finish = [&] {
         uint64_t passes = 0;
@@ -795,6 +801,14 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
     try {
         while (done_total < signal.size() && keep_going) {
             size_t want = std::min(batch, signal.size() - done_total);
+            if (periodic && can_speculate) {
+                const size_t target = last_look + period;
+                if (target >= done_total) {
+                    want = std::min(std::min(max_batch, target + 1 - done_total), signal.size() - done_total);
+                } else {
+                    periodic = false;  // (the step came and went unobserved)
+                }
+            }
             if (wanted_now()) want = 1;
             if (want > 1) {
                 if (wv_checkpoint(e) == WV_OK) {
@@ -834,6 +848,12 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
                 if (guard.looked) {
                     looked = true;
                     ++stats.fields_looked_at;
+                    const size_t at = done_total + i;
+                    if (last_look != never) {  // (the interval between the last two looks is the guess for the next one)
+                        period = at - last_look;
+                        periodic = true;
+                    }
+                    last_look = at;
                 }
             }
             done_total += fired;
@@ -842,7 +862,10 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
                 if (done < want) break;
             }
             // pace: one step at a time while somebody is looking, doubling batches once nobody has for a while
-            if (looked) {
+            if (looked && periodic && period > 1) {
+                batch = std::min(max_batch, period);  // (whatever the prediction leaves over is planned from the observer's own interval)
+                hold = 0;
+            } else if (looked) {
                 batch = 1;
                 hold = hold_steps;
             } else if (hold > fired) {

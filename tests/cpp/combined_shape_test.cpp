@@ -395,8 +395,9 @@ int main(int argc, char** argv) {
                                     every_step[step].first.size() * sizeof(float)) == 0);
             }
             REQUIRE(stats.fields_mirrored == waveguide_node_pressures_changed_.got.size());
-            if (k == 7) REQUIRE(stats.rollbacks == 0 && stats.batches == steps);  // never more than 16 steps without a look
-            if (k >= 40) REQUIRE(stats.rollbacks >= 2 && stats.batches < steps);
+            if (k == 7) REQUIRE(stats.rollbacks == 0 && stats.steps_rerun == 0);  // never more than 16 steps without a look: the run never got ahead of one
+            // (the first look the run was ahead of costs a rollback; the interval it tells puts the later ones on the last step of a batch)
+            if (k >= 40) REQUIRE(stats.rollbacks >= 1 && stats.rollbacks <= 2 && stats.batches < steps / 2);
             std::printf("listener every %zu steps: %zu batches, %zu checkpoints, %zu rollbacks, %zu steps re-run of %zu\n", k, stats.batches,
                         stats.checkpoints, stats.rollbacks, stats.steps_rerun, steps);
         }
@@ -426,7 +427,7 @@ int main(int argc, char** argv) {
             for (size_t j = 0; j < fields.size(); ++j)
                 REQUIRE(std::memcmp(fields[j].data(), every_step[at[j]].first.data(), fields[j].size() * sizeof(float)) == 0);
             if (k == 1) REQUIRE(stats.rollbacks == 0 && stats.batches == steps);
-            if (k == 40) REQUIRE(stats.rollbacks >= 2);
+            if (k == 40) REQUIRE(stats.rollbacks >= 1 && stats.rollbacks <= 2);
             if (k == 0) REQUIRE(stats.rollbacks == 0 && stats.batches <= 12);  // 1 + 2 + 4 + ... steps per batch
             std::printf("handles, a look every %zu steps: %zu batches, %zu checkpoints, %zu rollbacks\n", k, stats.batches, stats.checkpoints,
                         stats.rollbacks);

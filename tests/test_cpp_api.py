@@ -40,6 +40,18 @@ def test_reference_style_cpp_tests_pass(built_library):
     assert "ALL OK" in p.stdout
 
 
+def test_canonical_runs_ahead_of_its_callback_and_comes_back_for_what_it_looks_at():
+    """tests/cpp/canonical_pacing_test.cpp: the header's own logic (batches, checkpoints, rollback + re-run for a look at a passed
+    step, the observer's interval as the guess for its next look, flags, keep_going, stats) against a stand-in engine whose field is
+    a closed-form function of (step, node) -- the translation unit defines the C ABI entry points itself and is not linked against
+    the library.  No GPU."""
+    src = os.path.join(ROOT, "tests", "cpp", "canonical_pacing_test.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "canonical_pacing_test")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "CANONICAL PACING OK" in p.stdout, p.stdout + p.stderr
+
+
 SHAPE_SRC = os.path.join(ROOT, "tests", "cpp", "combined_shape_test.cpp")
 SHAPE_EXE = os.path.join(ROOT, "tests", "cpp", "combined_shape_test")
 OPENCL_INCLUDE = "/opt/rocm/include"     # CL/cl.hpp, the bindings the reference uses (core/cl/include.h)
