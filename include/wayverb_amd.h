@@ -272,8 +272,8 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
 enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_QUERY_MARCH_LIVE_PERMILLE = 3,
        WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5, WV_QUERY_HALO_WAIT_NS = 6, WV_QUERY_HALO_WAITS = 7,
        WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10,
-       /* kernel timing on: total time of the two boundary launches of the two-step passes whose march was timed (nodes to t+1 / to t+2),
-        * over that many passes; reset by wv_kernel_time */
+       /* kernel timing on: total time of the two boundary launches of every eighth two-step pass whose march was timed (nodes to t+1 /
+        * to t+2), over that many passes; reset by wv_kernel_time */
        WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */

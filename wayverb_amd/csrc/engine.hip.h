@@ -232,6 +232,7 @@ private:
     double part_ms_[2] = {0, 0};
     uint64_t part_n_[2] = {0, 0};
     bool pass_timed_ = false;
+    unsigned part_timing_calls_ = 0;
     std::vector<uint32_t> plane_start_, plane_start_rest_;
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)

@@ -321,6 +321,7 @@ int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* ste
         part_ms_[p] = 0;
         part_n_[p] = 0;
     }
+    part_timing_calls_ = 0;
     return WV_OK;
 }
 
