@@ -12,10 +12,28 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
-def write_traffic_record(where, out, workload="1024x1024x1024 f64"):
+DEFAULT_WORKLOAD = "1024x1024x1024 f64"
+
+
+def workload_of(where):
+    """The workload the counted command ran, from the bench line its log holds ("768x768x768 f64"); the bench default when there is no log."""
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        try:
+            for line in reversed(open(os.path.join(where, "pmc_%s.log" % c)).read().splitlines()):
+                if line.startswith("{") and '"config"' in line:
+                    rec = json.loads(line)
+                    m = re.match(r"(\d+x\d+x\d+) ", rec["config"]["workload"])
+                    return "%s %s" % (m.group(1), rec["dtype"])
+        except (OSError, ValueError, KeyError, AttributeError):
+            pass
+    return DEFAULT_WORKLOAD
+
+
+def write_traffic_record(where, out, workload=DEFAULT_WORKLOAD):
     """profiles/traffic.json (+ a copy beside the summary): the measured HBM bytes per launch of the dominant kernel and of the two
     boundary launches of a pass, stamped with the device code they were measured on -- what bench.py quotes as roofline.traffic."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +60,11 @@ def write_traffic_record(where, out, workload="1024x1024x1024 f64"):
             level[1 if name.rstrip(">").rstrip().endswith("true") else 0] = total(c)
     if len(level) == 2:
         rec["boundary_hbm_bytes_per_launch"] = [level[0], level[1]]
-    for path in (os.path.join(where, "traffic.json"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")):
+    # the record bench.py reads (profiles/traffic.json) is the default workload's; another size leaves its record beside its summary only
+    paths = [os.path.join(where, "traffic.json")]
+    if workload == DEFAULT_WORKLOAD:
+        paths.append(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"))
+    for path in paths:
         json.dump(rec, open(path, "w"), indent=1)
     print("traffic record:", json.dumps({k: rec[k] for k in ("kernel_sources", "hbm_bytes_per_launch") if k in rec}), rec.get("boundary_hbm_bytes_per_launch"))
 
@@ -59,7 +81,7 @@ def main():
             for k, v in agg.items():
                 out.setdefault(k, {})[c] = {"mean_KiB": sum(v) / len(v), "n": len(v)}
     json.dump(out, open(os.path.join(where, "pmc_summary.json"), "w"), indent=1)
-    write_traffic_record(where, out)
+    write_traffic_record(where, out, workload_of(where))
     for k, v in sorted(out.items()):
         if "boundary_kernel" in k or "pair_march" in k or "stream_sweep" in k:
             f, w = v.get("FETCH_SIZE", {}).get("mean_KiB", 0), v.get("WRITE_SIZE", {}).get("mean_KiB", 0)
