@@ -117,7 +117,11 @@ typedef struct wv_tuning {
                                * wv_create (the x-facing walls' compact copies leave out the planes an early pass steps ahead) */
     int32_t pair_split_rows;  /* 1: rows of 3..8 waves are marched as two overlapping windows (two smaller workgroups per CU); measurement only */
     int32_t fuse_planes;      /* z-slabs: 1 = the planes stepped around the halo exchanges take ONE launch (sweep + their boundary entries side by side) */
-    int32_t reserved_[4];
+    int32_t whole_step;       /* single steps as ONE launch each (sweep workgroups and boundary workgroups side by side, the next step's source /
+                               * receiver work served by the tiles that own those nodes): -1 the engine decides by mesh size (small meshes are
+                               * bound by launches, not bytes), 1 / 0 force on / off.  Only where it is legal (one domain, the source and the
+                               * receivers -- at most 63 -- on inside nodes); otherwise two launches per step as ever */
+    int32_t reserved_[3];
 } wv_tuning;
 
 typedef struct wv_options {
@@ -274,7 +278,8 @@ enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_
        WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10,
        /* kernel timing on: total time of the two boundary launches of every eighth two-step pass whose march was timed (nodes to t+1 /
         * to t+2), over that many passes; reset by wv_kernel_time */
-       WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13 };
+       WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13,
+       WV_QUERY_WHOLE_STEPS = 14 /* single steps taken as one launch each (wv_tuning::whole_step) */ };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

@@ -134,7 +134,7 @@ def test_tuning_reaches_the_options_struct_and_unknown_fields_are_refused(built_
     assert opt.struct_size == ctypes.sizeof(E.WvOptions) and opt.precision == E.PRECISION_F64 and opt.stream_variant == 2
     t = opt.tuning
     assert (t.pair, t.pair_inner_fix, t.pair_wide, t.pair_unit_planes, t.tile_lists, t.fuse_pre_post, t.graph, t.boundary_lds,
-            t.boundary_order, t.boundary_xwall, t.slab_early, t.pair_split_rows, t.fuse_planes) == (-1, 1, 1, 32, 1, 1, 0, 1, 1, 1, -1, 0, 1)
+            t.boundary_order, t.boundary_xwall, t.slab_early, t.pair_split_rows, t.fuse_planes, t.whole_step) == (-1, 1, 1, 32, 1, 1, 0, 1, 1, 1, -1, 0, 1, -1)
     old = dict(E.default_tuning)
     try:
         E.default_tuning.clear()

@@ -314,11 +314,11 @@ def test_frequency_independent_walls_beside_filtered_ones(oracle, built_library,
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
-@pytest.mark.parametrize("n,tuning", [(40, {}), (168, {}), (168, {"pair": 0})])
+@pytest.mark.parametrize("n,tuning", [(40, {}), (168, {"pair": 1}), (168, {"pair": 0}), (168, {"whole_step": 0})])
 def test_checkpoint_and_rollback_reproduce_the_abandoned_steps(built_library, precision, n, tuning):
     """wv_checkpoint / wv_rollback (what `canonical` runs ahead of its observers on): after a rollback the engine continues
     from the checkpoint and reproduces the abandoned steps bit for bit -- fields, filter memories, receiver rows, step count
-    and position in the source signal -- on single steps (40^3) and on two-step passes (168^3), and a second rollback to the
+    and position in the source signal -- on single steps (40^3: one launch each by default) and on two-step passes (168^3), and a second rollback to the
     same checkpoint does so again."""
     from helpers import set_tuning
     set_tuning(**tuning)
@@ -342,8 +342,10 @@ def test_checkpoint_and_rollback_reproduce_the_abandoned_steps(built_library, pr
                     [eng.read_boundary_data(d).tobytes() for d in (1, 2, 3)], eng.fetch_receivers(0, 11 + steps).tobytes())
 
         first = rest(24)
-        if n >= 160 and not tuning:
+        if n >= 160 and tuning.get("pair", -1) != 0:
             assert eng.query(0) > 0                               # WV_QUERY_PASSES: the abandoned steps were two-step passes
+        if not tuning:
+            assert eng.query(eng.QUERY_WHOLE_STEPS) > 0           # (40^3, defaults: one launch per step)
         eng.rollback()
         assert eng.step_count() == 11
         assert rest(24) == first

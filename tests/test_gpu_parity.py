@@ -58,7 +58,8 @@ def test_every_stream_variant_matches_golden(env, tag):
 
 
 @pytest.mark.parametrize("env", [dict(graph=1), dict(fuse_pre_post=0), dict(boundary_lds=0),
-                                 dict(boundary_order=0), dict(graph=1, fuse_pre_post=0)],
+                                 dict(boundary_order=0), dict(graph=1, fuse_pre_post=0), dict(whole_step=0), dict(whole_step=1),
+                                 dict(whole_step=0, graph=1)],
                          ids=lambda e: "-".join("%s%s" % (k[3:], v) for k, v in e.items()))
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 def test_engine_switches_do_not_change_results(env, tag):

@@ -310,7 +310,7 @@ SlabComm::~SlabComm() {
         if (t.owner == this) t = DeviceTurn{};
     }
     for (hipEvent_t e : {halo_joined_, bulk_done_, faces_ready_, ghosts_ready_, pushed_lo_[0], pushed_lo_[1], pushed_lo_[2], pushed_lo_[3], pushed_hi_[0], pushed_hi_[1],
-                         pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_})
+                         pushed_hi_[2], pushed_hi_[3], step_done_[0], step_done_[1], reduce_in_, reduce_out_, sync_ev_})
         if (e) (void)hipEventDestroy(e);
     if (spread_) (void)hipFree(spread_);
     if (host_words_) (void)hipHostFree(host_words_);

@@ -203,4 +203,27 @@ struct PrePostArgs {
     int nx, ny, nz, pitch;
 };
 
+// One-launch steps (plane_kernels.hip.h, whole_step_kernel): the NEXT step's source sample and receiver samples are served by the
+// sweep workgroup that produces the node's value, from its registers, before the value is stored.
+struct StepDuty {
+    uint64_t node;   // stored index (an inside / re-entrant node: a sweep tile owns it)
+    uint32_t block;  // the sweep workgroup (arithmetic tile mapping, no work list) whose tile holds it
+    uint32_t col;    // receiver: column of the step's row
+    uint32_t kind;   // 0 receiver, 1 hard source, 2 soft source (a source's duty comes first in the list)
+    uint32_t pad_;
+};
+template <typename Real>
+struct StepDuties {
+    const StepDuty* list;  // [n], n <= 64
+    uint32_t n;
+    const double* signal;        // the source signal (device)
+    uint64_t signal_pos;         // sample of the NEXT step (relative to *signal_base when that is set)
+    const uint64_t* signal_base;
+    Real* recv_out;              // row of the next step: [n_recv]
+    const uint64_t* recv;        // [n_recv] stored indices (~0: not recorded, its column gets 0)
+    uint32_t n_recv;
+    int* next_flag;              // the next step's error_code word, reset here (null: leave it alone)
+    int flag_init;
+};
+
 }  // namespace wv

@@ -63,6 +63,11 @@ public:
                         bool levels = false, BoundaryLaunch* plan_only = nullptr);
     wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
+    // one-launch steps (plane_kernels.hip.h, whole_step_kernel): may this engine take them (synchronises once per source / receiver
+    // set: not inside a capture), and the launch itself
+    bool whole_step_ready();
+    bool whole_step_sized() const;  // small enough for the form to beat two-step passes too (the automatic choice)
+    int launch_whole_step(Real* prev, const Real* cur, int slot, uint64_t signal_pos, bool source_live, bool serve_next);
     // ---- engine_pair.hip.h
     bool pair_eligible();
     int ensure_pair();
@@ -200,6 +205,11 @@ private:
     bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
     bool io_unfaced_known_ = false, io_unfaced_ = false;
+    bool duties_known_ = false, duties_ok_ = false;  // whole_step_ready
+    wv::StepDuty* duties_ = nullptr;                  // [n_duties_] the source first, then the recorded receivers
+    uint32_t n_duties_ = 0;
+    uint64_t whole_steps_ = 0;                        // steps taken as one launch (WV_QUERY_WHOLE_STEPS)
+    uint64_t graph_whole_steps_ = 0;                  // ... by one replay of the captured batch
     bool pair_list_early_ok_ = false;             // ensure_pair
     bool pair_unit_waves_ = false;                // the unit list carries each unit's live waves (build_pair_units)
     int pair_windows_ = 0;                        // WIDE march: workgroups side by side per row (0: one)

@@ -144,6 +144,7 @@ uint64_t Engine<Real>::plan_batch(uint64_t remaining) {
         batch = std::min(batch, left);
     }
     batch_can_fuse_ = !comm_ && io_nodes_plain() && opt_.tuning.fuse_pre_post != 0;
+    (void)whole_step_ready();  // (looks at the class map once per source / receiver set: here, not inside a capture)
     batch_source_live_ = source_kind_ != WV_SOURCE_NONE;
     // nothing rides across batches: whatever a batch that failed half-way left behind does not count
     pre_post_done_ = pair_mid_done_ = pair_list_done_ = false;
@@ -358,6 +359,7 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_BOUNDARY1_NS: *value = (uint64_t)(part_ms_[0] * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_BOUNDARY2_NS: *value = (uint64_t)(part_ms_[1] * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_BOUNDARY_TIMED: *value = std::min(part_n_[0], part_n_[1]); return WV_OK;
+        case WV_QUERY_WHOLE_STEPS: *value = whole_steps_; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

@@ -34,6 +34,7 @@ int Engine<Real>::set_source(int kind, uint64_t node, const double* signal, uint
     signal_pos_ = 0;
     io_plain_known_ = false;
     io_unfaced_known_ = false;
+    duties_known_ = false;
     if (kind == WV_SOURCE_NONE) return WV_OK;
     source_node_ = stored_index(node);
     // a source in an outside node keeps writing non-zero values there: no work lists then
@@ -73,6 +74,7 @@ int Engine<Real>::set_receivers(const uint64_t* nodes, uint32_t n) {
     n_recv_ = n;
     io_plain_known_ = false;
     io_unfaced_known_ = false;
+    duties_known_ = false;
     return WV_OK;
 }
 

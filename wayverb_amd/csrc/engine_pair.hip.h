@@ -33,6 +33,9 @@ bool Engine<Real>::pair_eligible() {
         // pass now -- single steps held out up to 256^3.)  fp32: half the bytes for the same arithmetic; the
         // march was bound by its instruction stream (383 vs 444 at 1024^3) until div3: 532-558 vs 452.
         if (stored_nodes_ < pair_min_nodes_) return false;
+        // ... and while both fields live in the Infinity Cache, single steps of ONE launch each beat the passes (engine_single.hip.h,
+        // whole_step_ready: where the source / receiver nodes allow them)
+        if (opt_.tuning.whole_step != 0 && whole_step_sized() && whole_step_ready()) return false;
     }
     return true;
 }

@@ -557,6 +557,7 @@ void Engine<Real>::release() {
         if (p) (void)hipFree(p);
     if (flags_host_) (void)hipHostFree(flags_host_);
     if (recv_stage_) (void)hipHostFree(recv_stage_);
+    if (duties_) (void)hipFree(duties_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }

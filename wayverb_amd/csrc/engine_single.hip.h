@@ -250,6 +250,125 @@ wv::PrePostArgs<Real> Engine<Real>::pre_post_args(Real* cur, int slot, bool with
     return pp;
 }
 
+// ---- one launch per step (small meshes) ---------------------------------------------------------------------------------------
+// wv_tuning::whole_step = -1: one-launch steps while both fields sit well inside the 256 MB Infinity Cache -- up to there they beat
+// two launches per step AND two-step passes (us per step, one launch / passes; fp64: 160^3 36.8 / 38.5, 192^3 46.3 / 48.4, 224^3
+// 63.2 / 60.1-63.9, 256^3 79.7 / 75.3; fp32: 192^3 33.3 / 37.5, 256^3 48.6 / 52.1, 320^3, whose rows are stored 512 wide, 177 / 112:
+// profiles/r05/small_mesh_one_launch_steps.txt); beyond, a step is bound by HBM bytes and the march's 16 B per node-update win.
+constexpr uint64_t kWholeStepMaxBytes = 160ull << 20;  // (fp64: up to 192^3 as stored, 9.4 M nodes; fp32: 256^3)
+
+template <typename Real>
+bool Engine<Real>::whole_step_sized() const {
+    return 2ull * stored_nodes_ * sizeof(Real) <= kWholeStepMaxBytes;
+}
+
+// May the engine's single steps be one launch each (whole_step_kernel)?  The sweep in the product's shape, no slab chain, and the
+// source / receiver nodes (at most 64 duties) all inside or re-entrant nodes: the tile that produces such a node's value serves the
+// next step's sample / receiver column from its registers.  Looks at the class map once per source / receiver set (synchronises).
+template <typename Real>
+bool Engine<Real>::whole_step_ready() {
+    if (opt_.tuning.whole_step == 0 || comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
+    if (plan_.variant != 2 || plan_.ry != 4 || plan_.nwx != 1 || plan_.nwy != 4) return false;
+    if (opt_.tuning.whole_step < 0 && !whole_step_sized()) return false;
+    if (duties_known_) return duties_ok_;
+    duties_known_ = true;
+    duties_ok_ = false;
+    if (n_recv_ > 63) return false;
+    std::vector<uint64_t> recv(n_recv_);
+    if (n_recv_ && hipMemcpy(recv.data(), recv_nodes_, (size_t)n_recv_ * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    constexpr int WX = 64 * (16 / (int)sizeof(Real));
+    const int nzr = z_end_ - z_begin_;
+    const int per_plane = plan_.tiles_x * plan_.tiles_y_stripe;
+    // block index of the sweep workgroup whose tile holds stored node idx: the inverse of stream_sweep_body's arithmetic mapping
+    auto duty = [&](uint64_t idx, uint32_t col, uint32_t kind, wv::StepDuty* out) -> bool {
+        const int x = (int)(idx % (uint64_t)pitch_);
+        const uint64_t row = idx / (uint64_t)pitch_;
+        const int y = (int)(row % (uint64_t)ny_), z = (int)(row / (uint64_t)ny_);
+        uint32_t cls = 0;
+        if (z < z_begin_ || z >= z_end_ || class_of((uint64_t)x, row, &cls) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (!(cls & 1u)) return false;  // a boundary node's value comes from a boundary workgroup, an outside node's from nobody
+        const int stripe = y / plan_.stripe_rows;
+        const int tl = ((y - stripe * plan_.stripe_rows) / 16) * plan_.tiles_x + x / WX;  // (tiles of RY 4 x NWY 4 rows)
+        const uint32_t j = (uint32_t)(((stripe / 8) * nzr + (z - z_begin_)) * per_plane + tl);
+        *out = wv::StepDuty{idx, j * 8u + (uint32_t)(stripe % 8), col, kind, 0u};
+        return true;
+    };
+    std::vector<wv::StepDuty> list;
+    wv::StepDuty q{};
+    if (source_kind_ != WV_SOURCE_NONE) {
+        if (!duty(source_node_, 0u, source_kind_ == WV_SOURCE_HARD ? 1u : 2u, &q)) return false;
+        list.push_back(q);
+    }
+    for (uint32_t c = 0; c < n_recv_; ++c) {
+        if (recv[c] == ~0ull) continue;  // (its column is zeroed by the launch's first workgroup)
+        if (!duty(recv[c], c, 0u, &q)) return false;
+        list.push_back(q);
+    }
+    if (!duties_ && hipMalloc((void**)&duties_, 64 * sizeof(wv::StepDuty)) != hipSuccess) {
+        (void)hipGetLastError();
+        duties_ = nullptr;
+        return false;
+    }
+    if (hipStreamSynchronize(stream_) != hipSuccess) return false;  // (no launch in flight reads the old list)
+    if (!list.empty() && hipMemcpy(duties_, list.data(), list.size() * sizeof(wv::StepDuty), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    n_duties_ = (uint32_t)list.size();
+    duties_ok_ = true;
+    return true;
+}
+
+// One step = one launch: the boundary entries' workgroups and the sweep's (masked stores, every tile: no work list) side by side.
+// `serve_next`: the launch also puts step slot + 1's source sample in place, records its receiver row and resets its flag word.
+template <typename Real>
+int Engine<Real>::launch_whole_step(Real* prev, const Real* cur, int slot, uint64_t signal_pos, bool source_live, bool serve_next) {
+    int* flag = flags_ + slot;
+    StreamLaunch sw;
+    BoundaryLaunch bd;
+    int rc = launch_stream(prev, cur, flag, z_begin_, z_end_, false, nullptr, 0, 0, &sw);
+    if (rc) return rc;
+    sw.args.tile_list = nullptr;
+    sw.grid = 8u * (unsigned)plan_.passes * (unsigned)(z_end_ - z_begin_) * (unsigned)(sw.args.tiles_x * sw.args.tiles_y_stripe);
+    if ((rc = launch_boundary(prev, cur, flag, z_begin_, z_end_, nullptr, nullptr, false, false, &bd))) return rc;
+    if (!n_entries_) bd.args = boundary_args(prev, cur, flag);
+    wv::StepDuties<Real> d{};
+    if (serve_next) {
+        const bool has_source_duty = n_duties_ && source_kind_ != WV_SOURCE_NONE;
+        d.list = duties_ + (has_source_duty && !source_live ? 1 : 0);
+        d.n = n_duties_ - (has_source_duty && !source_live ? 1u : 0u);
+        d.signal = signal_;
+        d.signal_pos = signal_pos + 1;
+        d.signal_base = graph_capturing_ ? signal_base_dev_ : nullptr;
+        d.recv_out = recv_out_ ? recv_out_ + (size_t)(slot + 1) * std::max<uint32_t>(n_recv_, 1) : nullptr;
+        d.recv = recv_nodes_;
+        d.n_recv = n_recv_;
+        d.next_flag = flags_ + slot + 1;
+        d.flag_init = static_flag_;
+    }
+    const bool timed = !on_ && time_this_launch();
+    if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+    bd.blocks = (bd.blocks + 7u) & ~7u;  // (the boundary workgroups come first; the sweep's workgroup j runs on XCD j % 8: keep that)
+    const dim3 grid(bd.blocks + sw.grid), block(256);
+    if (bd.blocks && bd.lds)
+        hipLaunchKernelGGL((wv::whole_step_kernel<Real, true>), grid, block, 0, st(), sw.args, bd.args, d, (uint32_t)bd.blocks);
+    else
+        hipLaunchKernelGGL((wv::whole_step_kernel<Real, false>), grid, block, 0, st(), sw.args, bd.args, d, (uint32_t)bd.blocks);
+    if (timed) {
+        WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+        timed_steps_ += 1;
+    }
+    ++whole_steps_;
+    return WV_OK;
+}
+
 // `fuse_next` (1: a single step follows in this batch, 2: a two-step pass): what follows gets its pre/post
 // work done by this step's boundary launch instead of a launch of its own -- one launch less per
 // step, which is what small meshes are bound by.
@@ -284,6 +403,10 @@ int Engine<Real>::enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos
         if ((rc = launch_stream(prev, cur, flag, zi0, zi1, true))) return rc;
         if (!comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
         if ((rc = launch_boundary(prev, cur, flag, zi0, zi1))) return rc;
+    } else if (fuse_next != 2 && whole_step_ready()) {
+        // (the duties were looked up when the batch was planned: nothing synchronises here)
+        if ((rc = launch_whole_step(prev, cur, slot, signal_pos, source_live, fuse_next == 1))) return rc;
+        pre_post_done_ = fuse_next == 1;
     } else {
         if ((rc = launch_stream(prev, cur, flag, z_begin_, z_end_, true))) return rc;
         if (fuse_next && n_entries_) {
@@ -324,7 +447,9 @@ int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) 
             if (rc) return rc;
         }
         (void)io_nodes_plain();
+        (void)whole_step_ready();
         const int cur_before = cur_, prv_before = prv_;
+        const uint64_t whole_before = whole_steps_;
         hipGraph_t graph = nullptr;
         WV_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         graph_capturing_ = true;
@@ -337,6 +462,8 @@ int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) 
         const hipError_t end = hipStreamEndCapture(stream_, &graph);
         cur_ = cur_before;
         prv_ = prv_before;
+        graph_whole_steps_ = whole_steps_ - whole_before;  // (counted per replay, not per capture)
+        whole_steps_ = whole_before;
         if (rc != WV_OK) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
@@ -349,6 +476,7 @@ int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) 
     }
     WV_HIP(hipMemcpyAsync(signal_base_dev_, &signal_pos_, sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
     WV_HIP(hipGraphLaunch(graph_exec_, stream_));
+    whole_steps_ += graph_whole_steps_;
     // batch is even: the fields are back in their roles
     // A replay runs no host code of enqueue_step: what that clears per step has to be cleared here -- the fields have moved
     // on without the x-facing walls' compact copies (a two-step pass after this must refill them), and every plane has

@@ -24,4 +24,29 @@ __global__ void __launch_bounds__(256) plane_step_kernel(const StreamArgs<Real> 
     }
 }
 
+// A whole step of a small mesh in ONE launch: the same two halves side by side over every owned plane, and the NEXT step's source
+// sample, receiver row and flag word served on the way (StepDuties: by the tile that produces the node's value, from its registers;
+// legal when every such node is an inside node -- the engine checks, engine_single.hip.h).  Below about 160^3 a step is two dependent
+// launches of 5-6 us each, each of them a chain of dependent loads however little it moves (a 32^3 sweep: 5 us); here the two chains
+// run beside each other and the stream sees one launch per step.  Same arithmetic, same bits.
+template <typename Real, bool LDSC>
+__global__ void __launch_bounds__(256) whole_step_kernel(const StreamArgs<Real> s, const BoundaryArgs<Real> b, const StepDuties<Real> d,
+                                                         const uint32_t boundary_blocks) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {  // what nobody else in this launch touches: the next step's flag word, columns of unrecorded receivers
+        if (threadIdx.x == 0 && d.next_flag) *d.next_flag = d.flag_init;
+        for (uint32_t r = threadIdx.x; r < d.n_recv; r += 64)
+            if (d.recv[r] == ~0ull) d.recv_out[r] = Real(0);
+    }
+    // The boundary entries' workgroups come FIRST in the grid: a boundary node is ~150 dependent instructions behind a chain of loads,
+    // the longest-lived workgroups of the step -- dispatched first they run under the sweep instead of after it (measured: 5-13 % of
+    // a step between 64^3 and 160^3 against "sweep first").  `boundary_blocks` is a multiple of 8, so that sweep workgroup j still
+    // lands on XCD j % 8.
+    if (blockIdx.x >= boundary_blocks) {
+        stream_sweep_body<Real, 4, 1, 4, ((X_SWEEP & ~X_STORE_ALL) | X_DUTIES)>(s, blockIdx.x - boundary_blocks, &d);
+    } else {
+        PrePostArgs<Real> none{};
+        boundary_body<Real, LDSC, false>(b, none, blockIdx.x, boundary_blocks);
+    }
+}
+
 }  // namespace wv

@@ -23,7 +23,8 @@ namespace wv {
 // to price a piece of the kernel; the nt ones are result-neutral cache hints.
 enum : int { X_NO_EDGE = 1, X_NO_CLS = 2, X_MUL_THIRD = 4, X_NT_STORE = 8, X_NT_PREV = 16, X_NT_CUR = 32,
              X_NO_HALO_ROWS = 64, X_TX_FAST = 128, X_NT_BELOW = 256, X_NT_MID = 512,
-             X_STORE_ALL = 1024 };  // boundary nodes get their old value written back: no masked stores
+             X_STORE_ALL = 1024,    // boundary nodes get their old value written back: no masked stores
+             X_DUTIES = 2048 };     // one-launch steps: the tile serves the next step's source / receiver samples at its nodes (StepDuties)
 // what the engine runs: `prev` and `next` are touched exactly once per step, so they carry the
 // non-temporal hint and do not displace the re-used `cur` lines from L2
 constexpr int X_PRODUCT = X_TX_FAST | X_NT_STORE | X_NT_PREV;
@@ -414,8 +415,38 @@ __global__ void __launch_bounds__(64 * NWX * NWY) stream_sweep_nolds_kernel(cons
 // (The body is a device function so that plane_step_kernel, boundary_kernels.hip.h, can run it beside the boundary entries of
 // the same planes in one launch -- there with masked stores, X = X_SWEEP & ~X_STORE_ALL, so that it leaves boundary nodes alone.
 // `block`: this workgroup's index among the sweep's workgroups.)
+// One-launch steps: the duties in `mine` (bit i = entry i of d.list) belong to this workgroup's tile; `out` holds the new values of
+// this lane's VX nodes from stored index `at` on.  The NEXT step's source sample goes into the value before it is stored
+// (hard_source.h:21 / soft_source.h:21-24), its receivers take what the node then holds (waveguide.h:121) -- a source's duty comes
+// first in the list, so a receiver on the source node reads the value with the sample in, as pre_post_body has it.
+template <typename Real>
+__device__ __forceinline__ void serve_duties(const StepDuties<Real>& d, uint64_t mine, int64_t at, typename Vec16<Real>::type& out) {
+    constexpr int VX = Vec16<Real>::N;
+    while (mine) {
+        const int i = __builtin_ctzll(mine);
+        mine &= mine - 1;
+        const StepDuty q = d.list[i];  // (wave-uniform)
+        const int64_t off = (int64_t)q.node - at;
+        if (off >= 0 && off < VX) {
+            Real v = 0;
+#pragma unroll
+            for (int j = 0; j < VX; ++j)
+                if (off == j) v = out[j];
+            if (q.kind) {
+                const Real s = (Real)d.signal[d.signal_pos + (d.signal_base ? *d.signal_base : 0ull)];
+                v = q.kind == 1 ? s : (Real)(v + s);
+#pragma unroll
+                for (int j = 0; j < VX; ++j)
+                    if (off == j) out[j] = v;
+            } else {
+                d.recv_out[q.col] = v;
+            }
+        }
+    }
+}
+
 template <typename Real, int RY, int NWX, int NWY, int X>
-__device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, unsigned block) {
+__device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, unsigned block, const StepDuties<Real>* d = nullptr) {
     using V = typename Vec16<Real>::type;
     constexpr int WX = TileIO<Real>::WX;
     __shared__ V halo[NWY][NWX][2][64];
@@ -462,11 +493,13 @@ __device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, uns
     V below[RY], mid[RY + 2], above[RY], pv[RY];
     uint32_t cl[RY];
     Real mid_e = 0;
+    uint32_t duty_block = ~0u;  // (X_DUTIES) lane i: the workgroup duty i belongs to
     if (active) {
         // ---- everything this tile needs from memory, issued back to back
         // (the rows that go through LDS first: they are needed before the barrier)
 #pragma unroll
         for (int r = 0; r < RY; ++r) mid[r + 1] = io.template cur_row<false>(y0 + r, z);  // L2: was z+1 a plane ago
+        if ((X & X_DUTIES) && lane < (int)d->n) duty_block = d->list[lane].block;
         if (!from_lo) mid[0] = io.template cur_row<false>(y0 - 1, z);
         if (!from_hi) mid[RY + 1] = io.template cur_row<false>(y0 + RY, z);
 #pragma unroll
@@ -491,12 +524,13 @@ __device__ __forceinline__ void stream_sweep_body(const StreamArgs<Real>& a, uns
     if (from_hi) mid[RY + 1] = halo[wy + 1][wx][0][lane];
 
     int bad = 0;
+    const uint64_t my_duties = (X & X_DUTIES) ? __ballot(duty_block == block) : 0ull;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         if (y0 + r < y_hi) {
             bool skip = false;
-            const V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r], bad,
-                                              skip);
+            V out = update_row<Real, X>(mid[r + 1], mid[r], mid[r + 2], below[r], above[r], pv[r], mid_e, r, cl[r], bad, skip);
+            if ((X & X_DUTIES) && my_duties) serve_duties<Real>(*d, my_duties, io.at(y0 + r, z), out);
             store_row<Real, X>(a.next + io.at(y0 + r, z), out, cl[r], skip);
         }
     }

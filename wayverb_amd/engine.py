@@ -47,12 +47,12 @@ class WvMesh(C.Structure):
 
 TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "pair_units_by_chunk", "tile_lists",
                  "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_xwall",
-                 "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks", "slab_early", "pair_split_rows", "fuse_planes")
+                 "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks", "slab_early", "pair_split_rows", "fuse_planes", "whole_step")
 
 
 class WvTuning(C.Structure):
     """wv_tuning (include/wayverb_amd.h): how the engine does its work, never what it computes."""
-    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 4)]
+    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 3)]
 
 
 class WvOptions(C.Structure):
@@ -480,6 +480,7 @@ class Engine:
     QUERY_PASSES, QUERY_XWALL_ENTRIES, QUERY_FIELDS, QUERY_MARCH_LIVE_PERMILLE, QUERY_SWEEP_LIVE_PERMILLE, QUERY_MARCH_ROUNDS = 0, 1, 2, 3, 4, 5
     QUERY_HALO_WAIT_NS, QUERY_HALO_WAITS, QUERY_HALO_EXCHANGES, QUERY_HALO_BYTES_SENT, QUERY_EARLY_PASSES = 6, 7, 8, 9, 10
     QUERY_BOUNDARY1_NS, QUERY_BOUNDARY2_NS, QUERY_BOUNDARY_TIMED = 11, 12, 13
+    QUERY_WHOLE_STEPS = 14
 
     def query(self, what):
         """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
