@@ -576,6 +576,25 @@ def run_bench(args, guard):
         dt = time.perf_counter() - t0
         out["config"]["also_256cubed_gnode_per_s"] = round(256 ** 3 * 2000 / dt / 1e9, 2)
         e2.close()
+        # ... and the launch-bound end of the size range: one launch per step there (wv_tuning::whole_step; plane_kernels.hip.h)
+        small = {}
+        for n in (64, 128):
+            m3 = M.box_mesh(n, n, n, coefficients=M.bench_materials(), surface_of_face=[0, 1, 2, 3, 2, 3])
+            e3 = E.Engine(m3, precision=args.precision, device=local_rank)
+            sig = np.zeros(10000)
+            sig[0] = 1.0
+            e3.set_source(E.SOURCE_HARD, m3.compute_index(n // 2, n // 2, n // 2), sig)
+            e3.set_receivers([m3.compute_index(n // 2 + 3, n // 2, n // 2)])
+            e3.run_steps(1000)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e3.run_steps(8000)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            small["%d^3" % n] = {"us_per_step": round(dt / 8000 * 1e6, 2), "gnode_per_s": round(n ** 3 * 8000 / dt / 1e9, 2),
+                                 "one_launch_steps": e3.query(e3.QUERY_WHOLE_STEPS)}
+            e3.close()
+        out["config"]["also_small_meshes"] = small
 
     if world == 1 and rank == 0 and not args.no_reference_on_gpu:
         # the reference's own OpenCL program, JIT-compiled by this box's OpenCL runtime and run on this
