@@ -467,6 +467,8 @@ def run_bench(args, guard):
     # kernel would have to sustain to keep up -- above the HBM peak is the point of the two-step pass
     per_update_equiv = 3 * elem * nx * ny * timed_planes * steps_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     kernel_name = "pair_march_kernel" if two_step else "stream_sweep_kernel"
+    if not two_step and world == 1 and eng.query(eng.QUERY_WHOLE_STEPS) > 0:
+        kernel_name = "whole_step_kernel"  # (a mesh that lives in the Infinity Cache: the step's sweep AND boundary work in one launch)
     # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
     # when it was measured on this very device code, this kernel and this workload
     traffic = None
