@@ -137,12 +137,13 @@ def test_a_receiver_on_a_boundary_node_keeps_two_launches_per_step(oracle, tag):
 
 
 def test_changing_the_receivers_between_runs_is_noticed(oracle):
-    """The duty list is made once per source / receiver set: a second run with other receivers (one of them on a boundary node,
-    then inside nodes again) must not be served from the first run's list."""
+    """The duty list is made once per source / receiver set and sweep plan: a second run with other receivers (one of them on a
+    boundary node, then inside nodes again), and a run after wv_set_stream_tuning has changed the stripes, must not be served from a
+    stale list."""
     from wayverb_amd import engine as E
-    case = _case((40, 24, 20), seed=4, steps=30, source_kind=2)
+    case = _case((40, 40, 20), seed=4, steps=40, source_kind=2)
     ci = case["mesh"].compute_index
-    sets = [case["recv"], [ci(1, 2, 2), ci(5, 5, 5)], [ci(6, 6, 6), ci(20, 12, 10), ci(7, 6, 6)]]
+    sets = [case["recv"], [ci(1, 2, 2), ci(5, 5, 5)], [ci(6, 6, 6), ci(20, 30, 10), ci(7, 22, 6)]]
     out = {}
     for whole in (1, 0):
         set_tuning(whole_step=whole, pair=0)
@@ -153,7 +154,9 @@ def test_changing_the_receivers_between_runs_is_noticed(oracle):
             eng.write_field(cur, E.BUF_CURRENT)
             eng.set_source(2, case["source_node"], case["signal"])
             rows, counts = [], []
-            for r in sets:
+            for i, r in enumerate(sets + [sets[2]]):
+                if i == 3:
+                    eng.set_stream_tuning(2, 4, 1, 4, 32)  # other stripes: the tiles' workgroup numbers change with them
                 eng.set_receivers(r)
                 first = eng.step_count()
                 done, flag = eng.run_steps(10)
@@ -163,7 +166,7 @@ def test_changing_the_receivers_between_runs_is_noticed(oracle):
             out[whole] = (rows, counts, eng.read_field(E.BUF_CURRENT))
         finally:
             eng.close()
-    assert out[1][1] == [10, 10, 20] and out[0][1] == [0, 0, 0]
+    assert out[1][1] == [10, 10, 20, 30] and out[0][1] == [0, 0, 0, 0]
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(a, b)
     assert out[1][2].tobytes() == out[0][2].tobytes()

@@ -338,6 +338,7 @@ int Engine<Real>::build_plane_order() {
 template <typename Real>
 void Engine<Real>::plan_stream() {
     lists_built_ = false;  // tile shapes may change
+    duties_known_ = false;  // (... and with them the workgroup that owns a source / receiver node: whole_step_ready)
     StreamPlan& p = plan_;
     constexpr int VX = 16 / (int)sizeof(Real);
     constexpr int WX = 64 * VX;
