@@ -14,7 +14,8 @@ from wayverb_amd import mesh as M
 pytestmark = pytest.mark.gpu
 
 MODES = {"default": {}, "passes": dict(pair=1), "passes-list-only": dict(pair=1, pair_inner_fix=0),
-         "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0)}
+         "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0),  # (one launch each where the source / receivers allow)
+         "two-launch-steps": dict(pair=0, whole_step=0)}
 
 
 def random_case(seed):
@@ -109,7 +110,7 @@ def test_speckled_rooms_in_degenerate_meshes(oracle, built_library, seed):
     prev_o, cur_o = prev.astype(dtype), cur.astype(dtype)
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
     want_steps, want_flag, want_trace = oracle.run(prev_o, cur_o, mesh, bd, kind, src, case["signal"], steps, case["recv"], threads=2)
-    for env in ({}, dict(pair=1), dict(pair=0)):
+    for env in ({}, dict(pair=1), dict(pair=0), dict(pair=0, whole_step=0)):
         set_tuning(**env)
         eng = E.Engine(mesh, precision=tag)
         try:
