@@ -136,17 +136,18 @@ def test_a_receiver_on_a_boundary_node_keeps_two_launches_per_step(oracle, tag):
     _assert_same(got, want)
 
 
-def test_changing_the_receivers_between_runs_is_noticed(oracle):
+@pytest.mark.parametrize("graph", [0, 1], ids=["plain-launches", "graph-replays"])
+def test_changing_the_receivers_between_runs_is_noticed(oracle, graph):
     """The duty list is made once per source / receiver set and sweep plan: a second run with other receivers (one of them on a
     boundary node, then inside nodes again), and a run after wv_set_stream_tuning has changed the stripes, must not be served from a
-    stale list."""
+    stale list -- nor, with wv_tuning::graph, from a batch captured before the change (runs of 16 steps: replayed as hipGraphs)."""
     from wayverb_amd import engine as E
-    case = _case((40, 40, 20), seed=4, steps=40, source_kind=2)
+    case = _case((40, 40, 20), seed=4, steps=80, source_kind=2)
     ci = case["mesh"].compute_index
     sets = [case["recv"], [ci(1, 2, 2), ci(5, 5, 5)], [ci(6, 6, 6), ci(20, 30, 10), ci(7, 22, 6)]]
     out = {}
     for whole in (1, 0):
-        set_tuning(whole_step=whole, pair=0)
+        set_tuning(whole_step=whole, pair=0, graph=graph)
         eng = E.Engine(case["mesh"], precision="f64")
         try:
             prev, cur = initial_fields(case, np.float64)
@@ -154,19 +155,24 @@ def test_changing_the_receivers_between_runs_is_noticed(oracle):
             eng.write_field(cur, E.BUF_CURRENT)
             eng.set_source(2, case["source_node"], case["signal"])
             rows, counts = [], []
-            for i, r in enumerate(sets + [sets[2]]):
+            for i, r in enumerate(sets + [sets[2], sets[0]]):
                 if i == 3:
                     eng.set_stream_tuning(2, 4, 1, 4, 32)  # other stripes: the tiles' workgroup numbers change with them
                 eng.set_receivers(r)
                 first = eng.step_count()
-                done, flag = eng.run_steps(10)
-                assert done == 10 and flag == 0
-                rows.append(eng.fetch_receivers(first, 10))
+                done, flag = eng.run_steps(16)
+                assert done == 16 and flag == 0
+                rows.append(eng.fetch_receivers(first, 16))
                 counts.append(eng.query(eng.QUERY_WHOLE_STEPS))
             out[whole] = (rows, counts, eng.read_field(E.BUF_CURRENT))
         finally:
             eng.close()
-    assert out[1][1] == [10, 10, 20, 30] and out[0][1] == [0, 0, 0, 0]
+            set_tuning()
+    assert out[1][1] == [16, 16, 32, 48, 64] and out[0][1] == [0, 0, 0, 0, 0]
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(a, b)
     assert out[1][2].tobytes() == out[0][2].tobytes()
+    # ... and both are what the oracle makes of the same 80 steps (the receivers of the last run: the first set again)
+    want = run_oracle(oracle, case, np.float64, threads=4)
+    assert want["current"].tobytes() == out[1][2].tobytes()
+    assert np.array_equal(out[1][0][4], want["trace"][64:80])

@@ -170,11 +170,12 @@ private:
         uint64_t signal_ptr, recv_ptr;
         bool lists;
         uint64_t cur_ptr, prv_ptr;
+        uint64_t io_generation;  // set_source / set_receivers calls so far: the one-launch steps' duty count and legality are baked into the capture
         bool operator==(const GraphKey& o) const {
             return batch == o.batch && cur == o.cur && source_live == o.source_live && can_fuse == o.can_fuse &&
                    n_recv == o.n_recv && source_node == o.source_node && source_kind == o.source_kind &&
                    signal_ptr == o.signal_ptr && recv_ptr == o.recv_ptr && lists == o.lists && cur_ptr == o.cur_ptr &&
-                   prv_ptr == o.prv_ptr;
+                   prv_ptr == o.prv_ptr && io_generation == o.io_generation;
         }
     };
     hipGraphExec_t graph_exec_ = nullptr;
@@ -210,6 +211,7 @@ private:
     uint32_t n_duties_ = 0;
     uint64_t whole_steps_ = 0;                        // steps taken as one launch (WV_QUERY_WHOLE_STEPS)
     uint64_t graph_whole_steps_ = 0;                  // ... by one replay of the captured batch
+    uint64_t io_generation_ = 0;                      // bumped by set_source / set_receivers (GraphKey)
     bool pair_list_early_ok_ = false;             // ensure_pair
     bool pair_unit_waves_ = false;                // the unit list carries each unit's live waves (build_pair_units)
     int pair_windows_ = 0;                        // WIDE march: workgroups side by side per row (0: one)

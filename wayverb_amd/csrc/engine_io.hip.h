@@ -35,6 +35,7 @@ int Engine<Real>::set_source(int kind, uint64_t node, const double* signal, uint
     io_plain_known_ = false;
     io_unfaced_known_ = false;
     duties_known_ = false;
+    ++io_generation_;
     if (kind == WV_SOURCE_NONE) return WV_OK;
     source_node_ = stored_index(node);
     // a source in an outside node keeps writing non-zero values there: no work lists then
@@ -75,6 +76,7 @@ int Engine<Real>::set_receivers(const uint64_t* nodes, uint32_t n) {
     io_plain_known_ = false;
     io_unfaced_known_ = false;
     duties_known_ = false;
+    ++io_generation_;
     return WV_OK;
 }
 

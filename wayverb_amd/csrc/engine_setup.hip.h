@@ -339,6 +339,12 @@ template <typename Real>
 void Engine<Real>::plan_stream() {
     lists_built_ = false;  // tile shapes may change
     duties_known_ = false;  // (... and with them the workgroup that owns a source / receiver node: whole_step_ready)
+    if (graph_exec_) {
+        // a captured batch holds the old plan's launches: their work list is about to be freed, their duty list to be rewritten
+        (void)hipStreamSynchronize(stream_);
+        (void)hipGraphExecDestroy(graph_exec_);
+        graph_exec_ = nullptr;
+    }
     StreamPlan& p = plan_;
     constexpr int VX = 16 / (int)sizeof(Real);
     constexpr int WX = 64 * VX;

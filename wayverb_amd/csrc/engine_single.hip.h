@@ -434,7 +434,7 @@ int Engine<Real>::replay_batch(uint64_t batch, bool source_live, bool can_fuse) 
     // allocates new ones, and after passes `cur_` / `prv_` may name any two of the four)
     const GraphKey key{batch, cur_, source_live, can_fuse, n_recv_, source_node_, source_kind_, (uint64_t)(uintptr_t)signal_,
                        (uint64_t)(uintptr_t)recv_nodes_, lists_built_ && tile_list_ != nullptr,
-                       (uint64_t)(uintptr_t)field_[cur_], (uint64_t)(uintptr_t)field_[prv_]};
+                       (uint64_t)(uintptr_t)field_[cur_], (uint64_t)(uintptr_t)field_[prv_], io_generation_};
     if (!graph_exec_ || !(key == graph_key_)) {
         if (graph_exec_) {
             (void)hipGraphExecDestroy(graph_exec_);
