@@ -176,3 +176,19 @@ def test_changing_the_receivers_between_runs_is_noticed(oracle, graph):
     want = run_oracle(oracle, case, np.float64, threads=4)
     assert want["current"].tobytes() == out[1][2].tobytes()
     assert np.array_equal(out[1][0][4], want["trace"][64:80])
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_more_stripes_than_xcds(oracle, tag):
+    """19 stripes of 16 rows (wv_tuning::stream_zchunks = 16 on 300 rows): the sweep's workgroups are dealt to the XCDs in three rounds
+    of stripes, and the owner of a source / receiver node has to be found in the right round (rows 5, 150, 290; the source in
+    stripe 9)."""
+    dtype = np.float32 if tag == "f32" else np.float64
+    case = _case((40, 300, 9), seed=12, steps=14, source_kind=2)
+    ci = case["mesh"].compute_index
+    case["source_node"] = ci(14, 150, 4)
+    case["recv"] = [ci(20, 5, 4), ci(14, 150, 4), ci(3, 290, 6), ci(36, 150, 2), ci(15, 151, 4), ci(30, 297, 4)]
+    want = run_oracle(oracle, case, dtype, threads=4)
+    for stripes in (16, 48, 0):
+        got = _run(case, tag, whole_step=1, pair=0, stream_zchunks=stripes)
+        assert got["whole"] == 14
+        _assert_same(got, want)
