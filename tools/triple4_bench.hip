@@ -83,10 +83,12 @@ __global__ void box_map_kernel(uint8_t* map, int nx, int ny, int nz, int cls_pit
 
 template <typename Real>
 struct Bench {
-    static constexpr int WX = 64 * (wv::kTripleLaneBytes / (int)sizeof(Real));  // columns per wave
+    int lb = 8;  // bytes of a row per lane
     static constexpr int PX = 64 * (16 / (int)sizeof(Real));                     // the engine's pitch granularity
     int* flags = nullptr;
     bool full_first = true;
+    bool dma = false;
+    int wx() const { return 64 * (lb / (int)sizeof(Real)); }  // columns per wave
 
     wv::TripleArgs<Real> make_args(const Real* prev, const Real* cur, Real* o1, Real* o2, Real* o3, const uint8_t* map, int pitch, int ny, int nz, int chunks) {
         if (!flags) {
@@ -109,7 +111,7 @@ struct Bench {
         a.z_end = nz;
         uint8_t win[4][wv::kTripleMaxWindows];
         int widest = 0;
-        a.windows = wv::triple_windows(pitch / WX, win, &widest, full_first);
+        a.windows = wv::triple_windows(pitch / wx(), win, &widest, full_first, dma ? wv::kTripleMaxWavesDma : wv::triple_max_waves(lb));
         if (a.windows < 0) {
             printf("row too long\n");
             exit(1);
@@ -128,16 +130,24 @@ struct Bench {
         return a;
     }
 
-    template <int X>
-    void launch(const wv::TripleArgs<Real>& a) {
+    template <int X, bool DMA = false, int LB = 8>
+    void launch_lb(const wv::TripleArgs<Real>& a) {
         static bool set = false;
         if (!set) {
-            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, X>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, X, DMA, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             set = true;
         }
         const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)a.chunks * (unsigned)(a.windows ? a.windows : 1);
-        hipLaunchKernelGGL((wv::triple_march_kernel<Real, X>), dim3(grid), dim3(64u * (unsigned)a.nw), wv::triple_lds_bytes(a.nw), 0, a);
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, X, DMA, LB>), dim3(grid), dim3(64u * (unsigned)a.nw), wv::triple_lds_bytes(a.nw, DMA, LB), 0, a);
         CK(hipGetLastError());
+    }
+    template <int X, bool DMA = false>
+    void launch(const wv::TripleArgs<Real>& a) {
+        if (lb == 16) {
+            if constexpr (!DMA) launch_lb<X, false, 16>(a);
+        } else {
+            launch_lb<X, DMA, 8>(a);
+        }
     }
 
     bool check(int nx, int ny, int nz, int chunks, bool with_map) {
@@ -174,7 +184,10 @@ struct Bench {
             hmap.resize(map_bytes);
             CK(hipMemcpy(hmap.data(), map, map_bytes, hipMemcpyDeviceToHost));
         }
-        launch<0>(make_args(A, B, O1, O2, O3, map, pitch, ny, nz, chunks));
+        if (dma)
+            launch<0, true>(make_args(A, B, O1, O2, O3, map, pitch, ny, nz, chunks));
+        else
+            launch<0>(make_args(A, B, O1, O2, O3, map, pitch, ny, nz, chunks));
         CK(hipDeviceSynchronize());
         std::vector<Real> t1(N), t2(N), t3(N), o1(N), o2(N), o3(N);
         CK(hipMemcpy(t1.data(), T1, N * sizeof(Real), hipMemcpyDeviceToHost));
@@ -227,8 +240,8 @@ struct Bench {
             }
         }
         const bool ok = !bad1 && !bad2 && !bad3;
-        printf("check %s %dx%dx%d (pitch %d), %d chunk(s), %s: t+1 %lld of %lld shell values, t+2 %lld and t+3 %lld of %lld values differ from three plain steps%s\n",
-               sizeof(Real) == 8 ? "f64" : "f32", nx, ny, nz, pitch, chunks, with_map ? "box map" : "interior", (long long)bad1, (long long)stored1, (long long)bad2,
+        printf("check %s%s %d-byte lanes %dx%dx%d (pitch %d), %d chunk(s), %s: t+1 %lld of %lld shell values, t+2 %lld and t+3 %lld of %lld values differ from three plain steps%s\n",
+               sizeof(Real) == 8 ? "f64" : "f32", dma ? " dma" : "", lb, nx, ny, nz, pitch, chunks, with_map ? "box map" : "interior", (long long)bad1, (long long)stored1, (long long)bad2,
                (long long)bad3, (long long)N, ok ? " -- bit-identical" : "");
         if (first >= 0)
             printf("   first t+3 difference at x %lld y %lld z %lld\n", (long long)(first % pitch), (long long)((first / pitch) % ny), (long long)(first / ((int64_t)pitch * ny)));
@@ -257,16 +270,26 @@ struct Bench {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        for (int pass = 0; pass < 6; ++pass) {
-            const int chunks = 1 << (pass % 3);
-            full_first = pass >= 3;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int chunks = 1 << (pass % 2);
+            full_first = false;
+            lb = pass >= 2 ? 16 : 8;
             if (n / chunks < 16) continue;
-            for (int variant = 0; variant < 3; ++variant) {
-                const wv::TripleArgs<Real> a = make_args(A, B, O1, O2, O3, variant == 1 ? map : deep, pitch, n, n, chunks);
+            for (int variant = 0; variant < 6; ++variant) {
+                if (variant == 3 || variant == 4) continue;
+                if (lb == 16 && variant == 3) continue;
+                dma = variant == 3;
+                const wv::TripleArgs<Real> a = make_args(A, B, O1, O2, O3, (variant == 1 || variant >= 3) ? map : deep, pitch, n, n, chunks);
                 for (int it = 0; it < iters + 2; ++it) {
                     if (it == 2) CK(hipEventRecord(e0));
                     if (variant == 2)
                         launch<wv::TX_NO_MEMORY>(a);
+                    else if (variant == 3)
+                        launch<0, true>(a);
+                    else if (variant == 4)
+                        launch<wv::TX_STORE_CACHED>(a);
+                    else if (variant == 5)
+                        launch<wv::TX_WRAP_Z>(a);
                     else
                         launch<0>(a);
                 }
@@ -276,9 +299,9 @@ struct Bench {
                 float ms = 0;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= iters;
-                printf("%s %d^3, %d chunk(s), %d window(s) of <= %d waves, %s: %.3f ms per pass of THREE steps = %.3f ms per step = %.1f Gnode-updates/s (%d B per node: %.0f GB/s)\n",
-                       sizeof(Real) == 8 ? "f64" : "f32", n, a.chunks, a.windows ? a.windows : 1, a.nw,
-                       variant == 2 ? "instructions only (no loads, no stores)" : (variant == 1 ? "three-step pass, box map" : "three-step pass, interior only"), ms, ms / 3,
+                printf("%s %d-byte lanes %d^3, %d chunk(s), %d window(s) of <= %d waves, %s: %.3f ms per pass of THREE steps = %.3f ms per step = %.1f Gnode-updates/s (%d B per node: %.0f GB/s)\n",
+                       sizeof(Real) == 8 ? "f64" : "f32", lb, n, a.chunks, a.windows ? a.windows : 1, a.nw,
+                       variant == 5 ? "three-step pass, box map, every plane wrapped onto two (cache-resident traffic)" : variant == 4 ? "three-step pass, box map, stores without the nt hint" : variant == 3 ? "three-step pass, box map, `previous` by LDS-DMA" : variant == 2 ? "instructions only (no loads, no stores)" : (variant == 1 ? "three-step pass, box map" : "three-step pass, interior only"), ms, ms / 3,
                        3.0 * N / ms / 1e6, (int)(4 * sizeof(Real)), 4.0 * sizeof(Real) * N / ms / 1e6);
             }
         }
@@ -302,8 +325,37 @@ int main(int argc, char** argv) {
         ok = d.check(1000, 20, 12, 1, with_map) && ok;   // two windows, pad columns
         ok = d.check(2048, 8, 11, 1, with_map) && ok;    // four windows
     }
+    d.dma = true;
+    for (int with_map = 0; with_map < 2; ++with_map) {
+        ok = d.check(256, 22, 19, 1, with_map) && ok;
+        ok = d.check(128, 9, 40, 3, with_map) && ok;
+        ok = d.check(100, 37, 23, 2, with_map) && ok;
+        ok = d.check(1000, 20, 12, 1, with_map) && ok;
+        ok = d.check(2048, 8, 11, 1, with_map) && ok;
+        ok = d.check(640, 256, 70, 1, with_map) && ok;
+    }
+    d.dma = false;
+    d.lb = 16;
+    for (int with_map = 0; with_map < 2; ++with_map) {
+        ok = d.check(256, 22, 19, 1, with_map) && ok;
+        ok = d.check(128, 9, 40, 3, with_map) && ok;
+        ok = d.check(1024, 12, 14, 2, with_map) && ok;
+        ok = d.check(100, 37, 23, 2, with_map) && ok;
+        ok = d.check(1000, 20, 12, 1, with_map) && ok;
+        ok = d.check(2048, 8, 11, 1, with_map) && ok;
+        ok = d.check(640, 256, 70, 1, with_map) && ok;
+    }
+    d.lb = 8;
     Bench<float> s;
     if (f32_too) {
+        s.dma = true;
+        ok = s.check(500, 21, 27, 2, true) && ok;
+        ok = s.check(1024, 64, 40, 1, true) && ok;
+        s.dma = false;
+        s.lb = 16;
+        ok = s.check(500, 21, 27, 2, true) && ok;
+        ok = s.check(2048, 64, 40, 1, true) && ok;
+        s.lb = 8;
         ok = s.check(256, 22, 19, 1, false) && ok;
         ok = s.check(500, 21, 27, 2, true) && ok;
     }

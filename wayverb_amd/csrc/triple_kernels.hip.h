@@ -51,15 +51,19 @@ constexpr int kTripleMaxWaves = 12;  // waves side by side in one workgroup (thr
 constexpr int kTripleLoSlots = 18;   // rows of the three "lo" planes a wave keeps in LDS: 8 of `current`, 6 of t+1, 4 of t+2
 constexpr int kTripleEdgeRows = 18;  // centre rows per trip that need x edges: 8 (t+1) + 6 (t+2) + 4 (t+3)
 constexpr int kTripleLaneBytes = 8;
+constexpr int kTriplePvSlots = 8;    // DMA form: the eight rows of `previous` a trip needs, landing in LDS a trip ahead
+constexpr int kTripleMaxWavesDma = 11;  // ... whose slots leave room for 11 waves in a CU's 160 KB
 
-// eight bytes of a row: one double or two floats
-template <typename Real>
-struct Vec8 {
-    static constexpr int N = kTripleLaneBytes / (int)sizeof(Real);
+// a lane's LB bytes of a row (8: one double or two floats; 16: two doubles or four floats)
+template <typename Real, int LB>
+struct VecL {
+    static constexpr int N = LB / (int)sizeof(Real);
     Real v[N];
     __device__ __forceinline__ Real& operator[](int k) { return v[k]; }
     __device__ __forceinline__ const Real& operator[](int k) const { return v[k]; }
 };
+// waves side by side in one workgroup: 8-byte lanes take <= 170 registers, three waves per SIMD; 16-byte lanes all 256, two per SIMD
+constexpr int triple_max_waves(int LB) { return LB == 8 ? 12 : 8; }
 
 template <typename Real>
 struct TripleArgs {
@@ -91,15 +95,15 @@ constexpr int kTripleMaxWindows = 8;
 // three on every SIMD) as the row gives and one short one for the rest -- two short ones share a CU -- instead of equal shares (16
 // waves: 12 + 6 instead of 9 + 9, whose 9 waves are 3 + 2 + 2 + 2 on a CU's SIMDs and as slow as 12).
 // Returns the number of windows (0: the row is one workgroup), -1 if the row is too long; *widest = waves per workgroup.
-inline int triple_windows(int row_waves, uint8_t win[4][kTripleMaxWindows], int* widest, bool full_first = true) {
+inline int triple_windows(int row_waves, uint8_t win[4][kTripleMaxWindows], int* widest, bool full_first = true, int max_waves = kTripleMaxWaves) {
     *widest = row_waves;
-    if (row_waves <= kTripleMaxWaves) return 0;
+    if (row_waves <= max_waves) return 0;
     int n = 0, at = 0;
     *widest = 0;
     if (full_first) {
         while (at < row_waves && n < kTripleMaxWindows) {
             const int lo_halo = at > 0 ? 1 : 0;
-            int end = at + kTripleMaxWaves - lo_halo;  // storing [at, end) with no halo above ...
+            int end = at + max_waves - lo_halo;  // storing [at, end) with no halo above ...
             if (end < row_waves) end -= 1;             // ... or one wave less and a halo wave
             end = end < row_waves ? end : row_waves;
             const int first = at - lo_halo, last = end + (end < row_waves ? 1 : 0);
@@ -114,7 +118,7 @@ inline int triple_windows(int row_waves, uint8_t win[4][kTripleMaxWindows], int*
         return at < row_waves ? -1 : n;
     }
     n = 2;  // the widest window stores ceil(row_waves / n) waves and has a halo wave on one side (n = 2) or two
-    while (n <= kTripleMaxWindows && (row_waves + n - 1) / n + (n > 2 ? 2 : 1) > kTripleMaxWaves) ++n;
+    while (n <= kTripleMaxWindows && (row_waves + n - 1) / n + (n > 2 ? 2 : 1) > max_waves) ++n;
     if (n > kTripleMaxWindows) return -1;
     for (int k = 0; k < n; ++k) {
         const int lo = row_waves * k / n, hi = row_waves * (k + 1) / n;
@@ -128,16 +132,17 @@ inline int triple_windows(int row_waves, uint8_t win[4][kTripleMaxWindows], int*
     return n;
 }
 
-inline size_t triple_lds_bytes(int nw) {
-    return (size_t)nw * kTripleLoSlots * 64 * kTripleLaneBytes + (size_t)2 * kTripleEdgeRows * (kTripleMaxWaves + 2) * 2 * kTripleLaneBytes;
+inline size_t triple_lds_bytes(int nw, bool dma = false, int LB = kTripleLaneBytes) {
+    return (size_t)nw * (kTripleLoSlots + (dma ? kTriplePvSlots : 0)) * 64 * LB + (size_t)2 * kTripleEdgeRows * (triple_max_waves(LB) + 2) * 2 * LB;
 }
 
 // The 7-point update of one lane's columns of one row, in the reference's order (pair_step_row, for 8-byte lanes).
-template <typename Real>
-__device__ __forceinline__ Vec8<Real> triple_step_row(const Vec8<Real>& c0, const Vec8<Real>& ym, const Vec8<Real>& yp, const Vec8<Real>& zm,
-                                                      const Vec8<Real>& zp, const Vec8<Real>& pv, Real edge_l, Real edge_r) {
-    constexpr int VX = Vec8<Real>::N;
-    Vec8<Real> out;
+template <typename Real, int LB>
+__device__ __forceinline__ VecL<Real, LB> triple_step_row(const VecL<Real, LB>& c0, const VecL<Real, LB>& ym, const VecL<Real, LB>& yp,
+                                                          const VecL<Real, LB>& zm, const VecL<Real, LB>& zp, const VecL<Real, LB>& pv, Real edge_l,
+                                                          Real edge_r) {
+    constexpr int VX = VecL<Real, LB>::N;
+    VecL<Real, LB> out;
 #pragma unroll
     for (int j = 0; j < VX; ++j) {
         const Real left = (j == 0) ? lane_from_below(edge_l, c0[VX - 1]) : c0[j - 1];
@@ -160,19 +165,63 @@ __device__ __forceinline__ uint32_t abs_bits_hi(double v) { return (uint32_t)__d
 __device__ __forceinline__ uint32_t abs_bits_hi(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
 
 // Experiment switches (tools/triple4_bench.hip only; the engine runs X = 0)
-enum : int { TX_NO_MEMORY = 1 };
+enum : int { TX_NO_MEMORY = 1, TX_STORE_CACHED = 2, TX_WRAP_Z = 4 /* every plane is plane z & 1: the traffic stays in the caches */ };
 
 // EDGE: the strip's trips touch rows off the grid (the first strip, the last one or two): every row offset goes through the range
 // check and rows of t+1 / t+2 off the grid are forced to zero.  Interior strips know their rows are there.
-template <typename Real, int X, bool EDGE>
+// Vector-memory instructions a trip issues in row step m (triple_march_body: the same conditions, in the same order) ...
+constexpr int triple_vm_ops(int LA, bool dma, int m) {
+    constexpr int R0 = kTripleRows + 6, R1 = kTripleRows + 4;
+    int n = 0;
+    n += (m + LA + 1 < R0) ? 1 : 0;               // b_new[m + LA + 1]
+    n += (m + LA + 1 == R0) ? 1 : 0;              // b_new[0]
+    n += (!dma && m + LA < R1) ? 1 : 0;           // pv[m + LA]
+    n += (m >= R1 + 1 - LA) ? (dma ? 1 : 2) : 0;  // the next trip's first rows
+    n += (m >= 2 && m - 2 < kTripleRows) ? 3 : 0;  // t+1 / t+2 / t+3 stores of a finished row
+    n += (dma && m >= 2 && (m & 1) == 0) ? 1 : 0;  // the DMA of pair m/2 - 1
+    return n;
+}
+// ... and so how many are issued, at the very least, between the DMA of pair p (first in row step 2p+2 of the trip before) and row step
+// 2p, where its rows are first read: the rest of that trip, the map load at the top of this one, this trip's row steps before 2p.  Two
+// less than counted, for safety: a smaller number only waits for more.
+constexpr int triple_dma_wait(int LA, int p) {
+    int n = triple_vm_ops(LA, true, 2 * p + 2) - 1;
+    for (int m = 2 * p + 3; m <= kTripleRows + 4; ++m) n += triple_vm_ops(LA, true, m);
+    n += 1;
+    for (int m = 0; m < 2 * p; ++m) n += triple_vm_ops(LA, true, m);
+    return n > 2 ? n - 2 : 0;
+}
+
+// vmcnt <= n, nothing else waited for (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+// lds_barrier() for a kernel with LDS-DMA in flight: its "local" fence would make the compiler wait for every pending `buffer_load ...
+// lds` (they are LDS writes to it) -- a memory latency at every barrier.  Here: the wave's own LDS instructions retired, then the barrier.
+__device__ __forceinline__ void lds_barrier_keep_vm() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+}
+
+// PVDMA: the rows of `previous` (each read once, as a node's own old value) do not pass through registers: `buffer_load ... lds` drops
+// them into eight more wave-private LDS slots a whole trip ahead, two rows per instruction.  The compiler counts such a load in vmcnt but
+// does not order LDS reads behind it; the waits are placed by hand (triple_dma_wait: vector-memory instructions are issued and retired
+// in order, and the row steps are fenced scheduling regions, so how many are issued between a DMA and the row step that reads its
+// rows is a compile-time number).
+template <typename Real, int X, bool EDGE, bool PVDMA, int LB>
 __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
-    using V = Vec8<Real>;
+    static_assert(!PVDMA || LB == 8, "the DMA form is written for 8-byte lanes");
+    using V = VecL<Real, LB>;
     constexpr int VX = V::N;
     constexpr int RY = kTripleRows;
     constexpr int R0 = RY + 6, R1 = RY + 4, R2 = RY + 2;
-    constexpr int NE = kTripleEdgeRows, WS = kTripleMaxWaves + 2;
+    constexpr int NE = kTripleEdgeRows, WS = triple_max_waves(LB) + 2;
     extern __shared__ __attribute__((aligned(16))) char triple_lds[];
     typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<LB == 8, U2, U4>::type UL;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -204,8 +253,9 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     // wave w's first vector (lane 0) in slot w + 1 side 0, its last vector (lane 63) in side 1; slots 0 and row_waves + 1 stay zero
     // (what lies beyond the row's ends -- or beyond a window's halo wave: see TripleArgs).  Both sets and all rows of one (slot, side)
     // lie within 288 bytes, and what a wave reads -- slot w side 1, slot w + 2 side 0 -- within 1 KB: one address register for all of it.
-    V* const lo = reinterpret_cast<V*>(triple_lds) + (size_t)wave * kTripleLoSlots * 64 + lane;
-    V* const edge = reinterpret_cast<V*>(triple_lds + (size_t)a.nw * kTripleLoSlots * 64 * kTripleLaneBytes);
+    constexpr int SLOTS = kTripleLoSlots + (PVDMA ? kTriplePvSlots : 0);
+    V* const lo = reinterpret_cast<V*>(triple_lds) + (size_t)wave * SLOTS * 64 + lane;
+    V* const edge = reinterpret_cast<V*>(triple_lds + (size_t)a.nw * SLOTS * 64 * LB);
     auto edge_at = [&](int set, int row, int slot, int side) -> V* { return edge + ((slot * 2 + side) * 2 + set) * NE + row; };
     V zero;
 #pragma unroll
@@ -217,13 +267,13 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
 
     const int row_bytes = pitch * (int)sizeof(Real);
     const uint32_t plane_bytes = (uint32_t)row_bytes * (uint32_t)a.ny;
-    const uint32_t lane_off = (uint32_t)((wave_abs * 64 + lane) * kTripleLaneBytes);
+    const uint32_t lane_off = (uint32_t)((wave_abs * 64 + lane) * LB);
     const uint32_t voff0 = lane_off + (uint32_t)((y0 - 3) * row_bytes);  // row y0-3 of a plane (may wrap: then it is off the grid)
     auto in_y = [&](int y) { return (unsigned)y < (unsigned)a.ny; };
     auto in_z = [&](int z) { return (unsigned)z < (unsigned)a.nz; };
     auto plane_of = [&](const Real* base, int z, bool wanted) {
         const bool ok = wanted && in_z(z);
-        const Real* p = base + (int64_t)(ok ? z : 0) * plane;
+        const Real* p = base + (int64_t)(ok ? ((X & TX_WRAP_Z) ? (z & 1) : z) : 0) * plane;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<Real*>(p), 0, ok ? plane_bytes : 0u, 0x00020000);
     };
     using Rsrc = decltype(plane_of(a.cur, 0, true));
@@ -237,16 +287,34 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     // otherwise the row's offset is scalar and the lanes' offset is one register for every access of the kernel.
     auto ld = [&](Rsrc r, int q, int z_for_made_up) -> V {
         if (X & TX_NO_MEMORY) return made_up(q, z_for_made_up);
-        const U2 raw = EDGE ? __builtin_amdgcn_raw_buffer_load_b64(r, voff0 + (uint32_t)(q * row_bytes), 0, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, (y0 - 3 + q) * row_bytes, 0);
+        const uint32_t voff = EDGE ? voff0 + (uint32_t)(q * row_bytes) : lane_off;
+        const int soff = EDGE ? 0 : (y0 - 3 + q) * row_bytes;
+        UL raw;
+        if constexpr (LB == 8)
+            raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        else
+            raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
         return __builtin_bit_cast(V, raw);
     };
     // `wanted`: a store only some lanes want -- the others aim beyond the plane and the range check drops them
     auto st = [&](Rsrc r, int q, const V& v, bool wanted) {
-        if (EDGE)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2, v), r, wanted ? voff0 + (uint32_t)(q * row_bytes) : 0xFFFFFFF0u, 0, 2 /* nt */);
+        const uint32_t voff = wanted ? (EDGE ? voff0 + (uint32_t)(q * row_bytes) : lane_off) : 0xFFFFFFF0u;
+        const int soff = EDGE ? 0 : (y0 - 3 + q) * row_bytes;
+        if constexpr (LB == 8)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(UL, v), r, voff, soff, (X & TX_STORE_CACHED) ? 0 : 2 /* nt */);
         else
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2, v), r, wanted ? lane_off : 0xFFFFFFF0u, (y0 - 3 + q) * row_bytes, 2 /* nt */);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(UL, v), r, voff, soff, (X & TX_STORE_CACHED) ? 0 : 2 /* nt */);
+    };
+    // (PVDMA) rows y0-2+2p and y0-1+2p of `previous` into pv slots 2p, 2p+1: lanes 0..31 fetch the first row, 16 bytes each, lanes 32..63
+    // the second; the 1024 bytes land lane by lane, i.e. row by row
+    typedef __attribute__((address_space(3))) char LdsChar;
+    const uint32_t dma_voff = (uint32_t)(wave_abs * 64 * LB + (lane & 31) * 16) + (uint32_t)(lane >> 5) * (uint32_t)row_bytes;
+    auto dma_pv = [&](Rsrc r, int p) {
+        LdsChar* const dst = (LdsChar*)triple_lds + (wave * SLOTS + kTripleLoSlots + 2 * p) * 64 * LB;
+        if (EDGE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, dma_voff + (uint32_t)((y0 - 2 + 2 * p) * row_bytes), 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, dma_voff, (y0 - 2 + 2 * p) * row_bytes, 0, 0);
     };
     // 2-bit codes of this lane's columns in the RY rows of the strip on plane z: one dword load (byte r = row r, 4 columns), through a
     // descriptor of its own (the map of 2^32 nodes is 1 GB: within a descriptor's reach)
@@ -258,7 +326,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     };
     auto row_codes = [&](uint32_t word, int r) -> uint32_t {  // bits 2k, 2k+1: column k of this lane
         const uint32_t byte = (word >> (r * 8)) & 0xFFu;
-        return (VX == 2) ? ((byte >> ((lane & 1) * 4)) & 0xFu) : ((byte >> ((lane & 3) * 2)) & 0x3u);
+        return VX == 4 ? byte : (VX == 2 ? ((byte >> ((lane & 1) * 4)) & 0xFu) : ((byte >> ((lane & 3) * 2)) & 0x3u));
     };
     // x edges: the last column of the wave to the left, the first column of the wave to the right (zeros beyond the row's ends)
     auto edge_l = [&](int set, int row) -> Real { return reinterpret_cast<const Real*>(edge_at(set, row, wave, 1))[VX - 1]; };
@@ -289,22 +357,43 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
         const Rsrc r_o1 = plane_of(a.out1, z, storing), r_o2 = plane_of(a.out2, z, storing), r_o3 = plane_of(a.out3, z, storing);
         const uint32_t code_word = codes_of(min(max(z, 0), a.nz - 1));
         const bool z1 = in_z(f - 1), z2 = in_z(f - 2);
-        lds_barrier();  // the edge columns of this trip's centre planes, published by every wave at the end of the last trip
+        // the edge columns of this trip's centre planes, published by every wave at the end of the last trip
+        if (PVDMA)
+            lds_barrier_keep_vm();
+        else
+            lds_barrier();
 #pragma unroll
         for (int m = 0; m <= R1; ++m) {
             __builtin_amdgcn_sched_barrier(0);  // (rows in the order written: the scheduler would hoist every LDS read of the trip to its top)
             if (m + LA + 1 < R0) b_new[m + LA + 1] = ld(r_cur, m + LA + 1, f);
             if (m + LA + 1 == R0) b_new[0] = ld(r_cur, 0, f);  // (row y0-3: the next trip's first y-1 neighbour)
-            if (m + LA < R1) pv[m + LA] = ld(r_prev, m + LA + 1, 1 - f);
+            if (PVDMA && !(X & TX_NO_MEMORY)) {
+                // rows m-2, m-1 of `previous` have been used: the next trip's take their slots.  (First in its region, and the
+                // region after it fenced: what follows counts as issued behind it, whatever order the scheduler likes.)
+                if (m >= 2 && (m & 1) == 0) {
+                    dma_pv(r_prev_n, m / 2 - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // rows m, m+1 are about to be read: their DMA, issued a trip ago, has to have landed
+                if (m < R1 && (m & 1) == 0) {
+                    if (m == 0) wait_vmcnt<triple_dma_wait(LA, 0)>();
+                    if (m == 2) wait_vmcnt<triple_dma_wait(LA, 1)>();
+                    if (m == 4) wait_vmcnt<triple_dma_wait(LA, 2)>();
+                    if (m == 6) wait_vmcnt<triple_dma_wait(LA, 3)>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!PVDMA && m + LA < R1) pv[m + LA] = ld(r_prev, m + LA + 1, 1 - f);
             if (m >= R1 + 1 - LA) {  // the next trip's first rows: its b_new is this trip's b_mid, whose rows 1 .. LA have retired
                 b_mid[m - (R1 - LA)] = ld(r_cur_n, m - (R1 - LA), f + 1);
-                pv_next[m - (R1 + 1 - LA)] = ld(r_prev_n, m - (R1 - LA), -f);
+                if (!PVDMA) pv_next[m - (R1 + 1 - LA)] = ld(r_prev_n, m - (R1 - LA), -f);
             }
             V zm_b = zero;
             if (m < R1) {  // t+1 on plane f-1, row y0-2+m
                 const int i = m;
                 zm_b = lo[i * 64];
-                V v = triple_step_row<Real>(b_mid[i + 1], b_mid[i], b_mid[i + 2], zm_b, b_new[i + 1], pv[i], edge_l(set, i), edge_r(set, i));
+                const V own = (PVDMA && !(X & TX_NO_MEMORY)) ? lo[(kTripleLoSlots + i) * 64] : ((PVDMA) ? made_up(i, 1 - f) : pv[i]);
+                V v = triple_step_row<Real, LB>(b_mid[i + 1], b_mid[i], b_mid[i + 2], zm_b, b_new[i + 1], own, edge_l(set, i), edge_r(set, i));
                 const bool ok = (!EDGE || in_y(y0 - 2 + i)) && z1;
 #pragma unroll
                 for (int k = 0; k < VX; ++k) v[k] = ok ? v[k] : Real(0);
@@ -314,7 +403,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
             if (m >= 1 && m - 1 < R2) {  // t+2 on plane f-2, row y0-1+r; own old value: current(f-2), slot r+1 -- read for the t+1 row above
                 const int r = m - 1;
                 zm_u = lo[(R1 + r) * 64];
-                V v = triple_step_row<Real>(u_mid[r + 1], u_mid[r], u_mid[r + 2], zm_u, u_new[r + 1], zm_b, edge_l(set, R1 + r), edge_r(set, R1 + r));
+                V v = triple_step_row<Real, LB>(u_mid[r + 1], u_mid[r], u_mid[r + 2], zm_u, u_new[r + 1], zm_b, edge_l(set, R1 + r), edge_r(set, R1 + r));
                 const bool ok = (!EDGE || in_y(y0 - 1 + r)) && z2;
 #pragma unroll
                 for (int k = 0; k < VX; ++k) v[k] = ok ? v[k] : Real(0);
@@ -323,7 +412,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
             if (m >= 2 && m - 2 < RY) {  // t+3 on plane z = f-3, row y0+s; own old value: t+1(f-3), slot r = s+1 -- read just above
                 const int s = m - 2;
                 const V zm_w = lo[(R1 + R2 + s) * 64];
-                const V v3 = triple_step_row<Real>(w_mid[s + 1], w_mid[s], w_mid[s + 2], zm_w, w_new[s + 1], zm_u, edge_l(set, R1 + R2 + s),
+                const V v3 = triple_step_row<Real, LB>(w_mid[s + 1], w_mid[s], w_mid[s + 2], zm_w, w_new[s + 1], zm_u, edge_l(set, R1 + R2 + s),
                                                    edge_r(set, R1 + R2 + s));
                 V o1 = zm_u, o2 = w_mid[s + 1], o3 = v3;
                 const uint32_t codes = row_codes(code_word, s);
@@ -332,6 +421,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
 #pragma unroll
                 for (int k = 0; k < VX; ++k) {
                     const bool live = (bits >> (2 * k)) & 1u;
+                    o1[k] = live ? o1[k] : Real(0);  // (a "none" column beside a shell one: every field holds 0 there)
                     o2[k] = live ? o2[k] : Real(0);
                     o3[k] = live ? o3[k] : Real(0);
                     top_exp = max(top_exp, abs_bits_hi(o3[k]));
@@ -342,7 +432,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
                         st(r_o3, 3 + s, o3, true);
                     }
                 } else {
-                    st(r_o1, 3 + s, o1, (want1 & 0x5u) != 0);
+                    st(r_o1, 3 + s, o1, (want1 & 0x55u) != 0);
                     st(r_o2, 3 + s, o2, true);
                     st(r_o3, 3 + s, o3, true);
                 }
@@ -390,7 +480,12 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
 #pragma unroll
         for (int q = 0; q < LA; ++q) {
             bB[q + 1] = ld(r_cur, q + 1, zb - 1);
-            pA[q] = ld(r_prev, q + 1, 2 - zb);
+            if (!PVDMA) pA[q] = ld(r_prev, q + 1, 2 - zb);
+        }
+        if (PVDMA && !(X & TX_NO_MEMORY)) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dma_pv(r_prev, p);
+            wait_vmcnt<0>();  // (the waits inside the trips count on a whole trip's instructions between a DMA and its use)
         }
     }
     for (int f = zb - 1; f <= ze + 2; f += 2) {
@@ -401,17 +496,17 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     if (__any(top_exp >= (sizeof(Real) == 8 ? 0x7FF00000u : 0x7F800000u)) && lane == 0) atomicOr(a.suspect, 1);
 }
 
-template <typename Real, int X = 0>
-__global__ void __launch_bounds__(64 * kTripleMaxWaves) triple_march_kernel(const TripleArgs<Real> a) {
+template <typename Real, int X = 0, bool PVDMA = false, int LB = kTripleLaneBytes>
+__global__ void __launch_bounds__(64 * triple_max_waves(LB)) triple_march_kernel(const TripleArgs<Real> a) {
     // (which strip: as in the body)
     int j = (int)(blockIdx.x >> 3);
     if (a.windows) j %= (int)(gridDim.x >> 3) / a.windows;
     const int strip = (int)(blockIdx.x & 7) * a.strips_per_xcd + j % a.strips_per_xcd;
     const int y0 = strip * kTripleRows;
     if (y0 < 4 || y0 + kTripleRows + 2 >= a.ny)
-        triple_march_body<Real, X, true>(a);
+        triple_march_body<Real, X, true, PVDMA, LB>(a);
     else
-        triple_march_body<Real, X, false>(a);
+        triple_march_body<Real, X, false, PVDMA, LB>(a);
 }
 
 }  // namespace wv
