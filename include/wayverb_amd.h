@@ -121,7 +121,11 @@ typedef struct wv_tuning {
                                * receiver work served by the tiles that own those nodes): -1 the engine decides by mesh size (small meshes are
                                * bound by launches, not bytes), 1 / 0 force on / off.  Only where it is legal (one domain, the source and the
                                * receivers -- at most 63 -- on inside nodes); otherwise two launches per step as ever */
-    int32_t reserved_[3];
+    int32_t triple;           /* three-step passes (triple_kernels.hip.h: 10.7 B per node-update where a two-step pass moves 16): -1 the engine
+                               * decides by mesh size, 1 / 0 force on / off.  One domain only (z-slabs keep two-step passes), rooms that fill
+                               * their mesh; a batch takes them wherever it has three steps left, then a two-step pass or a single step */
+    int32_t triple_chunks;    /* workgroups along z of the three-step march; 0 = fill whole rounds of workgroup slots */
+    int32_t reserved_[1];
 } wv_tuning;
 
 typedef struct wv_options {
@@ -272,14 +276,16 @@ int wv_kernel_time_detail(wv_engine* e, double* mean_ms, uint64_t* launches, uin
  *                            ghost planes (the part of the halo exchange the interior work did not hide), over that many timed
  *                            waits (every fourth); both reset by wv_kernel_time
  *   WV_QUERY_HALO_EXCHANGES, WV_QUERY_HALO_BYTES_SENT   exchanges issued and bytes handed to neighbours since creation
- *   WV_QUERY_EARLY_PASSES    two-step passes of a slab that ran both exchanges under the march (wv_tuning::slab_early) */
+ *   WV_QUERY_EARLY_PASSES    two-step passes of a slab that ran both exchanges under the march (wv_tuning::slab_early)
+ *   WV_QUERY_TRIPLE_PASSES   three-step passes taken since creation (wv_tuning::triple) */
 enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_QUERY_MARCH_LIVE_PERMILLE = 3,
        WV_QUERY_SWEEP_LIVE_PERMILLE = 4, WV_QUERY_MARCH_ROUNDS = 5, WV_QUERY_HALO_WAIT_NS = 6, WV_QUERY_HALO_WAITS = 7,
        WV_QUERY_HALO_EXCHANGES = 8, WV_QUERY_HALO_BYTES_SENT = 9, WV_QUERY_EARLY_PASSES = 10,
        /* kernel timing on: total time of the two boundary launches of every eighth two-step pass whose march was timed (nodes to t+1 /
         * to t+2), over that many passes; reset by wv_kernel_time */
        WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13,
-       WV_QUERY_WHOLE_STEPS = 14 /* single steps taken as one launch each (wv_tuning::whole_step) */ };
+       WV_QUERY_WHOLE_STEPS = 14 /* single steps taken as one launch each (wv_tuning::whole_step) */,
+       WV_QUERY_TRIPLE_PASSES = 15 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

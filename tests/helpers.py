@@ -46,7 +46,8 @@ def run_engine(case, precision, **engine_kw):
         steps, out = E.run_fast(eng, case["source_kind"], case["source_node"], case["signal"], case["recv"])
         return dict(steps=steps, flag=0, trace=out.astype(dtype),
                     current=eng.read_field(E.BUF_CURRENT), previous=eng.read_field(E.BUF_PREVIOUS),
-                    bd=[eng.read_boundary_data(d) for d in (1, 2, 3)])
+                    bd=[eng.read_boundary_data(d) for d in (1, 2, 3)],
+                    passes=eng.query(E.Engine.QUERY_PASSES), triple_passes=eng.query(E.Engine.QUERY_TRIPLE_PASSES))
     finally:
         eng.close()
 

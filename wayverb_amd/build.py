@@ -13,8 +13,8 @@ LIB = os.path.join(HERE, "libwayverb_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["engine.hip", "mesh_setup.hip", "node_inside.hip", "boundary_surfaces.hip", "scene_mesh.hip", "comm.cpp", "box_mesh.cpp", "filter_design.cpp", "postprocess.cpp"]
-HEADERS = ["device_common.hip.h", "stream_kernels.hip.h", "boundary_kernels.hip.h", "pair_kernels.hip.h", "plane_kernels.hip.h", "comm.h", "engine_base.h", "engine.hip.h",
-           "engine_setup.hip.h", "engine_single.hip.h", "engine_pair.hip.h", "engine_batch.hip.h", "engine_io.hip.h", "engine_slab.hip.h",
+HEADERS = ["device_common.hip.h", "stream_kernels.hip.h", "boundary_kernels.hip.h", "pair_kernels.hip.h", "plane_kernels.hip.h", "triple_kernels.hip.h", "comm.h", "engine_base.h", "engine.hip.h",
+           "engine_setup.hip.h", "engine_single.hip.h", "engine_pair.hip.h", "engine_triple.hip.h", "engine_batch.hip.h", "engine_io.hip.h", "engine_slab.hip.h",
            os.path.join("..", "..", "include", "wayverb_amd.h")]
 
 # -ffp-contract=off: results must not depend on where the compiler chooses to fuse a*b+c

@@ -8,6 +8,7 @@
 //   engine_single.hip.h  one time step per pass: sweep + boundary launches, source / receiver launch, the slab form
 //                        (faces first, exchange, interior), hipGraph replay for small meshes
 //   engine_pair.hip.h    two time steps per pass: eligibility, pair map + fix-up lists, march geometry, parts A / B
+//   engine_triple.hip.h  three time steps per pass: eligibility, triple map + third-level list, march geometry, the pass
 //   engine_batch.hip.h   wv_step / wv_run: batches of steps, flag words, kernel timing
 //   engine_io.hip.h      everything a caller reads or writes: values, fields, planes, filter memories, source,
 //                        receivers
@@ -20,6 +21,7 @@
 #include "pair_kernels.hip.h"
 #include "stream_kernels.hip.h"
 #include "plane_kernels.hip.h"
+#include "triple_kernels.hip.h"
 
 namespace wv {
 
@@ -90,6 +92,11 @@ public:
     uint64_t role_signature() const override {
         return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
     }
+    // ---- engine_triple.hip.h
+    static constexpr int kLaneBytes = sizeof(Real) == 8 ? 16 : 8;  // bytes of a row per lane of the three-step march (triple_kernels.hip.h)
+    bool triple_eligible();
+    int ensure_triple();
+    int enqueue_triple(int slot, uint64_t signal_pos, bool source_live);
     // ---- engine_batch.hip.h
     bool time_this_launch();
     int drain_timing();
@@ -254,6 +261,18 @@ private:
     bool xw_active_ = false;       // this (mesh, source) runs its passes on them
     bool xw_valid_ = false;        // the copies hold what the fields hold
     uint64_t passes_taken_ = 0;
+    // three-step passes (engine_triple.hip.h)
+    Real* field1_ = nullptr;           // t+1 at shell and boundary nodes of the pass in flight, zeros at outside nodes
+    uint8_t* triple_map_ = nullptr;
+    uint32_t* triple_list_ = nullptr;  // third level's fix-up list: every shell node
+    uint32_t triple_list_n_ = 0;
+    int* suspect_ = nullptr;           // [kRing] per step slot: the march saw an inf / nan
+    uint64_t triple_source_ = 0, triple_io_generation_ = ~0ull;
+    bool triple_failed_ = false, triple_ready_ = false, triple_attr_set_ = false;
+    uint64_t triple_min_nodes_ = 96ull << 20;  // stored nodes: below, the chunks' warm-up planes and the launches cost more than the bytes save
+    int triple_nw_ = 1, triple_strips_ = 0, triple_zc_ = 0, triple_chunks_ = 1, triple_windows_ = 0;
+    uint8_t triple_win_[4][wv::kTripleMaxWindows] = {};
+    uint64_t triples_taken_ = 0;
     int* status_ = nullptr;
     int* static_flag_dev_ = nullptr;
     int static_flag_ = 0;

@@ -282,10 +282,27 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             }
             if (singles_first < 0 && (rc = batch_pair_vetoed())) return rc;
             const bool pairs = singles_first >= 0;
-            auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+            // ... and three steps per pass wherever it has three left (one domain, a room that fills its mesh: engine_triple.hip.h).
+            // The passes do not reset flag words one by one: the whole batch's are set here.
+            bool triples = false;
+            if (pairs && !chain && batch >= (uint64_t)singles_first + 3 && triple_eligible()) {
+                if ((rc = ensure_triple())) return rc;
+                triples = triple_ready_;
+                if (triples) {
+                    WV_HIP(hipMemsetD32Async((hipDeviceptr_t)flags_, static_flag_, (size_t)batch, stream_));
+                    WV_HIP(hipMemsetAsync(suspect_, 0, (size_t)batch * sizeof(int), stream_));
+                    batch_flags_reset_ = true;
+                }
+            }
+            auto triple_at = [&](uint64_t i) { return triples && i >= (uint64_t)singles_first && i + 3 <= batch; };
+            auto pair_at = [&](uint64_t i) { return pairs && !triple_at(i) && i >= (uint64_t)singles_first && i + 2 <= batch; };
+            // (a three-step pass serves its own first step's source / receiver work unless the launch before it has: as a single step would)
             auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
             for (uint64_t i = 0; i < batch;) {
-                if (pair_at(i)) {
+                if (triple_at(i)) {
+                    if ((rc = enqueue_triple((int)i, signal_pos_ + i, batch_source_live_))) return rc;
+                    i += 3;
+                } else if (pair_at(i)) {
                     if ((rc = enqueue_batch_pair(i, 0, 0))) return rc;
                     if ((rc = enqueue_batch_pair(i, 1, kind_at(i + 2)))) return rc;
                     i += 2;
@@ -335,6 +352,7 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_FIELDS: {
             uint64_t n = 0;
             for (int i = 0; i < 4; ++i) n += field_[i] != nullptr;
+            n += field1_ != nullptr;
             *value = n;
             return WV_OK;
         }
@@ -360,6 +378,7 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_BOUNDARY2_NS: *value = (uint64_t)(part_ms_[1] * 1e6 + 0.5); return WV_OK;
         case WV_QUERY_BOUNDARY_TIMED: *value = std::min(part_n_[0], part_n_[1]); return WV_OK;
         case WV_QUERY_WHOLE_STEPS: *value = whole_steps_; return WV_OK;
+        case WV_QUERY_TRIPLE_PASSES: *value = triples_taken_; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

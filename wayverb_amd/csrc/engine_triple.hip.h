@@ -1,0 +1,302 @@
+// engine_triple.hip.h -- three time steps per pass over the fields (triple_kernels.hip.h): when, with what map and lists, in which launches.
+//
+// Part of the engine behind the C ABI of include/wayverb_amd.h (engine.hip is the translation unit; see engine.hip.h for
+// the class and the map of which file holds what).
+//
+// A pass takes (t-1, t) to (t+2, t+3):
+//   [source sample into t, receivers from t]
+//   MARCH                      reads t-1, t; writes t+2 and t+3 everywhere (placeholders where it cannot know), t+1 at shell nodes only
+//   exact flags                (a launch that leaves at once unless the march has seen an inf or a nan)
+//   boundary nodes -> t+1      own old value from t-1, neighbours from t, into the t+1 field
+//   [source sample into t+1, receivers from t+1]
+//   fix-up list 2 -> t+2       the nodes next to something that is not a plain node (those no boundary entry finishes), from the t+1 field
+//   boundary nodes -> t+2      own old value from t, neighbours from t+1; a 1-D entry also finishes the inside node it faces
+//   [source sample into t+2, receivers from t+2]
+//   fix-up list 3 -> t+3       every shell node (something else within two nodes), from the finished t+2 field and its own t+1
+//   boundary nodes -> t+3      own old value from t+1, neighbours from t+2
+// Five fields: the engine's four rotate as in a two-step pass (the two that held t-1 and t receive t+2 and t+3 of the next pass), the
+// fifth holds t+1 at the shell nodes and the boundary nodes of whatever pass is in flight and zeros at outside nodes.
+// Results are bit-identical to three single steps (tests/test_gpu_triple.py).
+#pragma once
+#include "engine.hip.h"
+#include "triple_kernels.hip.h"
+
+namespace wv {
+
+// May this engine take three-step passes right now?  Everything a two-step pass needs (it shares the pair map, the second level's
+// fix-up list and the spare fields), one domain (a slab's faces would need three exchanges per pass), a room that fills its mesh
+// (the march has no unit lists), and -- unless forced -- a mesh big enough that bytes, not launches and warm-up planes, decide.
+template <typename Real>
+bool Engine<Real>::triple_eligible() {
+    if (opt_.tuning.triple == 0 || triple_failed_) return false;
+    if (comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
+    if (!pair_eligible()) return false;
+    constexpr int WX = 64 * (kLaneBytes / (int)sizeof(Real));
+    uint8_t win[4][wv::kTripleMaxWindows];
+    int widest = 0;
+    if (wv::triple_windows(pitch_ / WX, win, &widest, false, wv::triple_max_waves(kLaneBytes)) < 0) return false;
+    if (opt_.tuning.triple < 0 && stored_nodes_ < triple_min_nodes_) return false;
+    return true;
+}
+
+template <typename Real>
+int Engine<Real>::ensure_triple() {
+    int rc = ensure_pair();
+    if (rc) return rc;
+    if (pair_failed_ || pair_units_ || !pair_sparse_ok_) {  // (a sparse room keeps its two-step passes over live units)
+        triple_ready_ = false;
+        return WV_OK;
+    }
+    const uint64_t src = source_kind_ != WV_SOURCE_NONE ? source_node_ : ~0ull;
+    if (!field1_) {
+        if (hipMalloc((void**)&field1_, field_bytes_ + 256) != hipSuccess) {
+            (void)hipGetLastError();
+            field1_ = nullptr;
+            triple_failed_ = true;  // not enough memory for a fifth field: two-step passes
+            triple_ready_ = false;
+            return WV_OK;
+        }
+        WV_HIP(hipMemsetAsync(field1_, 0, field_bytes_ + 256, stream_));
+    }
+    if (!suspect_) {
+        WV_HIP(hipMalloc((void**)&suspect_, kRing * sizeof(int)));
+        WV_HIP(hipMemsetAsync(suspect_, 0, kRing * sizeof(int), stream_));
+    }
+    if (triple_map_ && triple_source_ == src && triple_io_generation_ == io_generation_) {
+        triple_ready_ = true;
+        return WV_OK;
+    }
+    const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
+    if (!triple_map_) {
+        WV_HIP(hipMalloc((void**)&triple_map_, cls_bytes + 16));
+        WV_HIP(hipMemsetAsync(triple_map_, 0, cls_bytes + 16, stream_));
+    }
+    // map + third-level list: count per block, scan on the host, fill
+    const int64_t n_bytes = (int64_t)cls_pitch_ * ny_ * nz_;
+    const unsigned blocks = (unsigned)((n_bytes + 255) / 256);
+    ScopedDevice counts;
+    WV_HIP(hipMalloc(&counts.p, (size_t)blocks * sizeof(uint32_t)));
+    wv::TripleMapArgs m{};
+    m.pair_map = pair_map_;
+    m.map = triple_map_;
+    m.block_count = static_cast<uint32_t*>(counts.p);
+    m.ny = ny_;
+    m.nz = nz_;
+    m.pitch = pitch_;
+    m.cls_pitch = cls_pitch_;
+    m.z_begin = z_begin_;
+    m.z_end = z_end_;
+    hipLaunchKernelGGL(wv::triple_map_kernel, dim3(blocks), dim3(256), 0, stream_, m);
+    WV_HIP(hipGetLastError());
+    std::vector<uint32_t> per_block(blocks);
+    WV_HIP(hipMemcpyAsync(per_block.data(), counts.p, (size_t)blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    WV_HIP(hipStreamSynchronize(stream_));
+    uint64_t total = 0;
+    for (unsigned b = 0; b < blocks; ++b) {
+        const uint32_t c = per_block[b];
+        per_block[b] = (uint32_t)total;
+        total += c;
+    }
+    if (triple_list_) {
+        (void)hipFree(triple_list_);
+        triple_list_ = nullptr;
+    }
+    triple_list_n_ = 0;
+    if (total >= (1ull << 32)) {
+        triple_ready_ = false;
+        return WV_OK;
+    }
+    if (total) {
+        WV_HIP(hipMalloc((void**)&triple_list_, (size_t)total * sizeof(uint32_t)));
+        WV_HIP(hipMemcpyAsync(counts.p, per_block.data(), (size_t)blocks * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+        m.list = triple_list_;
+        hipLaunchKernelGGL(wv::triple_map_kernel, dim3(blocks), dim3(256), 0, stream_, m);
+        WV_HIP(hipGetLastError());
+        WV_HIP(hipStreamSynchronize(stream_));  // (per_block is on this function's stack)
+        triple_list_n_ = (uint32_t)total;
+    }
+    // receivers and the source node: their t+1 is read / written in the t+1 field whatever lies around them
+    if (n_recv_ || src != ~0ull) {
+        wv::TripleMarkArgs k{};
+        k.map = triple_map_;
+        k.recv = recv_nodes_;
+        k.n_recv = n_recv_;
+        k.source_node = src;
+        k.ny = ny_;
+        k.pitch = pitch_;
+        k.cls_pitch = cls_pitch_;
+        hipLaunchKernelGGL(wv::triple_mark_kernel, dim3((n_recv_ + 1 + 255) / 256), dim3(256), 0, stream_, k);
+        WV_HIP(hipGetLastError());
+    }
+    triple_source_ = src;
+    triple_io_generation_ = io_generation_;
+    // march geometry: strips of four rows; windows where a row is longer than a workgroup; chunks along z so that the workgroups fill
+    // whole rounds of the chip's workgroup slots, weighed against the four warm-up planes every chunk marches before its first output
+    constexpr int WX = 64 * (kLaneBytes / (int)sizeof(Real));
+    int widest = 0;
+    triple_windows_ = wv::triple_windows(pitch_ / WX, triple_win_, &widest, false, wv::triple_max_waves(kLaneBytes));
+    if (triple_windows_ < 0) {
+        triple_ready_ = false;
+        return WV_OK;
+    }
+    triple_nw_ = widest;
+    triple_strips_ = (ny_ + wv::kTripleRows - 1) / wv::kTripleRows;
+    const size_t lds = wv::triple_lds_bytes(triple_nw_, false, kLaneBytes);
+    const int by_lds = std::max<int>(1, (int)((160u * 1024u) / lds));
+    const int by_waves = std::max(1, (kLaneBytes == 16 ? 8 : 12) / triple_nw_);
+    const int64_t slots = 256ll * std::min(by_lds, by_waves);
+    const int owned = z_end_ - z_begin_;
+    int chunks = opt_.tuning.triple_chunks;
+    if (chunks <= 0) {
+        double best = 0;
+        chunks = 1;
+        for (int c = 1; c <= std::max(1, owned / 12) && c <= 256; ++c) {
+            const int64_t wgs = (int64_t)triple_strips_ * c * std::max(1, triple_windows_);
+            const int64_t rounds = (wgs + slots - 1) / slots;
+            const double zc = (double)((owned + c - 1) / c);
+            const double cost = (double)(rounds * slots) / (double)wgs * (zc + 4.0) / zc;
+            if (c == 1 || cost < best - 1e-9) {
+                best = cost;
+                chunks = c;
+            }
+        }
+    }
+    chunks = std::max(1, std::min(chunks, std::max(1, owned / 4)));
+    triple_zc_ = (owned + chunks - 1) / chunks;
+    triple_chunks_ = (owned + triple_zc_ - 1) / triple_zc_;
+    if (!triple_attr_set_) {
+        WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, kLaneBytes>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        triple_attr_set_ = true;
+    }
+    triple_ready_ = true;
+    return WV_OK;
+}
+
+// Steps `slot` .. `slot + 2` of a batch in one pass.  The flag words of the batch hold the mesh-static bits already (run()).
+template <typename Real>
+int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live) {
+    DeviceGuard guard(device_);
+    Real* A = field_[prv_];
+    Real* B = field_[cur_];
+    Real* O1 = field1_;
+    Real* O2 = field_[spare_[0]];
+    Real* O3 = field_[spare_[1]];
+    int* flag1 = flags_ + slot;
+    int* flag2 = flags_ + slot + 1;
+    int* flag3 = flags_ + slot + 2;
+    int rc;
+    const bool io = n_recv_ || source_live;
+    if (!pre_post_done_ && io) {  // step t: source sample into t, receivers from t
+        wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
+        pp.flag = nullptr;
+        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    }
+    pre_post_done_ = false;
+    wv::TripleArgs<Real> a{};
+    a.prev = A;
+    a.cur = B;
+    a.out1 = O1;
+    a.out2 = O2;
+    a.out3 = O3;
+    a.map = triple_map_;
+    a.suspect = suspect_ + slot;
+    a.ny = ny_;
+    a.nz = nz_;
+    a.pitch = pitch_;
+    a.cls_pitch = cls_pitch_;
+    a.z_begin = z_begin_;
+    a.z_end = z_end_;
+    a.nw = triple_nw_;
+    a.zc = triple_zc_;
+    a.chunks = triple_chunks_;
+    a.strips = triple_strips_;
+    a.strips_per_xcd = (triple_strips_ + 7) / 8;
+    a.windows = triple_windows_;
+    for (int k = 0; k < triple_windows_; ++k) {
+        a.win_first |= (uint64_t)triple_win_[0][k] << (8 * k);
+        a.win_count |= (uint64_t)triple_win_[1][k] << (8 * k);
+        a.win_store_lo |= (uint64_t)triple_win_[2][k] << (8 * k);
+        a.win_store_hi |= (uint64_t)triple_win_[3][k] << (8 * k);
+    }
+    const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
+    const bool timed = time_this_launch();
+    if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+    hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
+                       wv::triple_lds_bytes(triple_nw_, false, kLaneBytes), stream_, a);
+    if (timed) {
+        WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+        timed_steps_ += 3;
+    }
+    pass_timed_ = timed && (part_timing_calls_++ & 7u) == 0;
+    {
+        wv::TripleFlagsArgs<Real> f{};
+        f.prev = A;
+        f.cur = B;
+        f.out2 = O2;
+        f.out3 = O3;
+        f.pair_map = pair_map_;
+        f.suspect = suspect_ + slot;
+        f.flag1 = flag1;
+        f.flag2 = flag2;
+        f.flag3 = flag3;
+        f.source_node = source_live ? source_node_ : ~0ull;
+        f.nx = nx_;
+        f.ny = ny_;
+        f.nz = nz_;
+        f.pitch = pitch_;
+        f.cls_pitch = cls_pitch_;
+        f.z_begin = z_begin_;
+        f.z_end = z_end_;
+        hipLaunchKernelGGL(wv::triple_flags_kernel<Real>, dim3(1024), dim3(256), 0, stream_, f);
+    }
+    // level 1: boundary nodes to t+1
+    int token = begin_part_timing(0);
+    if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false))) return rc;
+    if ((rc = end_part_timing(0, token))) return rc;
+    if (io) {
+        wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
+        pp.flag = nullptr;
+        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    }
+    // level 2: the second level's list (as in a two-step pass), then the boundary nodes, whose 1-D entries finish the nodes they face
+    if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+    token = begin_part_timing(1);
+    if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2, pair_inner_ok_ > 0, false))) return rc;
+    if ((rc = end_part_timing(1, token))) return rc;
+    if (io) {
+        wv::PrePostArgs<Real> pp = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
+        pp.flag = nullptr;
+        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    }
+    // level 3: every shell node from the finished t+2 field, then the boundary nodes
+    if (triple_list_n_) {
+        wv::PairFixupArgs<Real> f{};
+        f.nodes = triple_list_;
+        f.n = triple_list_n_;
+        f.t1 = O2;
+        f.cur = O1;
+        f.out2 = O3;
+        f.flag2 = flag3;
+        f.nx = nx_;
+        f.ny = ny_;
+        f.nz = nz_;
+        f.pitch = pitch_;
+        hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((triple_list_n_ + 255) / 256), dim3(256), 0, stream_, f);
+    }
+    if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false))) return rc;
+    pass_timed_ = false;
+    WV_HIP(hipGetLastError());
+    ++triples_taken_;
+    xw_valid_ = false;  // (the x-facing walls' compact copies belong to the two-step passes)
+    // roles: (previous, current) = (t+2, t+3); the fields that held t-1 and t are the spares now
+    const int a_idx = prv_, b_idx = cur_;
+    prv_ = spare_[0];
+    cur_ = spare_[1];
+    spare_[0] = a_idx;
+    spare_[1] = b_idx;
+    return WV_OK;
+}
+
+}  // namespace wv

@@ -509,4 +509,146 @@ __global__ void __launch_bounds__(64 * triple_max_waves(LB)) triple_march_kernel
         triple_march_body<Real, X, false, PVDMA, LB>(a);
 }
 
+// ---- the triple map and the third level's fix-up list, once per (mesh, source node, receiver set) ------------------------------
+// From the two-step pass's map (pair_map_kernel: 3 = takes the 7-point update and has a neighbour that does not, or the source node for
+// a neighbour): a node that takes the 7-point update is a SHELL node when it or one of its six neighbours has that code -- something
+// other than a plain node lies within two nodes of it -- and deep otherwise.  Shell nodes are the third level's fix-up list (their t+3
+// is recomputed from the finished t+2 field; those with pair code 3 are the second level's list, as in a two-step pass).  One thread
+// per map byte (four nodes of a row); lists are written in map order, by a block scan (count pass, host scan over blocks, fill pass).
+struct TripleMapArgs {
+    const uint8_t* pair_map;
+    uint8_t* map;
+    uint32_t* block_count;   // count pass: [blocks] listed nodes per block; fill pass: exclusive offsets
+    uint32_t* list;          // fill pass: stored indices of the shell nodes; null: count pass
+    int ny, nz, pitch, cls_pitch;
+    int z_begin, z_end;      // planes this engine owns (nodes outside them are not listed)
+};
+
+__global__ void __launch_bounds__(256) triple_map_kernel(const TripleMapArgs a) {
+    __shared__ uint32_t scan[256];
+    const int64_t n_bytes = (int64_t)a.cls_pitch * a.ny * a.nz;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t out = 0, mine = 0;
+    int xb = 0, y = 0, z = 0;
+    if (i < n_bytes) {
+        xb = (int)(i % a.cls_pitch);
+        const int64_t row = i / a.cls_pitch;
+        y = (int)(row % a.ny);
+        z = (int)(row / a.ny);
+        auto code_at = [&](int x, int yy, int zz) -> uint32_t {  // off the grid: plain
+            if (x < 0 || x >= a.pitch || yy < 0 || yy >= a.ny || zz < 0 || zz >= a.nz) return 1u;
+            return (a.pair_map[cls_byte_index(x, yy, zz, a.ny, a.cls_pitch)] >> ((x & 3) * 2)) & 3u;
+        };
+        for (int k = 0; k < 4; ++k) {
+            const int x = xb * 4 + k;
+            const uint32_t pc = code_at(x, y, z);
+            uint32_t code = pc;
+            if (pc & 1u) {
+                const bool shell = pc == 3u || code_at(x - 1, y, z) == 3u || code_at(x + 1, y, z) == 3u || code_at(x, y - 1, z) == 3u ||
+                                   code_at(x, y + 1, z) == 3u || code_at(x, y, z - 1) == 3u || code_at(x, y, z + 1) == 3u;
+                code = shell ? 3u : 1u;
+                if (shell && z >= a.z_begin && z < a.z_end) ++mine;
+            }
+            out |= code << (2 * k);
+        }
+        if (!a.list) a.map[cls_byte_index(xb * 4, y, z, a.ny, a.cls_pitch)] = (uint8_t)out;
+    }
+    // exclusive scan of `mine` over the block
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)d ? scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (!a.list) {
+        if (threadIdx.x == 255) a.block_count[blockIdx.x] = scan[255];
+        return;
+    }
+    uint32_t at = a.block_count[blockIdx.x] + scan[threadIdx.x] - mine;
+    if (i < n_bytes && z >= a.z_begin && z < a.z_end)
+        for (int k = 0; k < 4; ++k)
+            if (((out >> (2 * k)) & 3u) == 3u) a.list[at++] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + xb * 4 + k);
+}
+
+// receiver nodes and the source node that came out deep: shell all the same -- their t+1 has to be in the t+1 field (the source's
+// sample goes into it, a receiver reads it).  After the list has been made: they need no fix-up.
+struct TripleMarkArgs {
+    uint8_t* map;
+    const uint64_t* recv;  // stored indices, ~0 = not recorded
+    uint32_t n_recv;
+    uint64_t source_node;  // ~0 = none
+    int ny, pitch, cls_pitch;
+};
+
+__global__ void __launch_bounds__(256) triple_mark_kernel(const TripleMarkArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > a.n_recv) return;
+    const uint64_t idx = t == a.n_recv ? a.source_node : a.recv[t];
+    if (idx == ~0ull) return;
+    const int x = (int)(idx % (uint64_t)a.pitch);
+    const uint64_t row = idx / (uint64_t)a.pitch;
+    const int64_t at = cls_byte_index(x, (int)(row % (uint64_t)a.ny), (int)(row / (uint64_t)a.ny), a.ny, a.cls_pitch);
+    uint32_t* const word = reinterpret_cast<uint32_t*>(a.map + (at & ~(int64_t)3));
+    const uint32_t shift = (uint32_t)(at & 3) * 8u + (uint32_t)(x & 3) * 2u;
+    // code 1 -> 3 (one more bit); every other code stays
+    if (((*word >> shift) & 3u) == 1u) atomicOr(word, 2u << shift);
+}
+
+// ---- exact error bits of the values the march is the last to write, when it has seen an inf or a nan (never in a healthy run) -------
+// Launched behind every march; leaves at once unless `suspect` is set.  t+1 of every node that takes the 7-point update (recomputed:
+// a deep node's t+1 is not stored); t+2 where nothing but plain nodes lies within one node, t+3 within two (the placeholders' owners --
+// fix-up lists, boundary launches -- test their own values).
+template <typename Real>
+struct TripleFlagsArgs {
+    const Real *prev, *cur, *out2, *out3;
+    const uint8_t* pair_map;  // 1: the node and its six neighbours are plain
+    const int* suspect;
+    int *flag1, *flag2, *flag3;
+    uint64_t source_node;
+    int nx, ny, nz, pitch, cls_pitch;
+    int z_begin, z_end;
+};
+
+template <typename Real>
+__global__ void __launch_bounds__(256) triple_flags_kernel(const TripleFlagsArgs<Real> a) {
+    if (*a.suspect == 0) return;
+    const int64_t plane = (int64_t)a.pitch * a.ny;
+    const int64_t n = plane * (a.z_end - a.z_begin);
+    auto pc_at = [&](int x, int y, int z) -> uint32_t {
+        if (x < 0 || x >= a.pitch || y < 0 || y >= a.ny || z < 0 || z >= a.nz) return 1u;
+        return (a.pair_map[cls_byte_index(x, y, z, a.ny, a.cls_pitch)] >> ((x & 3) * 2)) & 3u;
+    };
+    auto at = [&](const Real* f, int x, int y, int z) -> Real {
+        if (x < 0 || x >= a.nx || y < 0 || y >= a.ny || z < 0 || z >= a.nz) return Real(0);
+        return f[(int64_t)z * plane + (int64_t)y * a.pitch + x];
+    };
+    int bad1 = 0, bad2 = 0, bad3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.pitch);
+        const int64_t q = i / a.pitch;
+        const int y = (int)(q % a.ny), z = a.z_begin + (int)(q / a.ny);
+        const uint32_t pc = pc_at(x, y, z);
+        if (!(pc & 1u)) continue;
+        Real s = Real(0) + at(a.cur, x - 1, y, z);
+        s += at(a.cur, x + 1, y, z);
+        s += at(a.cur, x, y - 1, z);
+        s += at(a.cur, x, y + 1, z);
+        s += at(a.cur, x, y, z - 1);
+        s += at(a.cur, x, y, z + 1);
+        s = div3(s);
+        s -= at(a.prev, x, y, z);
+        bad1 |= bad_bits(s);
+        if (pc != 1u) continue;  // t+2 is somebody else's (a fix-up list, a boundary entry)
+        bad2 |= bad_bits(at(a.out2, x, y, z));
+        const bool deep = pc_at(x - 1, y, z) == 1u && pc_at(x + 1, y, z) == 1u && pc_at(x, y - 1, z) == 1u && pc_at(x, y + 1, z) == 1u &&
+                          pc_at(x, y, z - 1) == 1u && pc_at(x, y, z + 1) == 1u;
+        if (deep) bad3 |= bad_bits(at(a.out3, x, y, z));
+    }
+    if (bad1) atomicOr(a.flag1, bad1);
+    if (bad2) atomicOr(a.flag2, bad2);
+    if (bad3) atomicOr(a.flag3, bad3);
+}
+
 }  // namespace wv

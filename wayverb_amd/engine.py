@@ -47,12 +47,13 @@ class WvMesh(C.Structure):
 
 TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "pair_units_by_chunk", "tile_lists",
                  "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_xwall",
-                 "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks", "slab_early", "pair_split_rows", "fuse_planes", "whole_step")
+                 "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks", "slab_early", "pair_split_rows", "fuse_planes", "whole_step", "triple",
+                 "triple_chunks")
 
 
 class WvTuning(C.Structure):
     """wv_tuning (include/wayverb_amd.h): how the engine does its work, never what it computes."""
-    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 3)]
+    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 1)]
 
 
 class WvOptions(C.Structure):
@@ -481,6 +482,7 @@ class Engine:
     QUERY_HALO_WAIT_NS, QUERY_HALO_WAITS, QUERY_HALO_EXCHANGES, QUERY_HALO_BYTES_SENT, QUERY_EARLY_PASSES = 6, 7, 8, 9, 10
     QUERY_BOUNDARY1_NS, QUERY_BOUNDARY2_NS, QUERY_BOUNDARY_TIMED = 11, 12, 13
     QUERY_WHOLE_STEPS = 14
+    QUERY_TRIPLE_PASSES = 15
 
     def query(self, what):
         """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
