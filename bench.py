@@ -395,6 +395,7 @@ def run_bench(args, guard):
     fence()
     eng.enable_kernel_timing(True)
     eng.kernel_time_ms()
+    passes_before = (eng.query(E.Engine.QUERY_PASSES), eng.query(E.Engine.QUERY_TRIPLE_PASSES))
     guard.phase = "timed region (%d steps)" % args.steps
     t0 = time.perf_counter()
     run(args.steps)
@@ -423,7 +424,22 @@ def run_bench(args, guard):
     Q = E.Engine
     b_n = eng.query(Q.QUERY_BOUNDARY_TIMED)
     boundary_ms = [eng.query(Q.QUERY_BOUNDARY1_NS) / 1e6 / b_n, eng.query(Q.QUERY_BOUNDARY2_NS) / 1e6 / b_n] if b_n else None
+    # three-step passes (an account of their own: a run of K steps is K // 3 of them and then a two-step pass or a single step)
+    pair_passes = eng.query(Q.QUERY_PASSES) - passes_before[0]
+    triple_passes = eng.query(Q.QUERY_TRIPLE_PASSES) - passes_before[1]
+    t_n = eng.query(Q.QUERY_TRIPLE_MARCH_TIMED)
+    triple_ms = eng.query(Q.QUERY_TRIPLE_MARCH_NS) / 1e6 / t_n if t_n else None
+    tp_n = eng.query(Q.QUERY_TRIPLE_PARTS_TIMED)
+    triple_parts_ms = [eng.query(Q.QUERY_BOUNDARY3_NS) / 1e6 / tp_n, eng.query(Q.QUERY_FIXUP3_NS) / 1e6 / tp_n] if tp_n else None
     kernel_ms, launches, timed_steps = eng.kernel_time_detail()
+    other_kernel = None
+    three_step = bool(t_n) and triple_passes * 3 >= pair_passes * 2
+    if three_step:
+        # the dominant kernel is the three-step march; what the leftover steps of each run took (a two-step march or a sweep) goes along
+        if launches:
+            other_kernel = {"kernel": "pair_march_kernel" if timed_steps / launches > 1.5 else "stream_sweep_kernel", "kernel_ms": round(kernel_ms, 4),
+                            "launches": int(launches), "time_steps_per_launch": round(timed_steps / launches, 3)}
+        kernel_ms, launches, timed_steps = triple_ms, t_n, 3 * t_n
     eng.enable_kernel_timing(False)
     windows = None
     if window_steps:
@@ -454,7 +470,7 @@ def run_bench(args, guard):
     # updated by two small launches before the halo exchange) at N>1; time steps per launch: 2 when
     # the engine took two-step passes (N=1 on a mesh this size), else 1
     steps_per_launch = (timed_steps / launches) if launches else 1.0
-    two_step = steps_per_launch > 1.5
+    two_step = steps_per_launch > 1.5   # (more than one: the fields cross the HBM interface once per PASS, 4 x elem bytes per node)
     timed_planes = (layout.z1 - layout.z0) - (int(layout.ghost_lo) + int(layout.ghost_hi))
     # Algorithmic bytes of one launch = what the kernel has to move if every value crosses the HBM
     # interface once: the single-step sweep reads 2 fields and writes 1 per node
@@ -466,7 +482,7 @@ def run_bench(args, guard):
     # the same launch priced at the single-step figure (24 B per node-update): what a one-step-per-pass
     # kernel would have to sustain to keep up -- above the HBM peak is the point of the two-step pass
     per_update_equiv = 3 * elem * nx * ny * timed_planes * steps_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    kernel_name = "pair_march_kernel" if two_step else "stream_sweep_kernel"
+    kernel_name = "triple_march_kernel" if three_step else ("pair_march_kernel" if two_step else "stream_sweep_kernel")
     if not two_step and world == 1 and eng.query(eng.QUERY_WHOLE_STEPS) > 0:
         kernel_name = "whole_step_kernel"  # (a mesh that lives in the Infinity Cache: the step's sweep AND boundary work in one launch)
     # HBM traffic from the PMC passes (tools/measure_traffic.sh -> profiles/traffic.json): quoted only
@@ -493,15 +509,20 @@ def run_bench(args, guard):
     boundary_alg = [level1, level1 + 64 * n_b[0]]
     boundary = None
     if boundary_ms:
-        boundary = {"launches_per_pass": 2, "ms": [round(boundary_ms[0], 4), round(boundary_ms[1], 4)], "timed_passes": int(b_n),
+        boundary = {"launches_per_pass": 3 if three_step else 2, "ms": [round(boundary_ms[0], 4), round(boundary_ms[1], 4)], "timed_passes": int(b_n),
                     "alg_bytes_per_launch": boundary_alg,
                     "alg_bytes_definition": "168 B per 1-D boundary node and level (+ 104 B per further filter of a 2-D / 3-D node; + 64 B in the "
                                             "second launch for the inside node a 1-D node faces): %d / %d / %d nodes" % tuple(n_b),
                     "achieved_gbs": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(boundary_alg, boundary_ms)],
                     "traffic": boundary_traffic,
-                    "share_of_a_pass": round(sum(boundary_ms) / (sum(boundary_ms) + kernel_ms), 4) if kernel_ms > 0 else None,
+                    "share_of_a_pass": round((sum(boundary_ms) + (sum(triple_parts_ms) if three_step and triple_parts_ms else 0.0))
+                                             / (sum(boundary_ms) + (sum(triple_parts_ms) if three_step and triple_parts_ms else 0.0) + kernel_ms), 4) if kernel_ms > 0 else None,
                     "note": "the march holds every register of every CU, so these run behind it, not beside it: "
-                            "ms_per_step ~ (kernel_ms + ms[0] + ms[1]) / time_steps_per_launch"}
+                            "ms_per_step ~ (kernel_ms + the launches behind it) / time_steps_per_launch"}
+        if three_step and triple_parts_ms:
+            boundary["third_level_ms"] = {"boundary_nodes_to_t3": round(triple_parts_ms[0], 4), "fixup_list_of_the_shell_nodes": round(triple_parts_ms[1], 4),
+                                          "note": "a three-step pass: boundary launches to t+1, t+2 (ms above; the second also finishes the nodes its 1-D entries face), "
+                                                  "to t+3, and the list of every node within two of something that is not a plain node, recomputed from the finished t+2 field"}
     triad = None
     if world == 1:
         try:
@@ -538,21 +559,30 @@ def run_bench(args, guard):
                      # which bound the algorithmic figures are fractions of: the dominant kernel's own algorithmic bytes (NOT SURVEY.md
                      # 8(d)'s 24 B per node-update when the engine takes two-step passes -- that figure is below as
                      # single_step_equivalent / whole_step_frac_at_24B_per_update)
-                     "frac_bound": ("two-step pass, %d B per node-update (4 fields x %d B per node and launch)" % (2 * elem, elem)) if two_step
+                     "frac_bound": ("three-step pass, %.1f B per node-update (4 fields x %d B per node and launch)" % (4 * elem / 3.0, elem)) if three_step
+                                   else ("two-step pass, %d B per node-update (4 fields x %d B per node and launch)" % (2 * elem, elem)) if two_step
                                    else ("single-step sweep, %d B per node-update" % (3 * elem)),
                      # the WHOLE step (march + boundary launches + source / receiver work + gaps) at that same bound
-                     "whole_step_frac": round((fields_per_launch / steps_per_launch if launches else 3) * elem * owned_nodes
+                     # (a timed region of mixed passes: 4 fields per pass of either kind, 3 per single step)
+                     "whole_step_frac": round((4 * (triple_passes + pair_passes) + 3 * max(0, args.steps - 3 * triple_passes - 2 * pair_passes)) * elem * owned_nodes
+                                              / elapsed / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else
+                                        round((fields_per_launch / steps_per_launch if launches else 3) * elem * owned_nodes
                                               / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                      "time_steps_per_launch": round(steps_per_launch, 3),
                      "alg_bytes_per_launch": alg_bytes,
-                     "alg_bytes_definition": ("two-step pass: read fields t-1, t, write t+1, t+2 = 4 x %d B per node and launch "
+                     "alg_bytes_definition": ("three-step pass: read fields t-1, t, write t+2, t+3 = 4 x %d B per node and launch "
+                                              "(10.7 B per node-update in fp64; t+1 is stored only within two nodes of a wall / the source / at receivers: not counted)" % elem) if three_step else
+                                             ("two-step pass: read fields t-1, t, write t+1, t+2 = 4 x %d B per node and launch "
                                               "(16 B per node-update in fp64)" % elem) if two_step else
                                              ("single-step sweep: read 2 fields, write 1 = 3 x %d B per node-update" % elem),
                      "single_step_equivalent": {"bytes_per_node_update": 3 * elem, "achieved": round(per_update_equiv, 1),
                                                 "frac": round(per_update_equiv / HBM_PEAK_GBS, 4)},
                      "triad_gbs": triad,
+                     "passes_in_the_timed_region": {"three_step": int(triple_passes), "two_step": int(pair_passes),
+                                                    "single_steps": int(max(0, args.steps - 3 * triple_passes - 2 * pair_passes))},
+                     "other_kernel": other_kernel,
                      "boundary": boundary,
                      "whole_step_frac_at_24B_per_update": round(3 * elem * owned_nodes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }

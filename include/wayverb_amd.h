@@ -285,7 +285,13 @@ enum { WV_QUERY_PASSES = 0, WV_QUERY_XWALL_ENTRIES = 1, WV_QUERY_FIELDS = 2, WV_
         * to t+2), over that many passes; reset by wv_kernel_time */
        WV_QUERY_BOUNDARY1_NS = 11, WV_QUERY_BOUNDARY2_NS = 12, WV_QUERY_BOUNDARY_TIMED = 13,
        WV_QUERY_WHOLE_STEPS = 14 /* single steps taken as one launch each (wv_tuning::whole_step) */,
-       WV_QUERY_TRIPLE_PASSES = 15 };
+       WV_QUERY_TRIPLE_PASSES = 15,
+       /* kernel timing of the three-step passes (wv_enable_kernel_timing; reset by wv_kernel_time_ms like the rest): total time and count
+        * of the timed three-step marches (kept apart from wv_kernel_time_ms's account, which is the two-step march's or the sweep's); of
+        * the passes whose parts were timed (every eighth timed pass): their third boundary launch and their third-level fix-up list
+        * (WV_QUERY_BOUNDARY1_NS / 2_NS count the first two boundary launches of either kind of pass) */
+       WV_QUERY_TRIPLE_MARCH_NS = 16, WV_QUERY_TRIPLE_MARCH_TIMED = 17, WV_QUERY_BOUNDARY3_NS = 18, WV_QUERY_FIXUP3_NS = 19,
+       WV_QUERY_TRIPLE_PARTS_TIMED = 20 };
 int wv_query(wv_engine* e, int what, uint64_t* value);
 /* hipStreamSynchronize on every engine stream. */
 int wv_synchronize(wv_engine* e);

@@ -83,7 +83,7 @@ public:
     bool slab_early_now() const;
     int begin_halo_wait_timing();
     int end_halo_wait_timing(int token);
-    int begin_part_timing(int part);
+    int begin_part_timing(int part, bool always = false);
     int end_part_timing(int part, int token);
     int enqueue_batch_pair(uint64_t i, int part, int next_kind) override;
     int batch_pair_eligible(int* eligible) override;
@@ -246,10 +246,13 @@ private:
     double halo_wait_ms_ = 0;
     uint64_t halo_wait_n_ = 0, early_passes_ = 0;
     // kernel timing of a two-step pass's two boundary launches (part 0: nodes to t+1, part 1: to t+2), in the passes whose march is timed
-    std::vector<hipEvent_t> part_events_[2];
-    int part_ev_used_[2] = {0, 0};
-    double part_ms_[2] = {0, 0};
-    uint64_t part_n_[2] = {0, 0};
+    // (three-step passes: [2] boundary nodes to t+3, [3] the third level's fix-up list, [4] the three-step march itself -- kept apart
+    // from the two-step march's account, a batch may take both kinds of pass)
+    static constexpr int kParts = 5;
+    std::vector<hipEvent_t> part_events_[kParts];
+    int part_ev_used_[kParts] = {0, 0, 0, 0, 0};
+    double part_ms_[kParts] = {0, 0, 0, 0, 0};
+    uint64_t part_n_[kParts] = {0, 0, 0, 0, 0};
     bool pass_timed_ = false;
     unsigned part_timing_calls_ = 0;
     std::vector<uint32_t> plane_start_, plane_start_rest_;

@@ -33,7 +33,7 @@ int Engine<Real>::drain_timing() {
         ++halo_wait_n_;
     }
     halo_ev_used_ = 0;
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < kParts; ++p) {
         for (int i = 0; i + 1 < part_ev_used_[p]; i += 2) {
             float ms = 0;
             WV_HIP(hipEventElapsedTime(&ms, part_events_[p][i], part_events_[p][i + 1]));
@@ -48,8 +48,8 @@ int Engine<Real>::drain_timing() {
 // Kernel timing of the boundary launches of a two-step pass whose march is timed (bench.py's roofline.boundary: what stands between
 // the dominant kernel's rate and the whole step's).
 template <typename Real>
-int Engine<Real>::begin_part_timing(int part) {
-    if (!timing || !pass_timed_) return -1;
+int Engine<Real>::begin_part_timing(int part, bool always) {
+    if (!timing || !(pass_timed_ || always)) return -1;
     auto& ev = part_events_[part];
     if (ev.empty()) {
         ev.resize(2 * 512);
@@ -335,7 +335,7 @@ int Engine<Real>::kernel_time(double* mean_ms, uint64_t* launches, uint64_t* ste
     halo_wait_ms_ = 0;
     halo_wait_n_ = 0;
     halo_timing_calls_ = 0;
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < kParts; ++p) {
         part_ms_[p] = 0;
         part_n_[p] = 0;
     }
@@ -379,6 +379,11 @@ int Engine<Real>::query(int what, uint64_t* value) {
         case WV_QUERY_BOUNDARY_TIMED: *value = std::min(part_n_[0], part_n_[1]); return WV_OK;
         case WV_QUERY_WHOLE_STEPS: *value = whole_steps_; return WV_OK;
         case WV_QUERY_TRIPLE_PASSES: *value = triples_taken_; return WV_OK;
+        case WV_QUERY_BOUNDARY3_NS: *value = (uint64_t)(part_ms_[2] * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_FIXUP3_NS: *value = (uint64_t)(part_ms_[3] * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_TRIPLE_PARTS_TIMED: *value = std::min(part_n_[2], part_n_[3]); return WV_OK;
+        case WV_QUERY_TRIPLE_MARCH_NS: *value = (uint64_t)(part_ms_[4] * 1e6 + 0.5); return WV_OK;
+        case WV_QUERY_TRIPLE_MARCH_TIMED: *value = part_n_[4]; return WV_OK;
         default: return fail(WV_E_INVALID_ARGUMENT, "unknown query");
     }
 }

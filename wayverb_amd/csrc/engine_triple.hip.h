@@ -220,15 +220,12 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         a.win_store_hi |= (uint64_t)triple_win_[3][k] << (8 * k);
     }
     const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
-    const bool timed = time_this_launch();
-    if (timed) WV_HIP(hipEventRecord(events_[ev_used_], stream_));
+    // (kernel timing: the march in an account of its own -- WV_QUERY_TRIPLE_MARCH_NS -- and, every eighth timed pass, its parts)
+    const bool timed = timing && time_this_launch();
+    int token = timed ? begin_part_timing(4, true) : -1;
     hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
                        wv::triple_lds_bytes(triple_nw_, false, kLaneBytes), stream_, a);
-    if (timed) {
-        WV_HIP(hipEventRecord(events_[ev_used_ + 1], stream_));
-        ev_used_ += 2;
-        timed_steps_ += 3;
-    }
+    if ((rc = end_part_timing(4, token))) return rc;
     pass_timed_ = timed && (part_timing_calls_++ & 7u) == 0;
     {
         wv::TripleFlagsArgs<Real> f{};
@@ -252,7 +249,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         hipLaunchKernelGGL(wv::triple_flags_kernel<Real>, dim3(1024), dim3(256), 0, stream_, f);
     }
     // level 1: boundary nodes to t+1
-    int token = begin_part_timing(0);
+    token = begin_part_timing(0);
     if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false))) return rc;
     if ((rc = end_part_timing(0, token))) return rc;
     if (io) {
@@ -271,6 +268,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
     // level 3: every shell node from the finished t+2 field, then the boundary nodes
+    token = begin_part_timing(3);
     if (triple_list_n_) {
         wv::PairFixupArgs<Real> f{};
         f.nodes = triple_list_;
@@ -285,7 +283,10 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         f.pitch = pitch_;
         hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((triple_list_n_ + 255) / 256), dim3(256), 0, stream_, f);
     }
+    if ((rc = end_part_timing(3, token))) return rc;
+    token = begin_part_timing(2);
     if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false))) return rc;
+    if ((rc = end_part_timing(2, token))) return rc;
     pass_timed_ = false;
     WV_HIP(hipGetLastError());
     ++triples_taken_;

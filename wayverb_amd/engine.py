@@ -483,6 +483,7 @@ class Engine:
     QUERY_BOUNDARY1_NS, QUERY_BOUNDARY2_NS, QUERY_BOUNDARY_TIMED = 11, 12, 13
     QUERY_WHOLE_STEPS = 14
     QUERY_TRIPLE_PASSES = 15
+    QUERY_TRIPLE_MARCH_NS, QUERY_TRIPLE_MARCH_TIMED, QUERY_BOUNDARY3_NS, QUERY_FIXUP3_NS, QUERY_TRIPLE_PARTS_TIMED = 16, 17, 18, 19, 20
 
     def query(self, what):
         """wv_query: two-step passes taken / wall nodes on compact copies / fields allocated."""
