@@ -401,6 +401,7 @@ def run_bench(args, guard):
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_mine = elapsed
     guard.phase = "after the timed region"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
@@ -419,7 +420,16 @@ def run_bench(args, guard):
                 "exposed_wait_us_per_wait": round(eng.query(Q.QUERY_HALO_WAIT_NS) / 1e3 / waits, 2) if waits else None,
                 "timed_waits": int(waits),
                 "passes_with_both_exchanges_under_the_march": int(eng.query(Q.QUERY_EARLY_PASSES)), "passes": int(eng.query(Q.QUERY_PASSES)),
+                "neighbours": int(layout.ghost_lo) + int(layout.ghost_hi), "ms_per_step": round(elapsed_mine / args.steps * 1e3, 4),
                 "rank": rank}
+        # ... of EVERY rank: rank 0 is an end slab with one neighbour, the least loaded of the chain -- the line carries them all and
+        # names the worst (the rank whose compute stream stood longest per wait; a middle rank, when the links are what costs)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, halo)
+        waited = [(h["exposed_wait_us_per_wait"] or 0.0, h["rank"]) for h in everyone]
+        worst = max(waited)[1]
+        halo = dict(everyone[worst], per_rank=everyone, worst_rank=worst,
+                    note="the figures at this level are the WORST rank's (longest exposed wait per timed wait); per_rank holds every rank's")
     # the two boundary launches of the timed passes (read before kernel_time_detail, which resets)
     Q = E.Engine
     b_n = eng.query(Q.QUERY_BOUNDARY_TIMED)
@@ -547,12 +557,10 @@ def run_bench(args, guard):
                    "halo_parity": halo_parity,
                    "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     # `frac`: at the MEASURED traffic when a PMC figure for this very kernel / workload / device code is on file
-                     # (what the memory system actually moved per launch / kernel_ms / peak), else at the algorithmic bytes
-                     "frac": round((traffic if traffic else alg_bytes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else 0.0,
-                     "frac_definition": ("traffic / kernel_ms / peak: HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, "
-                                         "gfx950 corrections) of the same kernel, workload and device code" if traffic else
-                                         "alg_bytes_per_launch / kernel_ms / peak (no PMC figure on file for this device code)"),
+                     # `frac`: the kernel's ALGORITHMIC bytes per launch / kernel_ms / peak, as in every round's BENCH file (round 5 had
+                     # switched it to the measured traffic where a PMC figure was on file: that one is `frac_measured_traffic` now)
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_definition": "alg_bytes_per_launch / kernel_ms / peak",
                      "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
                      "frac_measured_traffic": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_ms > 0 else None,
                      "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,

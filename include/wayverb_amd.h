@@ -220,7 +220,9 @@ int wv_device_buffer(wv_engine* e, int buffer, void** device_ptr);
  * put back (wv_rollback: the engine continues from the checkpoint and, being deterministic, reproduces the abandoned steps bit for
  * bit).  For callers that run batches of steps ahead of per-step observers: `canonical`'s pressure callback may look at the field
  * of ANY step (canonical.h:66-69), so the C++ mirror runs batches speculatively and re-runs up to the step an observer looks at.
- * The source and the receivers must be the ones in place at the checkpoint (WV_E_STATE otherwise); wv_drop_checkpoint frees the copy. */
+ * The source and the receivers must be the ones in place at the checkpoint (WV_E_STATE otherwise); wv_drop_checkpoint frees the copy.
+ * One domain only: a slab of a chain (ghost planes, or a communicator of more than one rank) answers WV_E_STATE -- its neighbours'
+ * planes and the transport's counters would have to go back with it. */
 int wv_checkpoint(wv_engine* e);
 int wv_rollback(wv_engine* e);
 int wv_drop_checkpoint(wv_engine* e);

@@ -20,23 +20,32 @@
 //
 // -- one line where the listener is connected (the application that calls
 // engine::connect_waveguide_node_pressures_changed, src/combined/src/engine.cpp:260-264; src/combined
-// itself stays as it is), or `cl_mirror_always()` for "whenever the callback runs".  While the predicate
-// is empty or returns false the buffer keeps its zeros and `canonical` runs whole batches of two-step
-// passes on the device; a step for which it returns true gets exactly its own field (if the run has already
+// itself stays as it is), or `cl_mirror_always()` for "whenever the callback runs", or `cl_mirror_never()`.
+// While the predicate returns false the buffer keeps its zeros and `canonical` runs whole batches of passes
+// on the device; a step for which it returns true gets exactly its own field (if the run has already
 // passed that step: roll back, re-run up to it -- waveguide.h, run_device_observed), and the run goes on
 // step by step for as long as it keeps returning true.  `cl_mirror_planes()` narrows the refresh to a
 // range of z planes (a visualiser's slice).
+//
+// NOBODY HAS SAID ANYTHING (the predicate is empty: a build that swapped the headers and added no line): the
+// buffer is not refreshed either -- an unchanged engine.cpp hands its callback to every run, listener or not, and
+// mirroring 4.3 GB per step for nobody would cost it a factor of 400 -- but it holds NaN, not zeros, and the first
+// such run says so on stderr: a visualiser that does read it shows nothing and the log says which line is missing,
+// instead of a silent field of zeros.
 #pragma once
 
+#include <cstdio>
 #include <functional>
+#include <limits>
 
 #include "waveguide.h"
 
 namespace wayverb {
 namespace waveguide {
 
-/// Empty (default) or returning false: nobody reads the cl::Buffer, it is not refreshed (it holds zeros).
+/// Returning false: nobody reads the cl::Buffer, it is not refreshed (it holds zeros).
 /// Returning true when evaluated for a step: that step's field is in the buffer when the callback runs.
+/// Empty (default): not refreshed either, but the buffer holds NaN and the first run warns on stderr (above).
 inline std::function<bool()>& cl_mirror_wanted() {
     static std::function<bool()> f;
     return f;
@@ -44,6 +53,10 @@ inline std::function<bool()>& cl_mirror_wanted() {
 /// `cl_mirror_wanted() = cl_mirror_always();` -- every step is mirrored (the behaviour of a plain OpenCL field).
 inline std::function<bool()> cl_mirror_always() {
     return [] { return true; };
+}
+/// `cl_mirror_wanted() = cl_mirror_never();` -- "nobody reads the buffer", said out loud: zeros, whole batches, no warning.
+inline std::function<bool()> cl_mirror_never() {
+    return [] { return false; };
 }
 /// Planes [z_begin, z_begin + z_count) are refreshed; z_count < 0 (default): the whole field.
 struct mirror_planes final {
@@ -67,15 +80,28 @@ public:
               queue_{cc.context, cc.device},
               buffer_{cc.context, CL_MEM_READ_WRITE, sizeof(cl_float) * nodes},
               nodes_{nodes} {
-        // zeros until somebody wants the field (make_zeroed_buffer is what the reference's own field starts as, waveguide.h:47-56)
+        // zeros until somebody wants the field (make_zeroed_buffer is what the reference's own field starts as, waveguide.h:47-56) --
+        // NaN when nobody has said whether anybody will (an empty predicate): a reader then sees that it is not looking at a field
+        const bool unset = !cl_mirror_wanted();
+        const cl_float fill = unset ? std::numeric_limits<cl_float>::quiet_NaN() : cl_float{0};
+        if (unset) {
+            static bool warned = false;
+            if (!warned) {
+                warned = true;
+                std::fprintf(stderr,
+                             "wayverb_amd: a pressure callback that takes a cl::Buffer is attached and waveguide::cl_mirror_wanted() has not "
+                             "been set: the buffer holds NaN, not the field.  Set it where the listener is connected -- a predicate that says "
+                             "when the field is read, cl_mirror_always() or cl_mirror_never() (wayverb_amd/cl_mirror.h).\n");
+            }
+        }
 #if defined(CL_VERSION_1_2)
-        queue_.enqueueFillBuffer(buffer_, cl_float{0}, 0, sizeof(cl_float) * nodes);
+        queue_.enqueueFillBuffer(buffer_, fill, 0, sizeof(cl_float) * nodes);
         queue_.finish();
 #else
-        const std::vector<float> zeros(std::min<size_t>(nodes, size_t{4} << 20), 0.0f);
-        for (size_t at = 0; at < nodes; at += zeros.size())
-            queue_.enqueueWriteBuffer(buffer_, CL_TRUE, sizeof(cl_float) * at, sizeof(cl_float) * std::min(zeros.size(), nodes - at),
-                                      zeros.data());
+        const std::vector<float> block(std::min<size_t>(nodes, size_t{4} << 20), fill);
+        for (size_t at = 0; at < nodes; at += block.size())
+            queue_.enqueueWriteBuffer(buffer_, CL_TRUE, sizeof(cl_float) * at, sizeof(cl_float) * std::min(block.size(), nodes - at),
+                                      block.data());
 #endif
     }
     bool wanted_now() const {

@@ -103,6 +103,38 @@ struct field_guard final {
 };
 }  // namespace detail
 
+namespace detail {
+/// The values a step's `post` reads, learned and then served without a trip to the device (run<pre, post> ahead of its callbacks):
+/// every index a callback reads through core::read_value on a `buffer` handle is noted; from the next batch on the engine records
+/// that node like a receiver, and the read is answered from the step's row.  A read of an index not (yet) in the plan goes to the
+/// engine -- through the field_guard, which brings that step's field back if the run has passed it.
+struct read_plan final {
+    std::vector<uint64_t> indices;  // in column order
+    size_t served_columns = 0;      // how many of them the row in `row` holds
+    const double* row = nullptr;    // the step being fired: [served_columns]
+    bool grew = false;              // indices were added since the engine was last told
+    size_t reads_served = 0, reads_missed = 0;
+    bool serve(size_t index, double* v) {
+        for (size_t c = 0; c < indices.size(); ++c)  // (a handful of receivers: a linear look-up beats a map)
+            if (indices[c] == index) {
+                if (row && c < served_columns) {
+                    *v = row[c];
+                    ++reads_served;
+                    return true;
+                }
+                ++reads_missed;
+                return false;
+            }
+        if (indices.size() < 4096) {  // (a callback that reads whole fields value by value keeps its per-step path)
+            indices.push_back(index);
+            grew = true;
+        }
+        ++reads_missed;
+        return false;
+    }
+};
+}  // namespace detail
+
 /// What a step callback sees instead of cl::CommandQueue (hard_source.h:17, directional_receiver.h:36).
 class queue final {
 public:
@@ -115,8 +147,9 @@ private:
 /// What a step callback sees instead of cl::Buffer: one of the engine's two pressure fields.
 class buffer final {
 public:
-    buffer(wv_engine* e, int which, size_t items, int precision = WV_PRECISION_F64, detail::field_guard* guard = nullptr)
-            : e_{e}, which_{which}, items_{items}, precision_{precision}, guard_{guard} {}
+    buffer(wv_engine* e, int which, size_t items, int precision = WV_PRECISION_F64, detail::field_guard* guard = nullptr,
+           detail::read_plan* plan = nullptr)
+            : e_{e}, which_{which}, items_{items}, precision_{precision}, guard_{guard}, plan_{plan} {}
     /// The engine whose field this is, for wv_read_planes & co. on the handle.  Asking for it counts as looking at the
     /// field (in `canonical` the step's field is brought back first, see detail::field_guard).
     wv_engine* engine() const {
@@ -126,6 +159,8 @@ public:
     int which() const { return which_; }
     size_t items() const { return items_; }
     int precision() const { return precision_; }  // WV_PRECISION_*: how the engine stores pressures
+    /// a value the run has on the host already (detail::read_plan); false: ask the engine
+    bool served(size_t index, double* v) const { return plan_ && plan_->serve(index, v); }
 
 private:
     wv_engine* e_;
@@ -133,6 +168,7 @@ private:
     size_t items_;
     int precision_;
     detail::field_guard* guard_;
+    detail::read_plan* plan_;
 };
 
 }  // namespace waveguide
@@ -146,6 +182,7 @@ size_t items_in_buffer(const waveguide::buffer& b) {
 template <typename T>
 T read_value(waveguide::queue&, const waveguide::buffer& b, size_t index) {
     double v = 0;
+    if (b.served(index, &v)) return static_cast<T>(v);
     waveguide::detail::check(wv_read_value(b.engine(), b.which(), index, &v));
     return static_cast<T>(v);
 }
@@ -408,22 +445,68 @@ inline int& default_precision() {
 }
 
 // ---- run: arbitrary step callbacks (waveguide.h:36-126) -------------------------------------------
+namespace preprocessor {
+template <typename It>
+class hard_source;
+template <typename It>
+class soft_source;
+}  // namespace preprocessor
+namespace detail {
+// the step pre-processors the engine can run by itself (wv_set_source): this header's own hard_source / soft_source
+template <typename T>
+struct device_source : std::false_type {};
+template <typename It>
+struct device_source<preprocessor::hard_source<It>> : std::true_type {
+    static constexpr int kind = WV_SOURCE_HARD;
+};
+template <typename It>
+struct device_source<preprocessor::soft_source<It>> : std::true_type {
+    static constexpr int kind = WV_SOURCE_SOFT;
+};
+template <typename Context, typename Mesh, typename Source, typename step_postprocessor>
+size_t run_ahead(const Context& cc, const Mesh& mesh, Source& pre, step_postprocessor& post, const std::atomic_bool& keep_going);
+
+// the loop as the reference writes it: one host round trip per step, `pre` and `post` free to do anything to the field
 template <typename Context, typename Mesh, typename step_preprocessor, typename step_postprocessor>
-size_t run(const Context& cc, const Mesh& mesh, step_preprocessor&& pre, step_postprocessor&& post,
-           const std::atomic_bool& keep_going) {
-    auto engine = detail::make_engine(cc, mesh, default_precision());
+size_t run_step_by_step(const Context& cc, const Mesh& mesh, step_preprocessor& pre, step_postprocessor& post,
+                        const std::atomic_bool& keep_going) {
+    auto engine = make_engine(cc, mesh, default_precision());
     const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
     queue q{engine.get()};
     buffer current{engine.get(), WV_BUF_CURRENT, num_nodes, default_precision()};  // the handle follows the swaps
     size_t step = 0;
     for (; pre(q, current, step) && keep_going; ++step) {
         int32_t flag = 0;
-        detail::check(wv_step(engine.get(), &flag));
-        detail::throw_for_flag(flag);
+        check(wv_step(engine.get(), &flag));
+        throw_for_flag(flag);
         post(q, current, step);
-        detail::check(wv_swap(engine.get()));
+        check(wv_swap(engine.get()));
     }
     return step;
+}
+template <typename Context, typename Mesh, typename step_preprocessor, typename step_postprocessor>
+size_t run_dispatch(const Context& cc, const Mesh& mesh, step_preprocessor& pre, step_postprocessor& post, const std::atomic_bool& keep_going,
+                    std::true_type) {
+    return run_ahead(cc, mesh, pre, post, keep_going);
+}
+template <typename Context, typename Mesh, typename step_preprocessor, typename step_postprocessor>
+size_t run_dispatch(const Context& cc, const Mesh& mesh, step_preprocessor& pre, step_postprocessor& post, const std::atomic_bool& keep_going,
+                    std::false_type) {
+    return run_step_by_step(cc, mesh, pre, post, keep_going);
+}
+}  // namespace detail
+
+/// `pre` any callable: the reference's loop, a host round trip per step.  `pre` one of this header's preprocessor::hard_source /
+/// soft_source (what 10 of the reference's 11 call sites pass -- bin/boundary_test/boundary_test.cpp:137-147, src/waveguide/tests/
+/// waveguide_tests.cpp:95-107, ...): the source runs on the device and the steps are taken in batches AHEAD of `post`, which still fires
+/// once per step, in order, with the step's field behind its handle -- the values it reads through core::read_value are learned in the
+/// first steps and recorded on the device from then on (detail::read_plan); a read nobody has made before gets its step's field all
+/// the same (rollback, re-run: run_device_observed).  last_run_stats() says what a run did.
+template <typename Context, typename Mesh, typename step_preprocessor, typename step_postprocessor>
+size_t run(const Context& cc, const Mesh& mesh, step_preprocessor&& pre, step_postprocessor&& post,
+           const std::atomic_bool& keep_going) {
+    using source_t = typename std::decay<step_preprocessor>::type;
+    return detail::run_dispatch(cc, mesh, pre, post, keep_going, std::integral_constant<bool, detail::device_source<source_t>::value>{});
 }
 
 // ---- step pre-processors --------------------------------------------------------------------------
@@ -442,6 +525,7 @@ public:
     size_t get_node() const { return node_; }
     It begin() const { return begin_; }
     It end() const { return end_; }
+    void advance(size_t samples) { std::advance(begin_, samples); }  // (run: the device took them)
 
 private:
     size_t node_;
@@ -474,6 +558,7 @@ public:
     size_t get_node() const { return node_; }
     It begin() const { return begin_; }
     It end() const { return end_; }
+    void advance(size_t samples) { std::advance(begin_, samples); }  // (run: the device took them)
 
 private:
     size_t node_;
@@ -594,6 +679,8 @@ struct run_stats final {
     size_t steps_rerun = 0;      // steps computed a second time after a rollback
     size_t fields_looked_at = 0; // callbacks during which somebody looked at the field
     size_t fields_mirrored = 0;  // cl_mirror.h: whole-field (or plane-range) copies into the cl::Buffer
+    size_t reads_served = 0;     // run<pre, post> ahead of its callbacks: core::read_value calls answered from recorded rows ...
+    size_t reads_missed = 0;     // ... and those that went to the engine (the first steps, an index nobody had read before)
     uint64_t passes = 0;         // two-step passes the engine took (WV_QUERY_PASSES)
     double seconds = 0;          // wall time of the step loop (engine set-up excluded)
 };
@@ -602,11 +689,31 @@ inline run_stats& last_run_stats() {
     return s;
 }
 
+/// How long a batch of steps may keep the device to itself (seconds of predicted work, from the rate of the batch before): what bounds
+/// the latency of `keep_going` and the cadence of progress callbacks whatever the mesh size -- the reference looks at keep_going before
+/// every step (waveguide.h:80) and reports progress after every step (src/combined/src/engine.cpp:171-172); a batch of 256 steps of a
+/// 1024^3 mesh would be 0.7 s.  <= 0: batches are bounded by their step count only.
+inline double& batch_seconds() {
+    static double s = 0.05;
+    return s;
+}
+
 namespace detail {
 inline double seconds_now() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+}  // namespace detail
+
+namespace detail {
+/// steps that fit `batch_seconds()` at `step_seconds` per step (measured on the batch before; 0 = not known yet: `probe` steps)
+inline size_t steps_within_budget(double step_seconds, size_t probe) {
+    const double budget = batch_seconds();
+    if (budget <= 0) return ~size_t{0};
+    if (step_seconds <= 0) return probe;
+    const double n = budget / step_seconds;
+    return n < 1.0 ? size_t{1} : (n > 1e9 ? ~size_t{0} : (size_t)n);
 }
 }  // namespace detail
 
@@ -656,11 +763,14 @@ size_t run_device(const Context& cc, const Mesh& mesh, source_kind kind, size_t 
             stats.seconds = detail::seconds_now() - t0;
         }
     } finish{stats, engine.get(), done_total, t0};
+    double step_seconds = 0;  // of the batch before (the first batch is a short one that finds out)
     while (done_total < signal.size() && keep_going) {
-        const uint64_t want = std::min<uint64_t>(batch, signal.size() - done_total);
+        const uint64_t want = std::min<uint64_t>(std::min<uint64_t>(batch, detail::steps_within_budget(step_seconds, 8)), signal.size() - done_total);
         uint64_t done = 0;
         int32_t flag = 0;
+        const double t_batch = detail::seconds_now();
         detail::check(wv_run(engine.get(), want, &done, &flag));
+        if (done) step_seconds = (detail::seconds_now() - t_batch) / (double)done;
         if (done) {
             ++stats.batches;
             samples.resize((size_t)done * receivers.size());
@@ -774,7 +884,7 @@ template <typename Context, typename Mesh, typename It, typename MakeBridge, typ
 size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind, size_t source_node, It begin, It end,
                            const std::vector<uint64_t>& receivers, field_guard& guard, MakeBridge&& make_bridge,
                            WantedNow&& wanted_now, Observe&& observe, const std::atomic_bool& keep_going,
-                           size_t max_batch = 256, size_t hold_steps = 16) {
+                           size_t max_batch = 256, size_t hold_steps = 16, read_plan* plan = nullptr) {
     auto engine = make_engine(cc, mesh, default_precision());
     wv_engine* e = engine.get();
     std::vector<double> signal(begin, end);
@@ -784,9 +894,11 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
     run_stats& stats = last_run_stats();
     stats = run_stats{};
     const double t0 = seconds_now();
-    const size_t n_recv = receivers.size();
+    // (`plan`: the receivers are what the callbacks have been seen to read -- `receivers` is the plan's own list and grows)
+    size_t n_recv = receivers.size();
     size_t done_total = 0, batch = 1, hold = 0;
-    bool can_speculate = max_batch > 1;
+    double step_seconds = 0;  // of the batch before: batches are bounded by time as well as by count (batch_seconds())
+    bool can_speculate = max_batch > 1, cancelled = false;
     constexpr size_t never = ~size_t{0};
     size_t last_look = never, period = 0;  // the step last looked at; the interval between the last two looks
     bool periodic = false;                 // the next look is expected at last_look + period
@@ -797,6 +909,11 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
         stats.steps = done_total;
         stats.seconds = seconds_now() - t0;
         guard.materialise = nullptr;
+        if (plan) {
+            plan->row = nullptr;
+            stats.reads_served = plan->reads_served;
+            stats.reads_missed = plan->reads_missed;
+        }
     };
     try {
         while (done_total < signal.size() && keep_going) {
@@ -810,8 +927,16 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
                 }
             }
             if (wanted_now()) want = 1;
+            want = std::max<size_t>(1, std::min(want, steps_within_budget(step_seconds, want)));
+            if (plan && plan->grew) {  // what the callbacks read is recorded on the device from this batch on
+                check(wv_set_receivers(e, receivers.data(), (uint32_t)receivers.size()));
+                n_recv = receivers.size();
+                plan->grew = false;
+            }
+            bool have_checkpoint = false;
             if (want > 1) {
                 if (wv_checkpoint(e) == WV_OK) {
+                    have_checkpoint = true;
                     ++stats.checkpoints;
                 } else {  // no room for a copy of the fields: one step at a time from here on
                     can_speculate = false;
@@ -820,8 +945,10 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
             }
             uint64_t done = 0;
             int32_t flag = 0;
+            const double t_batch = seconds_now();
             check(wv_run(e, want, &done, &flag));
             if (done) {
+                step_seconds = (seconds_now() - t_batch) / (double)done;
                 ++stats.batches;
                 samples.resize((size_t)done * n_recv);
                 check(wv_fetch_receivers(e, done_total, done, samples.data()));
@@ -843,6 +970,10 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
                     stats.steps_rerun += i + 1;
                     rewound = true;
                 };
+                if (plan) {
+                    plan->row = samples.data() + i * n_recv;
+                    plan->served_columns = n_recv;
+                }
                 observe(done_total + i, samples.data() + i * n_recv);
                 ++fired;
                 if (guard.looked) {
@@ -855,8 +986,25 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
                     }
                     last_look = at;
                 }
+                // keep_going turned off by this step's observer: the reference tests it before every iteration (waveguide.h:80), so no later
+                // step's callback may fire -- and the engine goes back to where this step left it, if the batch has taken it further
+                if (!keep_going && i + 1 < (size_t)done) {
+                    if (!rewound && have_checkpoint) {
+                        check(wv_rollback(e));
+                        uint64_t again = 0;
+                        int32_t flag_again = 0;
+                        check(wv_run(e, i + 1, &again, &flag_again));
+                        if (again != i + 1 || flag_again)
+                            throw engine_error("wayverb_amd: the re-run after a rollback did not reproduce the batch");
+                        ++stats.rollbacks;
+                        stats.steps_rerun += i + 1;
+                    }
+                    cancelled = true;
+                    break;
+                }
             }
             done_total += fired;
+            if (cancelled) break;
             if (!rewound) {
                 throw_for_flag(flag);
                 if (done < want) break;
@@ -881,6 +1029,30 @@ size_t run_device_observed(const Context& cc, const Mesh& mesh, source_kind kind
     }
     finish();
     return done_total;
+}
+
+/// run<pre, post> with a source the device runs by itself (see `run`).
+template <typename Context, typename Mesh, typename Source, typename step_postprocessor>
+size_t run_ahead(const Context& cc, const Mesh& mesh, Source& pre, step_postprocessor& post, const std::atomic_bool& keep_going) {
+    const size_t num_nodes = mesh.get_structure().get_condensed_nodes().size();
+    field_guard guard;
+    read_plan plan;
+    std::unique_ptr<queue> q;
+    std::unique_ptr<buffer> current;  // (wv_run has swapped the fields when `post` fires: the step's pre-update `current` is PREVIOUS now)
+    const auto first = pre.begin(), last = pre.end();
+    const size_t steps = run_device_observed(
+            cc, mesh, static_cast<source_kind>(device_source<Source>::kind), pre.get_node(), first, last, plan.indices, guard,
+            [&](wv_engine* e) {
+                q.reset(new queue{e});
+                current.reset(new buffer{e, WV_BUF_PREVIOUS, num_nodes, default_precision(), &guard, &plan});
+            },
+            [] { return false; },
+            [&](size_t step, const double*) { post(*q, static_cast<const buffer&>(*current), step); }, keep_going, 256, 4, &plan);
+    // the source object is left as the reference's loop leaves it: one sample taken per completed step, and one more by the call
+    // that found keep_going off (waveguide.h:80: `pre` runs before keep_going is looked at)
+    const size_t n = (size_t)std::distance(first, last);
+    pre.advance(std::min(n, steps + (steps < n ? 1 : 0)));
+    return steps;
 }
 
 /// canonical.h:29-88.  `callback(queue, buffer, step, ideal_steps)` fires once per completed step, in

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <limits>
 
+#include <time.h>
+
 #include "wayverb_amd/waveguide.h"
 
 // ---- the stand-in engine ---------------------------------------------------------------------------------------------
@@ -20,16 +22,18 @@ struct wv_engine {
     std::vector<uint64_t> receivers;
     std::vector<double> signal;
     uint64_t nodes = 0;
-    std::vector<double> log;        // receiver rows of every completed step
+    std::vector<double> log;        // receiver rows of every completed step since the receivers were set
+    uint64_t recv_first_step = 0;
     size_t log_at_checkpoint = 0;
     uint64_t flag_at_step = ~0ull;  // wv_run stops at this step with WV_FLAG_NAN
     bool no_checkpoints = false;
     // counters the tests look at
-    uint64_t runs = 0, steps_run = 0, checkpoints = 0, rollbacks = 0, field_reads = 0;
+    uint64_t runs = 0, steps_run = 0, checkpoints = 0, rollbacks = 0, field_reads = 0, longest_run = 0, receiver_sets = 0, value_reads = 0;
 };
 static wv_engine* g_last_engine = nullptr;
 static uint64_t g_flag_at_step = ~0ull;
 static bool g_no_checkpoints = false;
+static double g_seconds_per_step = 0;  // wv_run takes this long per step (a big mesh): the header bounds its batches by time
 
 // the pre-update `current` of step s at node i (what waveguide.h:121 hands to `post`): any function that tells steps and nodes apart
 static float field_value(uint64_t s, uint64_t i) { return (float)((s * 131u + i * 7u) % 8191u) * 0.125f + (float)s; }
@@ -59,6 +63,10 @@ int wv_set_source(wv_engine* e, int, uint64_t, const double* s, uint64_t n) {
 }
 int wv_set_receivers(wv_engine* e, const uint64_t* nodes, uint32_t n) {
     e->receivers.assign(nodes, nodes + n);
+    e->recv_first_step = e->steps_done;  // (as the engine: rows are recorded from here on)
+    e->log.clear();
+    e->checkpoint = ~0ull;               // (... and a checkpoint taken with other receivers is of no use)
+    ++e->receiver_sets;
     return WV_OK;
 }
 int wv_run(wv_engine* e, uint64_t n, uint64_t* done, int32_t* flag) {
@@ -74,13 +82,19 @@ int wv_run(wv_engine* e, uint64_t n, uint64_t* done, int32_t* flag) {
         ++e->steps_done;
         ++e->steps_run;
     }
+    if (e->longest_run < k) e->longest_run = k;
+    if (g_seconds_per_step > 0 && k) {
+        const double s = g_seconds_per_step * (double)k;
+        timespec ts{(time_t)s, (long)((s - (double)(time_t)s) * 1e9)};
+        nanosleep(&ts, nullptr);
+    }
     *done = k;
     return WV_OK;
 }
 int wv_fetch_receivers(wv_engine* e, uint64_t first, uint64_t n, double* dst) {
     const size_t w = e->receivers.size();
-    if ((first + n) * w > e->log.size()) return WV_E_INVALID_ARGUMENT;
-    std::memcpy(dst, e->log.data() + first * w, (size_t)n * w * sizeof(double));
+    if (first < e->recv_first_step || (first - e->recv_first_step + n) * w > e->log.size()) return WV_E_INVALID_ARGUMENT;
+    std::memcpy(dst, e->log.data() + (first - e->recv_first_step) * w, (size_t)n * w * sizeof(double));
     return WV_OK;
 }
 int wv_checkpoint(wv_engine* e) {
@@ -110,6 +124,7 @@ int wv_read_field(wv_engine* e, int which, void* dst, int elem) {
 }
 int wv_read_value(wv_engine* e, int which, uint64_t index, double* v) {
     if (which != WV_BUF_PREVIOUS || e->steps_done == 0) return WV_E_INVALID_ARGUMENT;
+    ++e->value_reads;
     *v = (double)field_value(e->steps_done - 1, index);
     return WV_OK;
 }
@@ -241,7 +256,36 @@ int main() {
         g_no_checkpoints = false;
         REQUIRE(s.all_right && s.steps.size() == 4 && st.batches == 200 && st.checkpoints == 0 && st.rollbacks == 0);
     }
-    // ---- keep_going turned off by the callback: the run ends after the batch in flight, canonical returns nothing (canonical.h:84-87)
+    // ---- batches are bounded by time, not only by count: an engine that takes 2 ms per step (a 800^3 mesh) never gets more than
+    // ~25 steps (50 ms, waveguide::batch_seconds()) at a time, so that keep_going and the progress callbacks stay that close to the
+    // reference's per-step cadence; a cancel is honoured within the batch in flight
+    {
+        g_seconds_per_step = 0.002;
+        const auto s = run(300, [](size_t) { return false; }, &st, &eng);
+        REQUIRE(s.all_right && s.order.size() == 300 && eng.longest_run <= 32 && st.batches >= 300 / 32);
+        std::atomic_bool keep{true};
+        const auto mesh = waveguide::make_box_mesh(8, 7, 6, 0.05f, waveguide::to_flat_coefficients(0.1));
+        const core::environment env{};
+        const double sr = waveguide::compute_sample_rate(mesh.get_descriptor(), env.speed_of_sound);
+        size_t calls = 0;
+        double cancelled_at = 0, returned_at = 0;
+        const auto out = waveguide::canonical(context{}, mesh, kSource, kReceiver, env, waveguide::single_band_parameters{100.0, 0.6}, 499.5 / sr, keep,
+                                              [&](auto&, const auto&, auto step, auto) {
+                                                  ++calls;
+                                                  if (step == 200) {
+                                                      keep = false;
+                                                      cancelled_at = waveguide::detail::seconds_now();
+                                                  }
+                                              });
+        returned_at = waveguide::detail::seconds_now();
+        g_seconds_per_step = 0;
+        REQUIRE(!out && calls == 201);
+        REQUIRE(returned_at - cancelled_at < 2 * 0.05 + 0.02);  // (the re-run up to the cancelling step is at most one more batch)
+        std::printf("2 ms per step: batches of at most %llu steps; cancel honoured after %.0f ms\n", (unsigned long long)eng.longest_run,
+                    1e3 * (returned_at - cancelled_at));
+    }
+    // ---- keep_going turned off by the callback: no later step's callback fires, the engine is back where that step left it, canonical
+    // returns nothing (canonical.h:84-87; waveguide.h:80 tests keep_going before every iteration)
     {
         std::atomic_bool keep{true};
         const auto mesh = waveguide::make_box_mesh(8, 7, 6, 0.05f, waveguide::to_flat_coefficients(0.1));
@@ -253,7 +297,9 @@ int main() {
                                                   ++calls;
                                                   if (step == 100) keep = false;
                                               });
-        REQUIRE(!out && calls >= 101 && calls < 500);
+        REQUIRE(!out && calls == 101);
+        REQUIRE(g_last_engine == nullptr);  // (the engine is gone with the run; what it was at the end:)
+        REQUIRE(waveguide::last_run_stats().steps == 101);
     }
     // ---- a flag on step 77: the callbacks of steps 0 .. 76 fire, then the reference's exception (waveguide.h:102-118); a callback that
     // looks at a step of the very batch that met the flag still gets its field (none of that batch's fields is on the device)
@@ -278,7 +324,69 @@ int main() {
         g_flag_at_step = ~0ull;
         REQUIRE(threw && right && calls == 77);
     }
-    // ---- a callback that cannot see the field, or promises not to look: whole batches, no checkpoints at all
+    // ---- waveguide::run<pre, post> with one of this header's sources (bin/boundary_test/boundary_test.cpp:137-147: a soft source and a
+    // lambda around callback_accumulator<postprocessor::node>s): the steps are taken in batches ahead of `post`, which fires once per
+    // step, in order, and reads what the per-step loop would have read -- the nodes it reads are learned in the first step and served
+    // from recorded rows; a node it has never read before (step 300) still gets its step's value
+    {
+        const auto mesh = waveguide::make_box_mesh(8, 7, 6, 0.05f, waveguide::to_flat_coefficients(0.1));
+        const std::atomic_bool go{true};
+        const size_t steps = 700;
+        std::vector<float> input(steps, 0.0f);
+        input[0] = 1000.0f;
+        auto prep = waveguide::preprocessor::make_soft_source(33, input.begin(), input.end());
+        std::vector<waveguide::postprocessor::node> holders{waveguide::postprocessor::node{5}, waveguide::postprocessor::node{101},
+                                                             waveguide::postprocessor::node{230}};
+        std::vector<std::vector<float>> outputs(holders.size());
+        size_t counter = 0;
+        bool right = true;
+        wv_engine snapshot;
+        const size_t done = waveguide::run(context{}, mesh, prep,
+                                           [&](auto& queue, const auto& buffer, auto step) {
+                                               right = right && step == counter++;
+                                               for (size_t k = 0; k < holders.size(); ++k) outputs[k].push_back(holders[k](queue, buffer, step));
+                                               if (step >= 300 && step % 100 == 0)
+                                                   right = right && core::read_value<float>(queue, buffer, 77) == field_value(step, 77);
+                                               if (g_last_engine) snapshot = *g_last_engine;
+                                           },
+                                           go);
+        const auto stats = waveguide::last_run_stats();
+        REQUIRE(done == steps && right && counter == steps && prep.begin() == prep.end());
+        for (size_t k = 0; k < holders.size(); ++k) {
+            REQUIRE(outputs[k].size() == steps);
+            for (size_t t = 0; t < steps; ++t) REQUIRE(outputs[k][t] == field_value(t, holders[k].get_output_node()));
+        }
+        // step 0 teaches the three nodes, step 300 the fourth (a rollback: the run was ahead); everything else comes from the rows
+        REQUIRE(stats.batches < 40 && stats.rollbacks == 1 && snapshot.receiver_sets == 3 && snapshot.value_reads == 4);
+        REQUIRE(stats.reads_missed == 4 && stats.reads_served == 3 * (steps - 1) + 3);  // (node 77: missed at step 300, served at 400, 500, 600)
+        std::printf("run<soft_source, post>: %zu steps in %zu batches, %zu reads served from recorded rows, %zu from the engine, %zu rollback(s)\n", done,
+                    stats.batches, stats.reads_served, stats.reads_missed, stats.rollbacks);
+        // cancelled from `post`: no later callback, the source object one sample further than the steps done (waveguide.h:80)
+        std::atomic_bool keep{true};
+        auto prep2 = waveguide::preprocessor::make_hard_source(33, input.begin(), input.end());
+        size_t calls = 0;
+        const size_t done2 = waveguide::run(context{}, mesh, prep2,
+                                            [&](auto& queue, const auto& buffer, auto step) {
+                                                ++calls;
+                                                (void)core::read_value<float>(queue, buffer, 5);
+                                                if (step == 150) keep = false;
+                                            },
+                                            keep);
+        REQUIRE(done2 == 151 && calls == 151 && (size_t)std::distance(input.begin(), prep2.begin()) == 152);
+        // a lambda around the source (src/waveguide/tests/waveguide_tests.cpp:95-100) cannot be recognised: the reference's loop, step by step
+        // (the stand-in engine has no wv_step: reaching it is the proof)
+        auto prep3 = waveguide::preprocessor::make_soft_source(33, input.begin(), input.end());
+        bool stepped = false;
+        try {
+            (void)waveguide::run(context{}, mesh, [&](auto& queue, auto& buffer, auto step) { return prep3(queue, buffer, step); },
+                                 [](auto&, const auto&, auto) {}, go);
+        } catch (const waveguide::engine_error&) {
+            stepped = true;
+        }
+        REQUIRE(stepped);
+    }
+    // ---- a callback that cannot see the field, or promises not to look: whole batches (after a first one of 8 steps that finds out what
+    // a step costs), no checkpoints at all
     {
         const auto mesh = waveguide::make_box_mesh(8, 7, 6, 0.05f, waveguide::to_flat_coefficients(0.1));
         const core::environment env{};
@@ -287,11 +395,11 @@ int main() {
         size_t calls = 0;
         auto out = waveguide::canonical(context{}, mesh, kSource, kReceiver, env, waveguide::single_band_parameters{100.0, 0.6}, 999.5 / sr, go,
                                         [&](size_t step, size_t total) { calls += step < total; });
-        REQUIRE(bool(out) && calls == 1000 && waveguide::last_run_stats().batches == 4 && waveguide::last_run_stats().checkpoints == 0);
+        REQUIRE(bool(out) && calls == 1000 && waveguide::last_run_stats().batches == 5 && waveguide::last_run_stats().checkpoints == 0);
         calls = 0;
         out = waveguide::canonical(context{}, mesh, kSource, kReceiver, env, waveguide::single_band_parameters{100.0, 0.6}, 999.5 / sr, go,
                                    waveguide::progress_only([&](auto&, const auto&, auto, auto) { ++calls; }));
-        REQUIRE(bool(out) && calls == 1000 && waveguide::last_run_stats().batches == 4 && waveguide::last_run_stats().checkpoints == 0);
+        REQUIRE(bool(out) && calls == 1000 && waveguide::last_run_stats().batches == 5 && waveguide::last_run_stats().checkpoints == 0);
     }
     std::puts("CANONICAL PACING OK");
     return 0;

@@ -444,20 +444,30 @@ int main(int argc, char** argv) {
             for (size_t j = 0; j < seen.size(); ++j) REQUIRE(seen[j] == band.directional[j * 50 + 49].pressure);
         }
 
-        // ---- no listener: nothing is mirrored, whole batches, the run is the same -- with the application's predicate and
-        // with the default (an empty predicate: SURVEY.md 8(b), the buffer keeps its zeros) ------------------------------------
+        // ---- no listener: nothing is mirrored, whole batches, the run is the same -- with the application's predicate (the buffer
+        // keeps its zeros), with cl_mirror_never(), and with the default (an empty predicate: nobody has said whether anybody reads --
+        // the buffer holds NaN, not a silent field of zeros, and stderr says which line is missing) ---------------------------------
         waveguide_node_pressures_changed_.attached = false;
-        for (int with_predicate = 1; with_predicate >= 0; --with_predicate) {
-            if (!with_predicate) waveguide::cl_mirror_wanted() = nullptr;
+        for (int with_predicate = 2; with_predicate >= 0; --with_predicate) {
+            if (with_predicate == 1) waveguide::cl_mirror_wanted() = waveguide::cl_mirror_never();
+            if (with_predicate == 0) waveguide::cl_mirror_wanted() = nullptr;
             float seen_max = 0;
+            size_t seen = 0, nans = 0;
             const auto quiet = waveguide_->run(compute_context_, voxels_and_mesh_, source_, receiver_, environment_,
                                                max_stochastic_time, keep_going, [&](auto& queue, const auto& buffer, auto step, auto) {
                                                    if (step == 100)
-                                                       for (float v : core::read_from_buffer<float>(queue, buffer)) seen_max = std::max(seen_max, std::fabs(v));
+                                                       for (float v : core::read_from_buffer<float>(queue, buffer)) {
+                                                           ++seen;
+                                                           if (std::isnan(v))
+                                                               ++nans;
+                                                           else
+                                                               seen_max = std::max(seen_max, std::fabs(v));
+                                                       }
                                                });
             const auto stats = waveguide::last_run_stats();
             REQUIRE(bool(quiet) && same_records(*quiet));
-            REQUIRE(stats.fields_mirrored == 0 && stats.rollbacks == 0 && stats.batches <= 12 && seen_max == 0.0f);
+            REQUIRE(stats.fields_mirrored == 0 && stats.rollbacks == 0 && stats.batches <= 12 && seen_max == 0.0f && seen > 0);
+            REQUIRE(nans == (with_predicate == 0 ? seen : size_t{0}));
         }
         // cl_mirror_always + a range of planes: only those planes of the buffer follow the field
         {

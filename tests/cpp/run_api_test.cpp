@@ -54,6 +54,30 @@ static void run_waveguide() {
                                },
                                true);
     REQUIRE(completed == steps);
+    // (`prep` itself is one of the header's sources: the run went ahead of `post` in batches, what `post` reads came from recorded rows --
+    // all but the first step's three reads, which taught it the nodes)
+    {
+        const auto stats = last_run_stats();
+        REQUIRE(stats.steps == steps && stats.batches < steps / 4 && stats.rollbacks == 0);
+        REQUIRE(stats.reads_missed == 3 && stats.reads_served == 3 * (steps - 1) && prep.begin() == prep.end());
+    }
+    // the reference's test wraps the source in a lambda (waveguide_tests.cpp:95-100): nothing to recognise, the loop as the reference
+    // writes it, a host round trip per step -- and the same floats
+    {
+        auto prep_again = preprocessor::make_soft_source(source_index, input.begin(), input.end());
+        std::vector<callback_accumulator<postprocessor::node>> again;
+        for (float z : {2.0f, 3.0f, 4.0f}) again.emplace_back(compute_index(m.get_descriptor(), vec3{2.0f, 1.5f, z}));
+        size_t counter = 0;
+        const auto n = run(cc, m, [&](auto& queue, auto& buffer, auto step) { return prep_again(queue, buffer, step); },
+                           [&](auto& queue, const auto& buffer, auto step) {
+                               for (auto& i : again) i(queue, buffer, step);
+                               REQUIRE(step == counter++);
+                           },
+                           true);
+        REQUIRE(n == steps);
+        for (size_t r = 0; r < again.size(); ++r)
+            REQUIRE(std::memcmp(again[r].get_output().data(), output_holders[r].get_output().data(), steps * sizeof(float)) == 0);
+    }
     for (const auto& h : output_holders) {
         REQUIRE(h.get_output().size() == steps);
         float mx = 0;
@@ -303,8 +327,79 @@ static void scene_to_audio() {
     std::puts("scene to audio ok");
 }
 
-int main() {
+// bin/boundary_test/boundary_test.cpp:103-147 at its own size (300^3 nodes, 420 steps, a transparent soft source, node receivers):
+// what the call costs as the reference writes it, step by step (the source wrapped in a lambda), run ahead of `post` (the source as it
+// is), and as run_device (no callbacks): node-updates per second
+static void rate(int n, size_t steps) {
+    const compute_context cc{};
+    auto m = make_box_mesh(n, n, n, 0.05f, to_flat_coefficients(0.05));
+    const size_t nodes = compute_num_nodes(m.get_descriptor());
+    const float c = n * 0.05f * 0.5f;
+    const auto source_index = compute_index(m.get_descriptor(), vec3{c, c, c});
+    std::vector<float> input(steps, 0.0f);
+    input[0] = 1000.0f;
+    std::vector<size_t> receivers;
+    for (float d : {0.5f, 1.0f, 1.5f}) receivers.push_back(compute_index(m.get_descriptor(), vec3{c + d, c, c - d}));
+    auto outputs = [&] {
+        std::vector<callback_accumulator<postprocessor::node>> h;
+        for (size_t r : receivers) h.emplace_back(r);
+        return h;
+    };
+    double rates[3] = {0, 0, 0}, loop_rates[3] = {0, 0, 0};  // (whole call; the step loop alone, from last_run_stats)
+    std::vector<std::vector<float>> seen[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        auto prep = preprocessor::make_soft_source(source_index, input.begin(), input.end());
+        auto holders = outputs();
+        const auto post = [&](auto& queue, const auto& buffer, auto step) {
+            for (auto& i : holders) i(queue, buffer, step);
+        };
+        const double t0 = detail::seconds_now();
+        const size_t done = mode == 0 ? run(cc, m, [&](auto& queue, auto& buffer, auto step) { return prep(queue, buffer, step); }, post, true)
+                                      : run(cc, m, prep, post, true);
+        const double dt = detail::seconds_now() - t0;
+        REQUIRE(done == steps);
+        rates[mode] = (double)nodes * (double)steps / dt / 1e9;
+        for (auto& h : holders) seen[mode].push_back(h.get_output());
+        if (mode == 1) {
+            const auto st = last_run_stats();
+            loop_rates[1] = (double)nodes * (double)steps / st.seconds / 1e9;
+            std::printf("run ahead of post: %zu batches, %zu checkpoints, %zu rollbacks, reads served / missed %zu / %zu, step loop %.3f s of %.3f\n",
+                        st.batches, st.checkpoints, st.rollbacks, st.reads_served, st.reads_missed, st.seconds, dt);
+        }
+    }
+    for (size_t r = 0; r < receivers.size(); ++r)
+        REQUIRE(std::memcmp(seen[0][r].data(), seen[1][r].data(), steps * sizeof(float)) == 0);  // bytewise what the per-step loop recorded
+    {
+        std::vector<uint64_t> recv(receivers.begin(), receivers.end());
+        const double t0 = detail::seconds_now();
+        const size_t done = run_device(cc, m, source_kind::soft, source_index, input.begin(), input.end(), recv,
+                                       [](size_t, size_t, const std::vector<double>&) {}, true, 256);
+        const double dt = detail::seconds_now() - t0;
+        REQUIRE(done == steps);
+        rates[2] = (double)nodes * (double)steps / dt / 1e9;
+        loop_rates[2] = (double)nodes * (double)steps / last_run_stats().seconds / 1e9;
+    }
+    std::printf("{\"what\": \"waveguide::run<soft_source, post> as bin/boundary_test calls it\", \"mesh\": \"%d^3\", \"steps\": %zu, \"precision\": \"%s\", "
+                "\"gnode_per_s\": {\"step_by_step\": %.2f, \"run_ahead_of_post\": %.2f, \"run_device\": %.2f}, \"us_per_step\": {\"step_by_step\": %.1f, "
+                "\"run_ahead_of_post\": %.1f, \"run_device\": %.1f}, \"run_ahead_over_run_device\": %.3f, "
+                "\"step_loop_only_gnode_per_s\": {\"run_ahead_of_post\": %.2f, \"run_device\": %.2f}, \"step_loop_only_ratio\": %.3f, "
+                "\"note\": \"gnode_per_s / us_per_step: the whole call, engine set-up (mesh upload, maps) included in all three\"}\n",
+                n, steps, default_precision() == WV_PRECISION_F64 ? "f64" : "f32", rates[0], rates[1], rates[2], 1e6 * nodes / rates[0] / 1e9,
+                1e6 * nodes / rates[1] / 1e9, 1e6 * nodes / rates[2] / 1e9, rates[1] / rates[2], loop_rates[1], loop_rates[2],
+                loop_rates[1] / loop_rates[2]);
+}
+
+int main(int argc, char** argv) {
     try {
+        if (argc > 1 && std::strcmp(argv[1], "rate") == 0) {
+            const int n = argc > 2 ? std::atoi(argv[2]) : 300;
+            const size_t steps = argc > 3 ? (size_t)std::atoi(argv[3]) : 420;
+            for (int precision : {WV_PRECISION_F32, WV_PRECISION_F64}) {
+                default_precision() = precision;
+                rate(n, steps);
+            }
+            return 0;
+        }
         filters_are_stable();
         // the fp64 engine (default) and the reference's own float storage
         for (int precision : {WV_PRECISION_F64, WV_PRECISION_F32}) {

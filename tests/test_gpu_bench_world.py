@@ -66,6 +66,11 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
         r2 = run_bench(world, shm_mock, *(extra + ["--transport", "ipc"]))
         assert "IPC-mapped" in r2["config"]["halo"] and r2["roofline"]["launches"] > 0 and r2["value"] > 0
         assert r2["config"]["halo_parity"]["bitwise_equal"] is True and r2["config"]["halo_parity"]["transport"] == "ipc"
+    # the halo figures are every rank's, and the ones at the top are the worst rank's (not rank 0's, an end slab with one neighbour)
+    hm = r["config"]["halo_measured"]
+    assert len(hm["per_rank"]) == world and [h["rank"] for h in hm["per_rank"]] == list(range(world))
+    assert all(h["ms_per_step"] > 0 and h["neighbours"] == (1 if h["rank"] in (0, world - 1) else 2) for h in hm["per_rank"])
+    assert hm["rank"] == hm["worst_rank"] and hm["exposed_wait_us_per_wait"] == max((h["exposed_wait_us_per_wait"] or 0.0) for h in hm["per_rank"])
     # value is the whole job: all nodes of all ranks x steps / (max-over-ranks) time
     assert r["value"] == pytest.approx(nx * ny * nz_global * steps / (r["ms_per_step"] * 1e-3 * steps) / 1e9, rel=1e-2)
     roof = r["roofline"]

@@ -284,8 +284,10 @@ def test_config2_1024cubed_full_size(oracle, built_library):
                 assert np.any(got_rows != 0) or hi == lo
 
 
-def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library):
-    """BASELINE configs[2] for 64 steps in the engine's own stepping (two single sweeps after the caller's writes, then
+@pytest.mark.parametrize("form", ["three-step-passes", "two-step-passes"])
+def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library, form):
+    """BASELINE configs[2] for 64 steps in the engine's own stepping (two single sweeps after the caller's writes, then 20
+    three-step passes and a two-step one -- the engine's choice at this size -- or, with three-step passes switched off,
     31 two-step passes with the x-facing walls on their compact copies) against the oracle, bit for bit, without the
     oracle having to step 2^30 nodes: the start fields are noise inside two thin bands of planes -- against the bottom wall
     and in mid-mesh -- and zero elsewhere, so after S steps everything further than S planes from a band is still exactly
@@ -318,7 +320,9 @@ def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library):
         return prev, cur
 
     mesh = box_slab_mesh(n, n, n, _Window(dims, 0, n), coefficients=coeffs)
+    set_tuning(**({"triple": 0} if form == "two-step-passes" else {}))
     eng = E.Engine(mesh, precision="f64")
+    set_tuning()
     mesh.nodes = None
     try:
         for lo, hi in bands:
@@ -326,7 +330,11 @@ def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library):
             eng.write_planes(lo, p, E.BUF_PREVIOUS)
             eng.write_planes(lo, c, E.BUF_CURRENT)
         done, trace = E.run_fast(eng, E.SOURCE_SOFT, src, signal, recv)
-        assert done == S and eng.query(E.Engine.QUERY_PASSES) == (S - 2) // 2 and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
+        assert done == S
+        if form == "two-step-passes":
+            assert eng.query(E.Engine.QUERY_PASSES) == (S - 2) // 2 and eng.query(E.Engine.QUERY_XWALL_ENTRIES) > 0
+        else:
+            assert eng.query(E.Engine.QUERY_TRIPLE_PASSES) == (S - 2) // 3 and eng.query(E.Engine.QUERY_PASSES) == 1
         for z in (200, 800, 516 + S + 1):
             for buf in (E.BUF_CURRENT, E.BUF_PREVIOUS):
                 assert not eng.read_planes(z, 1, buf).any(), "plane %d should still be zero" % z
@@ -372,7 +380,7 @@ def test_config2_1024cubed_64_steps_against_the_oracle(oracle, built_library):
 def test_config2_1024cubed_long_run_two_step_passes_equal_single_steps(built_library):
     """BASELINE configs[2] beyond the few steps an oracle window can follow: 1024^3 fp64 with the bench's four wall
     materials, an impulse at the centre, 1 200 steps (the wave front has crossed the room and come back) -- the
-    engine's own stepping (two-step passes, three launches each, a batch boundary in between) against single steps:
+    engine's own stepping (three-step passes, a batch boundary in between) and two-step passes against single steps:
     16 sampled planes of both fields, every filter memory word of all six walls and 1 200 samples of four
     receivers, bit for bit."""
     from wayverb_amd import engine as E
@@ -384,23 +392,27 @@ def test_config2_1024cubed_long_run_two_step_passes_equal_single_steps(built_lib
     recv = [ci(n // 2 + 3, n // 2, n // 2), ci(2, 2, 2), ci(n - 3, 400, 700), ci(1, 512, 512)]
     planes = [1, 2, 3, 255, 256, 510, 511, 512, 513, 700, 767, 768, 1020, 1021, 1022, 64]
     runs = {}
-    for pair in (0, -1):
-        set_tuning(**({"pair": 0} if pair == 0 else {}))
+    for pair in (0, -1, 2):
+        set_tuning(**({"pair": 0} if pair == 0 else ({"triple": 0} if pair == 2 else {})))
         mesh = box_slab_mesh(n, n, n, _Window((n, n, n), 0, n), coefficients=M.bench_materials())
         eng = E.Engine(mesh, precision="f64")
+        set_tuning()
         mesh.nodes = None
         try:
             done, out = E.run_fast(eng, E.SOURCE_HARD, ci(n // 2, n // 2, n // 2), sig, recv)
             assert done == steps
+            triples, pairs = eng.query(E.Engine.QUERY_TRIPLE_PASSES), eng.query(E.Engine.QUERY_PASSES)
+            assert (triples > 390 and pairs <= 2) if pair == -1 else (triples == 0 and pairs == (600 if pair == 2 else 0))
             runs[pair] = dict(trace=out, bd=[eng.read_boundary_data(d)["filter_memory"].copy() for d in (1, 2, 3)],
                               planes={(z, b): eng.read_planes(z, 1, b).copy() for z in planes for b in (E.BUF_CURRENT, E.BUF_PREVIOUS)})
         finally:
             eng.close()
-    a, b = runs[0], runs[-1]
+    a = runs[0]
     assert np.isfinite(a["trace"]).all() and np.abs(a["trace"][-200:, 0]).max() > 0
-    assert a["trace"].tobytes() == b["trace"].tobytes(), "receiver traces differ"
-    for d in range(3):
-        assert a["bd"][d].tobytes() == b["bd"][d].tobytes(), "filter memories differ (D=%d)" % (d + 1)
-    for key in a["planes"]:
-        assert a["planes"][key].tobytes() == b["planes"][key].tobytes(), "plane %d of buffer %d differs" % key
-        assert np.any(a["planes"][key] != 0)
+    for b in (runs[-1], runs[2]):
+        assert a["trace"].tobytes() == b["trace"].tobytes(), "receiver traces differ"
+        for d in range(3):
+            assert a["bd"][d].tobytes() == b["bd"][d].tobytes(), "filter memories differ (D=%d)" % (d + 1)
+        for key in a["planes"]:
+            assert a["planes"][key].tobytes() == b["planes"][key].tobytes(), "plane %d of buffer %d differs" % key
+            assert np.any(a["planes"][key] != 0)

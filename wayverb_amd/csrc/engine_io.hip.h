@@ -323,6 +323,10 @@ int Engine<Real>::checkpoint(int op) {
         ckpt_ = Checkpoint{};
         return WV_OK;
     }
+    // A slab of a chain is not alone with its state: its neighbours' ghost planes, the transport's step counters and mailbox words
+    // would have to go back with it, all ranks at once.  Nobody needs that (`canonical` runs one domain): refused, not half done.
+    if (comm_ && (opt_.ghost_lo || opt_.ghost_hi || comm_->nranks() > 1))
+        return fail(WV_E_STATE, "wv_checkpoint / wv_rollback: not on a slab of a chain (its neighbours would not go back with it)");
     if (op == 0) {
         ckpt_.valid = false;
         for (auto& f : ckpt_.field)
