@@ -90,7 +90,7 @@ def kernel_sources_hash():
     kernels they were measured on."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "wayverb_amd", "csrc")
-    for name in ("device_common.hip.h", "stream_kernels.hip.h", "pair_kernels.hip.h", "boundary_kernels.hip.h"):
+    for name in ("device_common.hip.h", "stream_kernels.hip.h", "pair_kernels.hip.h", "triple_kernels.hip.h", "boundary_kernels.hip.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -39,12 +39,16 @@ def write_traffic_record(where, out, workload=DEFAULT_WORKLOAD):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     total = lambda v: int(2 * v["FETCH_SIZE"]["mean_KiB"] * 1024 + v["WRITE_SIZE"]["mean_KiB"] * 1024)  # noqa: E731
-    march = [(k, v) for k, v in out.items() if k.startswith("pair_march_kernel<double") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    # the dominant kernel: the three-step march where the run took three-step passes (more launches of it than of the two-step march)
+    march = []
+    for name in ("triple_march_kernel", "pair_march_kernel"):
+        march += [(name, k, v) for k, v in out.items() if k.startswith(name + "<") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
     if not march:
         return
-    k, v = march[0]
+    march.sort(key=lambda m: -m[2]["FETCH_SIZE"]["n"])
+    kernel, k, v = march[0]
     tag = os.path.basename(os.path.normpath(where))
-    rec = {"workload": workload, "kernel": "pair_march_kernel", "kernel_full_name": "wv::" + k, "kernel_sources": bench.kernel_sources_hash(),
+    rec = {"workload": workload, "kernel": kernel, "kernel_full_name": "wv::" + k, "kernel_sources": bench.kernel_sources_hash(),
            "measured": tag, "files": "%s/pmc_summary.json" % tag,
            "source": "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel trace only, "
                      "launches of `bench.py --steps 30 --warmup 6`)" % tag,
@@ -53,13 +57,17 @@ def write_traffic_record(where, out, workload=DEFAULT_WORKLOAD):
                           "in tools/stream_bench.hip: 2*FETCH_SIZE*1024 = bytes read, exactly); WRITE_SIZE*1024 = bytes written, exactly; "
                           "Infinity-Cache hits are counted (fabric-side counter)",
            "hbm_bytes_per_launch": total(v)}
-    # the two boundary launches of a pass: boundary_kernel<double, ..., false> steps the boundary nodes to t+1, <..., true> to t+2
+    # the boundary launches of a pass: boundary_kernel<.., false> steps the boundary nodes to t+1 (and, in a three-step pass, to t+3: the
+    # mean is over both), <.., true> to t+2 and finishes the nodes its 1-D entries face
     level = {}
     for name, c in out.items():
-        if name.startswith("boundary_kernel<double") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if name.startswith("boundary_kernel<") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             level[1 if name.rstrip(">").rstrip().endswith("true") else 0] = total(c)
     if len(level) == 2:
         rec["boundary_hbm_bytes_per_launch"] = [level[0], level[1]]
+    fix = [total(c) for name, c in out.items() if name.startswith("pair_fixup_kernel<") and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+    if fix:
+        rec["fixup_list_hbm_bytes_per_launch"] = fix[0]  # (a three-step pass: the mean over the second level's short list and the third's long one)
     # the record bench.py reads (profiles/traffic.json) is the default workload's; another size leaves its record beside its summary only
     paths = [os.path.join(where, "traffic.json")]
     if workload == DEFAULT_WORKLOAD:
@@ -83,7 +91,7 @@ def main():
     json.dump(out, open(os.path.join(where, "pmc_summary.json"), "w"), indent=1)
     write_traffic_record(where, out, workload_of(where))
     for k, v in sorted(out.items()):
-        if "boundary_kernel" in k or "pair_march" in k or "stream_sweep" in k:
+        if "boundary_kernel" in k or "pair_march" in k or "stream_sweep" in k or "triple_" in k or "pair_fixup" in k:
             f, w = v.get("FETCH_SIZE", {}).get("mean_KiB", 0), v.get("WRITE_SIZE", {}).get("mean_KiB", 0)
             print("%-50s fetched 2 x %.0f KiB = %.3f GB, written %.3f GB, total %.3f GB (%d launches)"
                   % (k, f, 2 * f * 1024 / 1e9, w * 1024 / 1e9, (2 * f + w) * 1024 / 1e9, v.get("FETCH_SIZE", {}).get("n", 0)))

@@ -141,9 +141,23 @@ struct Bench {
         hipLaunchKernelGGL((wv::triple_march_kernel<Real, X, DMA, LB>), dim3(grid), dim3(64u * (unsigned)a.nw), wv::triple_lds_bytes(a.nw, DMA, LB), 0, a);
         CK(hipGetLastError());
     }
+    template <int X>
+    void launch_dense(const wv::TripleArgs<Real>& a) {
+        static bool set = false;
+        if (!set) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, X, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)a.chunks * (unsigned)(a.windows ? a.windows : 1);
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, X, false, 8, true>), dim3(grid), dim3(64u * (unsigned)a.nw), wv::triple_lds_bytes(a.nw, false, 8), 0, a);
+        CK(hipGetLastError());
+    }
+    bool dense = false;
     template <int X, bool DMA = false>
     void launch(const wv::TripleArgs<Real>& a) {
-        if (lb == 16) {
+        if (dense) {
+            if constexpr (!DMA) launch_dense<X>(a);
+        } else if (lb == 16) {
             if constexpr (!DMA) launch_lb<X, false, 16>(a);
         } else {
             launch_lb<X, DMA, 8>(a);
@@ -270,10 +284,11 @@ struct Bench {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < (sizeof(Real) == 4 ? 6 : 4); ++pass) {
             const int chunks = 1 << (pass % 2);
             full_first = false;
-            lb = pass >= 2 ? 16 : 8;
+            lb = (pass >= 2 && pass < 4) ? 16 : 8;
+            dense = pass >= 4;
             if (n / chunks < 16) continue;
             for (int variant = 0; variant < 6; ++variant) {
                 if (variant == 3 || variant == 4) continue;
@@ -299,8 +314,8 @@ struct Bench {
                 float ms = 0;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= iters;
-                printf("%s %d-byte lanes %d^3, %d chunk(s), %d window(s) of <= %d waves, %s: %.3f ms per pass of THREE steps = %.3f ms per step = %.1f Gnode-updates/s (%d B per node: %.0f GB/s)\n",
-                       sizeof(Real) == 8 ? "f64" : "f32", lb, n, a.chunks, a.windows ? a.windows : 1, a.nw,
+                printf("%s %d-byte lanes%s %d^3, %d chunk(s), %d window(s) of <= %d waves, %s: %.3f ms per pass of THREE steps = %.3f ms per step = %.1f Gnode-updates/s (%d B per node: %.0f GB/s)\n",
+                       sizeof(Real) == 8 ? "f64" : "f32", lb, dense ? " (four waves per SIMD)" : "", n, a.chunks, a.windows ? a.windows : 1, a.nw,
                        variant == 5 ? "three-step pass, box map, every plane wrapped onto two (cache-resident traffic)" : variant == 4 ? "three-step pass, box map, stores without the nt hint" : variant == 3 ? "three-step pass, box map, `previous` by LDS-DMA" : variant == 2 ? "instructions only (no loads, no stores)" : (variant == 1 ? "three-step pass, box map" : "three-step pass, interior only"), ms, ms / 3,
                        3.0 * N / ms / 1e6, (int)(4 * sizeof(Real)), 4.0 * sizeof(Real) * N / ms / 1e6);
             }
@@ -356,6 +371,11 @@ int main(int argc, char** argv) {
         ok = s.check(500, 21, 27, 2, true) && ok;
         ok = s.check(2048, 64, 40, 1, true) && ok;
         s.lb = 8;
+        s.dense = true;
+        ok = s.check(500, 21, 27, 2, true) && ok;
+        ok = s.check(1024, 64, 40, 1, true) && ok;
+        ok = s.check(2048, 24, 19, 1, true) && ok;
+        s.dense = false;
         ok = s.check(256, 22, 19, 1, false) && ok;
         ok = s.check(500, 21, 27, 2, true) && ok;
     }

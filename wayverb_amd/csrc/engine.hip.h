@@ -272,7 +272,10 @@ private:
     int* suspect_ = nullptr;           // [kRing] per step slot: the march saw an inf / nan
     uint64_t triple_source_ = 0, triple_io_generation_ = ~0ull;
     bool triple_failed_ = false, triple_ready_ = false, triple_attr_set_ = false;
-    uint64_t triple_min_nodes_ = 96ull << 20;  // stored nodes: below, the chunks' warm-up planes and the launches cost more than the bytes save
+    // stored nodes from which the engine takes three-step passes by itself (tools/pass_forms_by_size.py, profiles/r06/pass_forms_by_size_*.txt:
+    // Gnode-updates/s two-step / three-step, fp64: 256^3 212 / 216, 320^3 206 / 223, 384^3 258 / 288, 512^3 304 / 340, 768^3 326 / 396,
+    // 1024^3 355 / 421; fp32 (8-byte lanes: twice the instructions per byte): 384^3 364 / 375, 512^3 522 / 549, 768^3 577 / 532, 1024^3 660 / 693)
+    uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (24ull << 20) : (900ull << 20);
     int triple_nw_ = 1, triple_strips_ = 0, triple_zc_ = 0, triple_chunks_ = 1, triple_windows_ = 0;
     uint8_t triple_win_[4][wv::kTripleMaxWindows] = {};
     uint64_t triples_taken_ = 0;

@@ -210,7 +210,9 @@ __device__ __forceinline__ void lds_barrier_keep_vm() {
 // does not order LDS reads behind it; the waits are placed by hand (triple_dma_wait: vector-memory instructions are issued and retired
 // in order, and the row steps are fenced scheduling regions, so how many are issued between a DMA and the row step that reads its
 // rows is a compile-time number).
-template <typename Real, int X, bool EDGE, bool PVDMA, int LB>
+// DENSE: the kernel is built for four waves per SIMD (128 registers: 8-byte lanes of floats get there with a row less of lookahead) --
+// two workgroups of eight waves share a CU and its 160 KB of LDS, and sixteen waves hide what eight cannot.
+template <typename Real, int X, bool EDGE, bool PVDMA, int LB, bool DENSE>
 __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     static_assert(!PVDMA || LB == 8, "the DMA form is written for 8-byte lanes");
     using V = VecL<Real, LB>;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     // the trips' boundaries too: the first four rows of the NEXT trip are asked for in the last four row steps of this one, into the
     // registers of "mid" rows that have retired (all of a trip's loads at its top would be registers waiting for their turn, and a trip
     // that opens with its first loads opens with a memory latency, every wave of the workgroup at the same time).
-    constexpr int LA = EDGE ? 3 : 4;  // rows of lookahead (the edge strips' offsets live in vector registers: they have fewer to spare)
+    constexpr int LA = (EDGE ? 3 : 4) - (DENSE ? 1 : 0);  // rows of lookahead (the edge strips' offsets live in vector registers: they have fewer to spare)
     auto trip = [&](int f, int set, V(&b_mid)[R0], V(&b_new)[R0], V(&u_mid)[R1], V(&u_new)[R1], V(&w_mid)[R2], V(&w_new)[R2], V(&pv)[R1],
                     V(&pv_next)[R1]) {
         const int z = f - 3;
@@ -496,17 +498,17 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     if (__any(top_exp >= (sizeof(Real) == 8 ? 0x7FF00000u : 0x7F800000u)) && lane == 0) atomicOr(a.suspect, 1);
 }
 
-template <typename Real, int X = 0, bool PVDMA = false, int LB = kTripleLaneBytes>
-__global__ void __launch_bounds__(64 * triple_max_waves(LB)) triple_march_kernel(const TripleArgs<Real> a) {
+template <typename Real, int X = 0, bool PVDMA = false, int LB = kTripleLaneBytes, bool DENSE = false>
+__global__ void __launch_bounds__(DENSE ? 1024 : 64 * triple_max_waves(LB)) triple_march_kernel(const TripleArgs<Real> a) {
     // (which strip: as in the body)
     int j = (int)(blockIdx.x >> 3);
     if (a.windows) j %= (int)(gridDim.x >> 3) / a.windows;
     const int strip = (int)(blockIdx.x & 7) * a.strips_per_xcd + j % a.strips_per_xcd;
     const int y0 = strip * kTripleRows;
     if (y0 < 4 || y0 + kTripleRows + 2 >= a.ny)
-        triple_march_body<Real, X, true, PVDMA, LB>(a);
+        triple_march_body<Real, X, true, PVDMA, LB, DENSE>(a);
     else
-        triple_march_body<Real, X, false, PVDMA, LB>(a);
+        triple_march_body<Real, X, false, PVDMA, LB, DENSE>(a);
 }
 
 // ---- the triple map and the third level's fix-up list, once per (mesh, source node, receiver set) ------------------------------
