@@ -125,7 +125,8 @@ typedef struct wv_tuning {
                                * decides by mesh size, 1 / 0 force on / off.  One domain only (z-slabs keep two-step passes), rooms that fill
                                * their mesh; a batch takes them wherever it has three steps left, then a two-step pass or a single step */
     int32_t triple_chunks;    /* workgroups along z of the three-step march; 0 = fill whole rounds of workgroup slots */
-    int32_t reserved_[1];
+    int32_t triple_lanes;     /* bytes of a row per lane of the three-step march: 0 the engine decides (doubles: 16 on long rows, 8 on short ones;
+                               * floats: 8), 8 / 16 force (doubles only) */
 } wv_tuning;
 
 typedef struct wv_options {

@@ -66,6 +66,23 @@ def test_triple_path_ragged_meshes_match_oracle(oracle, dims, tag):
             assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("lanes", [8, 16])
+@pytest.mark.parametrize("dims", [(256, 40, 33), (300, 23, 41), (1024, 24, 19), (1100, 13, 12), (2100, 9, 8)], ids=lambda d: "x".join(map(str, d)))
+def test_triple_path_both_lane_widths_of_the_double_march(oracle, dims, lanes):
+    """Doubles march on 16-byte lanes (two per lane, eight waves per workgroup) or on 8-byte lanes (one per lane, up to twelve waves: what
+    short rows get by default): each forced on rows of every length -- one workgroup, two windows, several."""
+    set_tuning(**ON, triple_lanes=lanes)
+    case = _random_case(dims, seed=sum(dims) + lanes, steps=14)
+    want = run_oracle(oracle, case, np.float64, threads=4)
+    got = run_engine(case, "f64")
+    assert want["flag"] == 0 and got["steps"] == want["steps"] and got["triple_passes"] == 4
+    assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+    assert got["current"].tobytes() == want["current"].tobytes()
+    assert got["previous"].tobytes() == want["previous"].tobytes()
+    for a, b in zip(got["bd"], want["bd"]):
+        assert a.tobytes() == b.tobytes()
+
+
 @pytest.mark.parametrize("room", ["L", "sphere", "blob"])
 @pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
 def test_triple_path_non_box_rooms(oracle, room, tag, dtype):

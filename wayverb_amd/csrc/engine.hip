@@ -66,6 +66,7 @@ void wv_default_options(wv_options* o) {
     t.whole_step = -1;
     t.triple = -1;
     t.triple_chunks = 0;
+    t.triple_lanes = 0;
 }
 
 #ifdef WV_DEBUG_ENV
@@ -82,7 +83,7 @@ static void tuning_from_environment(wv_options* o) {
                           {"WV_PAIR_UNIT_PLANES", &t.pair_unit_planes}, {"WV_PAIR_UNITS_BY_CHUNK", &t.pair_units_by_chunk}, {"WV_TILE_LISTS", &t.tile_lists},
                           {"WV_FUSE_PRE_POST", &t.fuse_pre_post}, {"WV_GRAPH", &t.graph}, {"WV_BOUNDARY_LDS", &t.boundary_lds},
                           {"WV_BOUNDARY_ORDER", &t.boundary_order}, {"WV_BOUNDARY_XWALL", &t.boundary_xwall},
-                          {"WV_SLAB_EARLY", &t.slab_early}, {"WV_PAIR_SPLIT_ROWS", &t.pair_split_rows}, {"WV_FUSE_PLANES", &t.fuse_planes}, {"WV_WHOLE_STEP", &t.whole_step}, {"WV_TRIPLE", &t.triple}, {"WV_TRIPLE_CHUNKS", &t.triple_chunks},
+                          {"WV_SLAB_EARLY", &t.slab_early}, {"WV_PAIR_SPLIT_ROWS", &t.pair_split_rows}, {"WV_FUSE_PLANES", &t.fuse_planes}, {"WV_WHOLE_STEP", &t.whole_step}, {"WV_TRIPLE", &t.triple}, {"WV_TRIPLE_CHUNKS", &t.triple_chunks}, {"WV_TRIPLE_LANES", &t.triple_lanes},
                           {"WV_STREAM_VARIANT", &o->stream_variant},
                           {"WV_STREAM_RY", &t.stream_ry}, {"WV_STREAM_NWX", &t.stream_nwx}, {"WV_STREAM_NWY", &t.stream_nwy},
                           {"WV_STREAM_ZCHUNKS", &t.stream_zchunks}};

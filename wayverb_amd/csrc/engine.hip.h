@@ -93,10 +93,11 @@ public:
         return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
     }
     // ---- engine_triple.hip.h
-    static constexpr int kLaneBytes = sizeof(Real) == 8 ? 16 : 8;  // bytes of a row per lane of the three-step march (triple_kernels.hip.h)
+    static constexpr int kWideLaneBytes = sizeof(Real) == 8 ? 16 : 8;  // the wider form of the three-step march's lanes this precision has (triple_kernels.hip.h)
+    int triple_lane_bytes() const;
     bool triple_eligible();
     int ensure_triple();
-    int enqueue_triple(int slot, uint64_t signal_pos, bool source_live);
+    int enqueue_triple(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
     // ---- engine_batch.hip.h
     bool time_this_launch();
     int drain_timing();
@@ -274,10 +275,14 @@ private:
     bool triple_failed_ = false, triple_ready_ = false, triple_attr_set_ = false;
     // stored nodes from which the engine takes three-step passes by itself (tools/pass_forms_by_size.py, profiles/r06/pass_forms_by_size_*.txt:
     // Gnode-updates/s two-step / three-step, fp64: 256^3 212 / 216, 320^3 206 / 223, 384^3 258 / 288, 512^3 304 / 340, 768^3 326 / 396,
-    // 1024^3 355 / 421; fp32 (8-byte lanes: twice the instructions per byte): 384^3 364 / 375, 512^3 522 / 549, 768^3 577 / 532, 1024^3 660 / 693)
-    uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (24ull << 20) : (900ull << 20);
+    // 1024^3 355 / 421 -- 256^3 with 8-byte lanes and the pass's launches fused: 211 / 234; fp32 (8-byte lanes: twice the instructions per byte): 384^3 364 / 375, 512^3 522 / 549, 768^3 577 / 532, 1024^3 660 / 693)
+    uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (12ull << 20) : (900ull << 20);
     int triple_nw_ = 1, triple_strips_ = 0, triple_zc_ = 0, triple_chunks_ = 1, triple_windows_ = 0;
     uint8_t triple_win_[4][wv::kTripleMaxWindows] = {};
+    int triple_lb_ = 8;                // bytes of a row per lane of the march as set up (triple_lane_bytes)
+    // stored row length (elements) from which doubles march on 16-byte lanes (profiles/r06/lane_width_by_size.txt: Gnode-updates/s with
+    // 8- / 16-byte lanes 256^3 234 / 226, 320^3 220 / 234, 384^3 281 / 309, 512^3 346 / 340, 768^3 360 / 378, 1024^3 343 / 403)
+    int triple_wide_from_ = 320;
     uint64_t triples_taken_ = 0;
     int* status_ = nullptr;
     int* static_flag_dev_ = nullptr;

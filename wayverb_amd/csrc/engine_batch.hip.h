@@ -300,7 +300,7 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
             for (uint64_t i = 0; i < batch;) {
                 if (triple_at(i)) {
-                    if ((rc = enqueue_triple((int)i, signal_pos_ + i, batch_source_live_))) return rc;
+                    if ((rc = enqueue_triple((int)i, signal_pos_ + i, batch_source_live_, kind_at(i + 3)))) return rc;
                     i += 3;
                 } else if (pair_at(i)) {
                     if ((rc = enqueue_batch_pair(i, 0, 0))) return rc;

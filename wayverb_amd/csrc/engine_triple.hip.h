@@ -31,12 +31,23 @@ bool Engine<Real>::triple_eligible() {
     if (opt_.tuning.triple == 0 || triple_failed_) return false;
     if (comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
     if (!pair_eligible()) return false;
-    constexpr int WX = 64 * (kLaneBytes / (int)sizeof(Real));
+    const int lb = triple_lane_bytes();
+    const int WX = 64 * (lb / (int)sizeof(Real));
     uint8_t win[4][wv::kTripleMaxWindows];
     int widest = 0;
-    if (wv::triple_windows(pitch_ / WX, win, &widest, false, wv::triple_max_waves(kLaneBytes)) < 0) return false;
+    if (wv::triple_windows(pitch_ / WX, win, &widest, false, wv::triple_max_waves(lb)) < 0) return false;
     if (opt_.tuning.triple < 0 && stored_nodes_ < triple_min_nodes_) return false;
     return true;
+}
+
+// Bytes of a row per lane of the march.  Doubles: 16 (half the instructions per byte, two waves per SIMD) where the rows are long enough
+// to give a CU its eight waves in one or two workgroups; 8 on short rows, where three workgroups of four waves hide more than three of
+// two.  Floats: 8 (the 16-byte form does not fit the register file without spills).  wv_tuning::triple_lanes forces one.
+template <typename Real>
+int Engine<Real>::triple_lane_bytes() const {
+    if (sizeof(Real) == 4) return 8;
+    if (opt_.tuning.triple_lanes == 8 || opt_.tuning.triple_lanes == 16) return opt_.tuning.triple_lanes;
+    return pitch_ >= triple_wide_from_ ? 16 : 8;
 }
 
 template <typename Real>
@@ -132,18 +143,19 @@ int Engine<Real>::ensure_triple() {
     triple_io_generation_ = io_generation_;
     // march geometry: strips of four rows; windows where a row is longer than a workgroup; chunks along z so that the workgroups fill
     // whole rounds of the chip's workgroup slots, weighed against the four warm-up planes every chunk marches before its first output
-    constexpr int WX = 64 * (kLaneBytes / (int)sizeof(Real));
+    const int lb = triple_lb_ = triple_lane_bytes();
+    const int WX = 64 * (lb / (int)sizeof(Real));
     int widest = 0;
-    triple_windows_ = wv::triple_windows(pitch_ / WX, triple_win_, &widest, false, wv::triple_max_waves(kLaneBytes));
+    triple_windows_ = wv::triple_windows(pitch_ / WX, triple_win_, &widest, false, wv::triple_max_waves(lb));
     if (triple_windows_ < 0) {
         triple_ready_ = false;
         return WV_OK;
     }
     triple_nw_ = widest;
     triple_strips_ = (ny_ + wv::kTripleRows - 1) / wv::kTripleRows;
-    const size_t lds = wv::triple_lds_bytes(triple_nw_, false, kLaneBytes);
+    const size_t lds = wv::triple_lds_bytes(triple_nw_, false, lb);
     const int by_lds = std::max<int>(1, (int)((160u * 1024u) / lds));
-    const int by_waves = std::max(1, (kLaneBytes == 16 ? 8 : 12) / triple_nw_);
+    const int by_waves = std::max(1, (lb == 16 ? 8 : 12) / triple_nw_);
     const int64_t slots = 256ll * std::min(by_lds, by_waves);
     const int owned = z_end_ - z_begin_;
     int chunks = opt_.tuning.triple_chunks;
@@ -165,8 +177,11 @@ int Engine<Real>::ensure_triple() {
     triple_zc_ = (owned + chunks - 1) / chunks;
     triple_chunks_ = (owned + triple_zc_ - 1) / triple_zc_;
     if (!triple_attr_set_) {
-        WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, kLaneBytes>),
+        WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (sizeof(Real) == 8)
+            WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         triple_attr_set_ = true;
     }
     triple_ready_ = true;
@@ -174,8 +189,13 @@ int Engine<Real>::ensure_triple() {
 }
 
 // Steps `slot` .. `slot + 2` of a batch in one pass.  The flag words of the batch hold the mesh-static bits already (run()).
+// `fuse_next` (0: nothing follows in this batch, 1: a single step or another three-step pass, 2: a two-step pass): the next step's source /
+// receiver work rides in the last boundary launch -- like the source / receiver work of steps t+1 and t+2 in the first two, and the
+// second level's short list with t+1's -- wherever the launch in question writes none of the nodes concerned (the same conditions as in
+// a two-step pass: engine_pair.hip.h).  Five launches per pass then: march, boundary nodes to t+1, to t+2, third-level list + exact
+// flags, boundary nodes to t+3.
 template <typename Real>
-int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live) {
+int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live, int fuse_next) {
     DeviceGuard guard(device_);
     Real* A = field_[prv_];
     Real* B = field_[cur_];
@@ -187,6 +207,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     int* flag3 = flags_ + slot + 2;
     int rc;
     const bool io = n_recv_ || source_live;
+    const bool fuse = batch_can_fuse_ && n_entries_ != 0;
     if (!pre_post_done_ && io) {  // step t: source sample into t, receivers from t
         wv::PrePostArgs<Real> pp = pre_post_args(B, slot, true, signal_pos, source_live);
         pp.flag = nullptr;
@@ -223,53 +244,65 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     // (kernel timing: the march in an account of its own -- WV_QUERY_TRIPLE_MARCH_NS -- and, every eighth timed pass, its parts)
     const bool timed = timing && time_this_launch();
     int token = timed ? begin_part_timing(4, true) : -1;
-    hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
-                       wv::triple_lds_bytes(triple_nw_, false, kLaneBytes), stream_, a);
+    if (triple_lb_ == 8)
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, 8>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
+                           wv::triple_lds_bytes(triple_nw_, false, 8), stream_, a);
+    else
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
+                           wv::triple_lds_bytes(triple_nw_, false, kWideLaneBytes), stream_, a);
     if ((rc = end_part_timing(4, token))) return rc;
     pass_timed_ = timed && (part_timing_calls_++ & 7u) == 0;
-    {
-        wv::TripleFlagsArgs<Real> f{};
-        f.prev = A;
-        f.cur = B;
-        f.out2 = O2;
-        f.out3 = O3;
-        f.pair_map = pair_map_;
-        f.suspect = suspect_ + slot;
-        f.flag1 = flag1;
-        f.flag2 = flag2;
-        f.flag3 = flag3;
-        f.source_node = source_live ? source_node_ : ~0ull;
-        f.nx = nx_;
-        f.ny = ny_;
-        f.nz = nz_;
-        f.pitch = pitch_;
-        f.cls_pitch = cls_pitch_;
-        f.z_begin = z_begin_;
-        f.z_end = z_end_;
-        hipLaunchKernelGGL(wv::triple_flags_kernel<Real>, dim3(1024), dim3(256), 0, stream_, f);
-    }
-    // level 1: boundary nodes to t+1
+    // level 1: boundary nodes to t+1 -- and, by the launch's last workgroup, step t+1's source sample / receivers (none of those nodes
+    // is a boundary node: their t+1 has been final since the march) and then the second level's list where it is short and none of its
+    // nodes has a boundary node for a neighbour (the source's neighbours, typically)
+    bool list2_done = false;
     token = begin_part_timing(0);
-    if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false))) return rc;
+    if (fuse && io) {
+        wv::PrePostArgs<Real> nx = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
+        nx.flag = nullptr;
+        if (pair_list_early_ok_ && pair_list_n_) {
+            nx.fix_nodes = pair_list_;
+            nx.fix_n = pair_list_n_;
+            nx.fix_cur = B;
+            nx.fix_out2 = O2;
+            nx.fix_flag = flag2;
+            nx.nx = nx_;
+            nx.ny = ny_;
+            nx.nz = nz_;
+            nx.pitch = pitch_;
+            list2_done = true;
+        }
+        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, &nx, O1, false, false))) return rc;
+    } else {
+        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false))) return rc;
+        if (io) {
+            wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
+            pp.flag = nullptr;
+            hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
+    }
     if ((rc = end_part_timing(0, token))) return rc;
-    if (io) {
-        wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
-        pp.flag = nullptr;
-        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
-    }
-    // level 2: the second level's list (as in a two-step pass), then the boundary nodes, whose 1-D entries finish the nodes they face
-    if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+    // level 2: the second level's list (as in a two-step pass), then the boundary nodes, whose 1-D entries finish the nodes they face --
+    // with step t+2's source / receiver work where none of those nodes is written by the launch
+    if (!list2_done && (rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
     token = begin_part_timing(1);
-    if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2, pair_inner_ok_ > 0, false))) return rc;
-    if ((rc = end_part_timing(1, token))) return rc;
-    if (io) {
-        wv::PrePostArgs<Real> pp = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
-        pp.flag = nullptr;
-        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    if (fuse && io && io_nodes_unfaced()) {
+        wv::PrePostArgs<Real> nx = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
+        nx.flag = nullptr;
+        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, &nx, O2, pair_inner_ok_ > 0, false))) return rc;
+    } else {
+        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2, pair_inner_ok_ > 0, false))) return rc;
+        if (io) {
+            wv::PrePostArgs<Real> pp = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
+            pp.flag = nullptr;
+            hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+        }
     }
-    // level 3: every shell node from the finished t+2 field, then the boundary nodes
+    if ((rc = end_part_timing(1, token))) return rc;
+    // level 3: every shell node from the finished t+2 field -- and the exact error bits of what the march was the last to write, should it
+    // have seen an inf or a nan (fields t-1 and t are still what the march read) --, then the boundary nodes
     token = begin_part_timing(3);
-    if (triple_list_n_) {
+    {
         wv::PairFixupArgs<Real> f{};
         f.nodes = triple_list_;
         f.n = triple_list_n_;
@@ -281,11 +314,37 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         f.ny = ny_;
         f.nz = nz_;
         f.pitch = pitch_;
-        hipLaunchKernelGGL(wv::pair_fixup_kernel<Real>, dim3((triple_list_n_ + 255) / 256), dim3(256), 0, stream_, f);
+        wv::TripleFlagsArgs<Real> g{};
+        g.prev = A;
+        g.cur = B;
+        g.out2 = O2;
+        g.out3 = O3;
+        g.pair_map = pair_map_;
+        g.suspect = suspect_ + slot;
+        g.flag1 = flag1;
+        g.flag2 = flag2;
+        g.flag3 = flag3;
+        g.source_node = source_live ? source_node_ : ~0ull;
+        g.nx = nx_;
+        g.ny = ny_;
+        g.nz = nz_;
+        g.pitch = pitch_;
+        g.cls_pitch = cls_pitch_;
+        g.z_begin = z_begin_;
+        g.z_end = z_end_;
+        hipLaunchKernelGGL(wv::triple_list_kernel<Real>, dim3(std::max(1u, (triple_list_n_ + 255) / 256)), dim3(256), 0, stream_, f, g);
     }
     if ((rc = end_part_timing(3, token))) return rc;
     token = begin_part_timing(2);
-    if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false))) return rc;
+    if (fuse && fuse_next) {
+        // what follows reads its source / receiver nodes from the t+3 field: none of them is a boundary node
+        wv::PrePostArgs<Real> nx = pre_post_args(O3, slot + 3, true, signal_pos + 3, source_live);
+        if (fuse_next == 2) nx.flag2 = flags_ + slot + 4;
+        if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, &nx, O3, false, false))) return rc;
+        pre_post_done_ = true;
+    } else if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false))) {
+        return rc;
+    }
     if ((rc = end_part_timing(2, token))) return rc;
     pass_timed_ = false;
     WV_HIP(hipGetLastError());

@@ -415,8 +415,7 @@ struct PairFixupArgs {
 };
 
 template <typename Real>
-__global__ void __launch_bounds__(256) pair_fixup_kernel(const PairFixupArgs<Real> a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pair_fixup_node(const PairFixupArgs<Real>& a, uint32_t i) {
     if (i >= a.n) return;
     const uint32_t idx = a.nodes[i];
     const int x = (int)(idx % (uint32_t)a.pitch);
@@ -436,6 +435,11 @@ __global__ void __launch_bounds__(256) pair_fixup_kernel(const PairFixupArgs<Rea
     const int bad = bad_bits(s);
     if (bad) atomicOr(a.flag2, bad);
     a.out2[idx] = s;
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) pair_fixup_kernel(const PairFixupArgs<Real> a) {
+    pair_fixup_node<Real>(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- the pair map and the fix-up list, once per (mesh, source node) --------------------------------

@@ -614,7 +614,7 @@ struct TripleFlagsArgs {
 };
 
 template <typename Real>
-__global__ void __launch_bounds__(256) triple_flags_kernel(const TripleFlagsArgs<Real> a) {
+__device__ __forceinline__ void triple_flags_body(const TripleFlagsArgs<Real>& a) {
     if (*a.suspect == 0) return;
     const int64_t plane = (int64_t)a.pitch * a.ny;
     const int64_t n = plane * (a.z_end - a.z_begin);
@@ -651,6 +651,19 @@ __global__ void __launch_bounds__(256) triple_flags_kernel(const TripleFlagsArgs
     if (bad1) atomicOr(a.flag1, bad1);
     if (bad2) atomicOr(a.flag2, bad2);
     if (bad3) atomicOr(a.flag3, bad3);
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) triple_flags_kernel(const TripleFlagsArgs<Real> a) {
+    triple_flags_body<Real>(a);
+}
+
+// The third level's fix-up list and the exact-flags check in ONE launch (both want the fields t-1 and t of the pass intact and nothing
+// else of each other; a launch is 5 us, which is something at 256^3).
+template <typename Real>
+__global__ void __launch_bounds__(256) triple_list_kernel(const PairFixupArgs<Real> f, const TripleFlagsArgs<Real> g) {
+    pair_fixup_node<Real>(f, blockIdx.x * blockDim.x + threadIdx.x);
+    triple_flags_body<Real>(g);
 }
 
 }  // namespace wv

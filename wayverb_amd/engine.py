@@ -48,12 +48,12 @@ class WvMesh(C.Structure):
 TUNING_FIELDS = ("pair", "pair_chunks", "pair_inner_fix", "pair_wide", "pair_unit_waves", "pair_unit_planes", "pair_units_by_chunk", "tile_lists",
                  "fuse_pre_post", "graph", "boundary_lds", "boundary_order", "boundary_xwall",
                  "stream_ry", "stream_nwx", "stream_nwy", "stream_zchunks", "slab_early", "pair_split_rows", "fuse_planes", "whole_step", "triple",
-                 "triple_chunks")
+                 "triple_chunks", "triple_lanes")
 
 
 class WvTuning(C.Structure):
     """wv_tuning (include/wayverb_amd.h): how the engine does its work, never what it computes."""
-    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS] + [("reserved_", C.c_int32 * 1)]
+    _fields_ = [(name, C.c_int32) for name in TUNING_FIELDS]
 
 
 class WvOptions(C.Structure):
