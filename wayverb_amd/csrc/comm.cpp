@@ -131,20 +131,26 @@ __global__ void flag_spread_kernel(const int* flags, uint64_t* out, int n) {
 struct IpcFlags {
     uint64_t* flag[2];
     uint64_t value[2];
+    int side[2];  // 0: the lower neighbour's, 1: the upper one's (what a time-out names)
     int n;
 };
-__global__ void ipc_post_kernel(IpcFlags f) {
+// *status != 0: a wait of this rank has timed out -- its ghost planes are stale and so is everything computed from them since.  The
+// rank says nothing more to its neighbours (they time out in their turn and end with WV_E_COMM too, instead of stepping on with planes
+// that mean nothing), and its own later waits return at once (one time-out per batch, not one per exchange).
+__global__ void ipc_post_kernel(IpcFlags f, const int* status) {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     __threadfence_system();  // the copies before this kernel in stream order are visible to whoever sees the counter
     for (int i = 0; i < f.n; ++i) __hip_atomic_store(f.flag[i], f.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Waits until every counter has reached its value; gives up after `ticks` of the 100 MHz wall clock and says so in *status
-// (bit `code`): the batch then ends with WV_E_COMM instead of a stream that never drains.
+// (`code` << 4 * side): the batch then ends with WV_E_COMM instead of a stream that never drains.
 __global__ void ipc_wait_kernel(IpcFlags f, long long ticks, int* status, int code) {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     const long long t0 = wall_clock64();
     for (int i = 0; i < f.n; ++i) {
         while (__hip_atomic_load(f.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < f.value[i]) {
             if (ticks > 0 && wall_clock64() - t0 > ticks) {
-                __hip_atomic_fetch_or(status, code << (4 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_fetch_or(status, code << (4 * f.side[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
             __builtin_amdgcn_s_sleep(32);
@@ -377,6 +383,8 @@ bool SlabComm::ipc_wait(hipStream_t stream, int n, const uint64_t* const* flags,
     for (int i = 0; i < n; ++i) {
         f.flag[i] = const_cast<uint64_t*>(flags[i]);
         f.value[i] = values[i];
+        // (callers list the lower neighbour's counter first when there is one: with one neighbour only, it is whichever that is)
+        f.side[i] = (n == 2) ? i : (has_lo_ ? 0 : 1);
     }
     const long long ticks = timeout_s_ > 0 ? (long long)(timeout_s_ * 1e8) : 0;
     hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(1), 0, stream, f, ticks, ipc_status_, code);
@@ -390,7 +398,7 @@ bool SlabComm::ipc_post(hipStream_t stream, int n, uint64_t* const* flags, const
         f.flag[i] = flags[i];
         f.value[i] = values[i];
     }
-    hipLaunchKernelGGL(ipc_post_kernel, dim3(1), dim3(1), 0, stream, f);
+    hipLaunchKernelGGL(ipc_post_kernel, dim3(1), dim3(1), 0, stream, f, ipc_status_);
     return hip_ok(hipGetLastError(), "ipc_post_kernel", err);
 }
 
@@ -718,9 +726,11 @@ bool SlabComm::sync(hipStream_t stream, const std::string& what, std::string* er
         if (q == hipSuccess) {
             if (ipc_status_ && *ipc_status_) {
                 const int st = *ipc_status_;
+                const std::string which = std::string((st & 0x0F) ? "the lower" : "") + ((st & 0x0F) && (st & 0xF0) ? " and " : "") + ((st & 0xF0) ? "the upper" : "");
                 *err = "rank " + std::to_string(rank_) + " of " + std::to_string(nranks_) + ": " + what + ": a wait for " +
-                       ((st & 0x11) ? "ghost planes from" : "the end of a step on") + " a neighbouring rank timed out on the device after " +
-                       std::to_string((int)timeout_s_) + " s (status " + std::to_string(st) + "): the fields are no longer meaningful";
+                       ((st & 0x11) ? "ghost planes from " : "the end of a step on ") + which + " neighbouring rank timed out on the device after " +
+                       std::to_string((int)timeout_s_) + " s (status " + std::to_string(st) +
+                       "); this rank has told its neighbours nothing since: the fields are no longer meaningful";
                 dead_ = true;
                 return false;
             }
