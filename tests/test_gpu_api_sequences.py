@@ -66,11 +66,12 @@ def random_room(rng, seed):
     return M.mesh_from_nodes((nx, ny, nz), nodes, counts, coeffs, surface_of_port=surfaces)
 
 
-@pytest.mark.parametrize("mode", ["default", "passes", "single-steps", "two-launch-steps", "graph-replay", "graph-and-passes"])
+@pytest.mark.parametrize("mode", ["default", "passes", "three-step-passes", "single-steps", "two-launch-steps", "graph-replay", "graph-and-passes"])
 @pytest.mark.parametrize("seed", range(40))
 def test_random_api_sequence(oracle, built_library, seed, mode):
     set_tuning(**{"default": {}, "passes": dict(pair=1), "single-steps": dict(pair=0), "two-launch-steps": dict(pair=0, whole_step=0),
-                "graph-replay": dict(pair=0, graph=1), "graph-and-passes": dict(pair=1, graph=1)}[mode])
+                "graph-replay": dict(pair=0, graph=1), "graph-and-passes": dict(pair=1, graph=1),
+                "three-step-passes": dict(pair=1, triple=1, tile_lists=0)}[mode])
     rng = np.random.default_rng(4000 + seed)
     mesh = random_room(rng, seed)
     tag, dtype = ("f64", np.float64) if seed % 4 else ("f32", np.float32)

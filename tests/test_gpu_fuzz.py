@@ -1,8 +1,9 @@
 """Seeded random cases through the engine against the oracle: room shape, mesh dimensions (rows of one to
 three waves, ragged), wall materials, source kind and place (any node that is not `none`: inside, next to a wall,
 ON a wall, re-entrant), receivers anywhere (inside, faced by a wall, on walls, outside), step count, precision
--- each case with the engine's own choice of stepping, with two-step passes forced on, and with two-step
-passes whose wall-adjacent nodes all go through the fix-up list.  Everything the run leaves behind must be
+-- each case with the engine's own choice of stepping, with two-step passes forced on, with two-step
+passes whose wall-adjacent nodes all go through the fix-up list, and with three-step passes (fused into five launches and with
+every piece in a launch of its own; doubles on either lane width).  Everything the run leaves behind must be
 the oracle's bit for bit: receiver traces, both fields, every filter memory word, the step count and flag."""
 import numpy as np
 import pytest
@@ -15,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 MODES = {"default": {}, "passes": dict(pair=1), "passes-list-only": dict(pair=1, pair_inner_fix=0),
          "passes-own-launches": dict(pair=1, fuse_pre_post=0), "single-steps": dict(pair=0),  # (one launch each where the source / receivers allow)
-         "two-launch-steps": dict(pair=0, whole_step=0)}
+         "two-launch-steps": dict(pair=0, whole_step=0),
+         "three-step-passes": dict(pair=1, triple=1, tile_lists=0), "three-step-passes-own-launches": dict(pair=1, triple=1, tile_lists=0, fuse_pre_post=0),
+         "three-step-passes-list-only": dict(pair=1, triple=1, tile_lists=0, pair_inner_fix=0)}
 
 
 def random_case(seed):
@@ -66,6 +69,7 @@ def test_random_case_equals_the_oracle_in_every_stepping_mode(oracle, built_libr
     assert want["flag"] == 0, (room, dims)
     modes = dict(MODES)
     modes["passes-in-z-chunks"] = dict(pair=1, pair_chunks=2 + seed % 3)
+    modes["three-step-passes-in-z-chunks"] = dict(pair=1, triple=1, tile_lists=0, triple_chunks=2 + seed % 3, triple_lanes=8 if seed % 2 else 16)
     for mode, env in modes.items():
         set_tuning(**env)
         try:
@@ -110,7 +114,7 @@ def test_speckled_rooms_in_degenerate_meshes(oracle, built_library, seed):
     prev_o, cur_o = prev.astype(dtype), cur.astype(dtype)
     bd = [mesh.boundary_data(d) for d in (1, 2, 3)]
     want_steps, want_flag, want_trace = oracle.run(prev_o, cur_o, mesh, bd, kind, src, case["signal"], steps, case["recv"], threads=2)
-    for env in ({}, dict(pair=1), dict(pair=0), dict(pair=0, whole_step=0)):
+    for env in ({}, dict(pair=1), dict(pair=0), dict(pair=0, whole_step=0), dict(pair=1, triple=1, tile_lists=0), dict(pair=1, triple=1, tile_lists=0, triple_lanes=8)):
         set_tuning(**env)
         eng = E.Engine(mesh, precision=tag)
         try:
