@@ -108,7 +108,8 @@ typedef struct wv_tuning {
     int32_t graph;            /* 1: batches of single steps on small meshes are replayed as a hipGraph */
     int32_t boundary_lds;     /* 1: boundary workgroups stage the coefficient sets in LDS (<= 256 sets) */
     int32_t boundary_order;   /* 1: boundary entries processed in 64x8x8-brick order; 0: in the caller's order */
-    int32_t boundary_xwall;   /* 1: in two-step passes the wall nodes that face along x work on compact copies of what they would gather from the fields */
+    int32_t boundary_xwall;   /* 1: in two- and three-step passes the wall nodes that face along x work on compact copies of what they would gather
+                               * from the fields; 2: in two-step passes only (measurement); 0: nowhere */
     int32_t stream_ry, stream_nwx, stream_nwy, stream_zchunks; /* sweep tile shape as wv_set_stream_tuning; 0 = automatic */
     int32_t slab_early;       /* z-slabs, two-step passes: 1 = the faces AND the planes next to them are stepped ahead of the march, so that both
                                * halo exchanges of a pass (and the faces' second step, on the halo stream) run under it; 0 = the second exchange

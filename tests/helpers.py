@@ -47,7 +47,8 @@ def run_engine(case, precision, **engine_kw):
         return dict(steps=steps, flag=0, trace=out.astype(dtype),
                     current=eng.read_field(E.BUF_CURRENT), previous=eng.read_field(E.BUF_PREVIOUS),
                     bd=[eng.read_boundary_data(d) for d in (1, 2, 3)],
-                    passes=eng.query(E.Engine.QUERY_PASSES), triple_passes=eng.query(E.Engine.QUERY_TRIPLE_PASSES))
+                    passes=eng.query(E.Engine.QUERY_PASSES), triple_passes=eng.query(E.Engine.QUERY_TRIPLE_PASSES),
+                    xwall_entries=eng.query(E.Engine.QUERY_XWALL_ENTRIES))
     finally:
         eng.close()
 

@@ -66,6 +66,32 @@ def test_triple_path_ragged_meshes_match_oracle(oracle, dims, tag):
             assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("xwall", [1, 2, 0])
+@pytest.mark.parametrize("dims", [(24, 20, 18), (131, 9, 7), (300, 21, 13), (64, 64, 17), (9, 40, 37), (1100, 10, 9)], ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_triple_path_x_facing_walls_on_their_compact_copies_or_not(oracle, dims, tag, xwall):
+    """The wall nodes that face along x through a pass's three levels on compact copies of what they would gather from the fields
+    (boundary_xwall=1, the default: xwall3_node -- they also finish the node they face at t+2 and t+3, which the third level's list
+    then leaves out), in two-step passes only (2) or nowhere (0): the same bits; batches that end in a two-step pass or a single step
+    after the three-step ones hand the copies over and take them back."""
+    dtype = np.float32 if tag == "f32" else np.float64
+    set_tuning(boundary_xwall=xwall, **ON)
+    for steps in (11, 12, 13):
+        # (no re-entrant node: a mesh with a boundary entry that cannot finish the node it faces keeps all its entries on the fields)
+        case = _random_case(dims, seed=sum(dims) + xwall, steps=steps, reentrant=False)
+        want = run_oracle(oracle, case, dtype, threads=4)
+        got = run_engine(case, tag)
+        assert want["flag"] == 0 and got["steps"] == want["steps"] and got["triple_passes"] == (steps - 2) // 3
+        # (9 columns: the source, at x = 3, sits two nodes from the x = 1 wall, whose entries capture their neighbourhood's t+1 before
+        # the sample goes in -- such a run keeps every entry on the fields)
+        assert (got["xwall_entries"] > 0) == (xwall != 0 and dims[0] >= 12)
+        assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
+        assert got["current"].tobytes() == want["current"].tobytes()
+        assert got["previous"].tobytes() == want["previous"].tobytes()
+        for a, b in zip(got["bd"], want["bd"]):
+            assert a.tobytes() == b.tobytes()
+
+
 @pytest.mark.parametrize("lanes", [8, 16])
 @pytest.mark.parametrize("dims", [(256, 40, 33), (300, 23, 41), (1024, 24, 19), (1100, 13, 12), (2100, 9, 8)], ids=lambda d: "x".join(map(str, d)))
 def test_triple_path_both_lane_widths_of_the_double_march(oracle, dims, lanes):

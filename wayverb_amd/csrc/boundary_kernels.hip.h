@@ -347,6 +347,123 @@ __device__ __forceinline__ void xwall_node(const BoundaryArgs<Real>& a, const do
     }
 }
 
+// The same walls in a THREE-step pass (engine_triple.hip.h): three levels on the compact copies, the generations rotating through the
+// arrays so that no lane overwrites what another lane of the same launch still reads.  With t the pass's `current`:
+//   own value    xw_a = t-1, xw_b = t   --L1-->  xw_o2 = t+1   --L2-->  xw_a = t+2   --L3-->  xw_b = t+3        (the roles the next pass starts from)
+//   faced node   xw_f = t                --L1-->  xw_f1 = t+1 (captured from the march's t+1 field, with xw_g = the node behind it)
+//                                        --L2-->  xw_f2 = t+2 (computed here, as in a two-step pass)   --L3-->  xw_f = t+3 (computed here)
+//   level 1 (t-1, t -> t+1)    reads one line of the t+1 field (the march's shell values), writes its own t+1 into it
+//   level 2 (t, t+1 -> t+2)    reads no field; writes its own and the faced node's t+2 (one line)
+//   level 3 (t+1, t+2 -> t+3)  reads the node behind the faced one at t+2 from its own line of the t+2 field; writes its own and the faced
+//                              node's t+3 (one line) -- the faced nodes of these entries are not on the third level's list
+// (the node behind the faced one gets its t+3 from that list: its lateral neighbours at t+2 are four more lines.)
+// a.prev / a.cur / a.next are the fields at the levels boundary_node would read and write; rim entries fall back to them as in xwall_node.
+template <typename Real, int LEVEL>
+__device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t pos_e, int& bad) {
+    const uint32_t idx = a.bnode[pos_e];
+    const uint32_t dirs = a.btype[pos_e];  // 1: inner node at x-1, 2: at x+1
+    const int x = (int)(idx % (uint32_t)a.pitch);
+    const uint32_t q = idx / (uint32_t)a.pitch;
+    const int y = (int)(q % (uint32_t)a.ny);
+    const int z = (int)(q / (uint32_t)a.ny);
+    const int64_t plane = (int64_t)a.pitch * a.ny;
+    const int64_t stride[3] = {1, a.pitch, plane};
+    const int pos[3] = {x, y, z};
+    const int lim[3] = {a.nx, a.ny, a.nz};
+    const int step = (dirs & 2u) ? 1 : -1;
+    const int64_t fn = (int64_t)idx + step;  // the faced node: in the grid (xwall_eligible_kernel)
+    const bool far_off = x + 2 * step < 0 || x + 2 * step >= a.nx;
+    // which array holds what at this level
+    const Real* const own_nb = LEVEL == 1 ? a.xw_b : (LEVEL == 2 ? a.xw_o2 : a.xw_a);    // wall values at the level the neighbours are read at
+    const Real* const own_prev = LEVEL == 1 ? a.xw_a : (LEVEL == 2 ? a.xw_b : a.xw_o2);  // ... one level back: this node's own old value
+    Real* const own_out = LEVEL == 1 ? a.xw_o2 : (LEVEL == 2 ? a.xw_a : a.xw_b);
+    const Real* const f_nb = LEVEL == 1 ? a.xw_f : (LEVEL == 2 ? a.xw_f1 : a.xw_f2);     // the faced node at the neighbours' level
+
+    // ---- loads -----------------------------------------------------------------------------------
+    uint32_t ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ref[k] = a.xw_nbr[(size_t)k * a.xw_n + pos_e];
+    Real nb[3][2];
+    bool off[3][2];
+    off[0][0] = x - 1 < 0;
+    off[0][1] = x + 1 >= a.nx;
+    nb[0][0] = nb[0][1] = f_nb[pos_e];  // (only the inner side enters the sums)
+    bool any_field = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ax = 1 + (k >> 1), s = k & 1;
+        const int c = pos[ax] + (s ? 1 : -1);
+        off[ax][s] = c < 0 || c >= lim[ax];
+        const bool mirrored = ref[k] != XW_FIELD;
+        nb[ax][s] = own_nb[mirrored ? (ref[k] & ~XW_SAME_FACING) : pos_e];
+        any_field = any_field || !mirrored;
+    }
+    const Real prev = own_prev[pos_e];
+    double m[1][6];
+    const double* cf[1];
+    cf[0] = coeffs + (size_t)a.cidx[pos_e] * 14;  // (1-D entries: slot = position)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m[0][j] = __builtin_nontemporal_load(a.fmem + (size_t)j * a.n_slots + pos_e);
+    // level 1: what the later levels will want of the t+1 field (a.next), both in this node's line
+    Real f1 = 0, far1 = 0;
+    // levels 2, 3: the faced node's update from the level the neighbours are read at
+    Real fnb[3][2], fprev = 0;
+    bool any_lateral_field = false;
+    if (LEVEL == 1) {
+        f1 = a.next[fn];
+        far1 = a.next[fn + (far_off ? 0 : step)];
+        far1 = far_off ? Real(0) : far1;
+    } else {
+        const Real own_at = own_nb[pos_e];  // this node's own value at the neighbours' level
+        Real far = LEVEL == 2 ? a.xw_g[pos_e] : a.cur[fn + (far_off ? 0 : step)];
+        far = (LEVEL == 3 && far_off) ? Real(0) : far;
+        fnb[0][0] = step > 0 ? own_at : far;
+        fnb[0][1] = step > 0 ? far : own_at;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            const bool regular = ref[k] != XW_FIELD && (ref[k] & XW_SAME_FACING);
+            const Real v = f_nb[regular ? (ref[k] & ~XW_SAME_FACING) : pos_e];
+            fnb[ax][s] = off[ax][s] ? Real(0) : v;  // (the faced node's y, z are this node's)
+            any_lateral_field = any_lateral_field || (!regular && !off[ax][s]);
+        }
+        fprev = LEVEL == 2 ? a.xw_f[pos_e] : a.xw_f1[pos_e];
+    }
+    // the wall's rim, walls that meet other things than walls: those neighbours come from the fields
+    if (any_field) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            if (ref[k] == XW_FIELD) nb[ax][s] = a.cur[(int64_t)idx + (off[ax][s] ? 0 : (s ? stride[ax] : -stride[ax]))];
+        }
+    }
+    if (LEVEL != 1 && any_lateral_field) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            const bool regular = ref[k] != XW_FIELD && (ref[k] & XW_SAME_FACING);
+            if (!regular && !off[ax][s]) fnb[ax][s] = a.cur[fn + (s ? stride[ax] : -stride[ax])];
+        }
+    }
+
+    // ---- the node's new value, its filter's new memories; stores -----------------------------------------
+    const Real next = boundary_value<Real, 1>(a.courant, a.courant_sq, dirs, nb, off, prev, m, cf);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(m[0][j], a.fmem + (size_t)j * a.n_slots + pos_e);
+    bad |= bad_bits(next);
+    a.next[idx] = next;
+    own_out[pos_e] = next;
+    if (LEVEL == 1) {
+        a.xw_f1[pos_e] = f1;
+        a.xw_g[pos_e] = far1;
+    } else {
+        const Real sf = faced_value<Real>(fnb, fprev);
+        bad |= bad_bits(sf);
+        a.next[fn] = sf;
+        (LEVEL == 2 ? a.xw_f2 : a.xw_f)[pos_e] = sf;
+    }
+}
+
 // entry id -> dimensionality dispatch (entry order: all 1-D, all 2-D, all 3-D)
 template <typename Real, bool FIX>
 __device__ __forceinline__ void boundary_entry(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t e, int& bad) {
@@ -374,7 +491,8 @@ __device__ __forceinline__ void pre_post_body(const PrePostArgs<Real>& a, uint32
 // (BoundaryArgs::fix_z0 / fix_z1).
 // (`block` of `blocks`: this workgroup's place among the boundary workgroups of the launch -- all of it for boundary_kernel, the
 // tail of the grid for plane_step_kernel.)
-template <typename Real, bool LDSC, bool FIX>
+// XW3: 0, or the level (1, 2, 3) of a three-step pass whose x-facing walls work on their compact copies (xwall3_node)
+template <typename Real, bool LDSC, bool FIX, int XW3 = 0>
 __device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const PrePostArgs<Real>& next, uint32_t block, uint32_t blocks) {
     __shared__ double s_coeffs[LDSC ? kMaxLdsCoefficientSets * 14 : 1];
     if (LDSC) {
@@ -388,7 +506,12 @@ __device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const
         // two-step pass: the first xw_n entries (x-facing walls) by their compact copies, whole workgroups of them
         // first; then everything else as ever (FIX = this is the pass's second launch = level 2)
         if (t < a.xw_pad) {
-            if (t < a.xw_n) xwall_node<Real, FIX ? 2 : 1>(a, coeffs, t, bad);
+            if (t < a.xw_n) {
+                if (XW3)
+                    xwall3_node<Real, XW3 ? XW3 : 1>(a, coeffs, t, bad);
+                else
+                    xwall_node<Real, FIX ? 2 : 1>(a, coeffs, t, bad);
+            }
         } else if (a.order) {
             if (t - a.xw_pad < a.n_order) boundary_entry<Real, FIX>(a, coeffs, a.order[t - a.xw_pad], bad);
         } else {
@@ -403,9 +526,24 @@ __device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const
     if (next.fused && block == blocks - 1) pre_post_body<Real>(next, threadIdx.x, 256);
 }
 
-template <typename Real, bool LDSC, bool FIX = false>
+template <typename Real, bool LDSC, bool FIX = false, int XW3 = 0>
 __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
-    boundary_body<Real, LDSC, FIX>(a, next, blockIdx.x, gridDim.x);
+    boundary_body<Real, LDSC, FIX, XW3>(a, next, blockIdx.x, gridDim.x);
+}
+
+// the inside nodes the x-facing walls' entries finish at the third level of a three-step pass (xwall3_node): a bit per stored node, for the
+// third-level list to leave them out (triple_map_kernel)
+struct XwCoverArgs {
+    const uint32_t* bnode;
+    const uint8_t* btype;
+    uint32_t* covered;  // bitmap over stored node indices
+    uint32_t xw_n;
+};
+__global__ void __launch_bounds__(256) xwall_cover_kernel(const XwCoverArgs a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.xw_n) return;
+    const uint32_t fn = a.bnode[p] + ((a.btype[p] & 2u) ? 1u : 0xFFFFFFFFu);
+    atomicOr(a.covered + (fn >> 5), 1u << (fn & 31u));
 }
 
 // Which 1-D entries may live on compact copies (xwall_node): facing along x, in the planes the march produces, the

@@ -149,6 +149,9 @@ struct BoundaryArgs {
     uint32_t xw_n, xw_pad;
     const uint32_t* xw_nbr;                  // [4][xw_n]
     Real *xw_a, *xw_b, *xw_f, *xw_f1, *xw_g;  // [xw_n] each
+    // ... and in three-step passes (xwall3_node): two more generations, the wall node's own value at a third time level and the faced
+    // node at t+2
+    Real *xw_o2, *xw_f2;
 };
 
 template <typename Real>

@@ -62,7 +62,7 @@ public:
         bool lds = false;
     };
     int launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next = nullptr, Real* out = nullptr, bool fix_inner = false,
-                        bool levels = false, BoundaryLaunch* plan_only = nullptr);
+                        bool levels = false, BoundaryLaunch* plan_only = nullptr, int xw3 = 0);
     wv::PrePostArgs<Real> pre_post_args(Real* cur, int slot, bool with_pre_post, uint64_t signal_pos, bool source_live) const;
     int enqueue_step(int slot, bool with_pre_post, uint64_t signal_pos, bool source_live, int fuse_next = 0);
     // one-launch steps (plane_kernels.hip.h, whole_step_kernel): may this engine take them (synchronises once per source / receiver
@@ -260,7 +260,7 @@ private:
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)
     uint32_t* xw_nbr_ = nullptr;   // [4][n_xw_] in-wall neighbours by entry position
-    Real* xw_val_ = nullptr;       // [5][n_xw_]: own value at the odd / even level, faced node, and level 1's captures
+    Real* xw_val_ = nullptr;       // [7][n_xw_]: own value at the odd / even level, faced node, level 1's captures; a three-step pass's third generations
     bool xw_built_ = false;        // table and copies allocated (first ensure_pair that may use them)
     bool xw_active_ = false;       // this (mesh, source) runs its passes on them
     bool xw_valid_ = false;        // the copies hold what the fields hold
@@ -273,6 +273,7 @@ private:
     int* suspect_ = nullptr;           // [kRing] per step slot: the march saw an inf / nan
     uint64_t triple_source_ = 0, triple_io_generation_ = ~0ull;
     bool triple_failed_ = false, triple_ready_ = false, triple_attr_set_ = false;
+    bool triple_xw_ = false;           // the passes' three levels take the x-facing walls on their compact copies (and the third-level list leaves the nodes they face out)
     // stored nodes from which the engine takes three-step passes by itself (tools/pass_forms_by_size.py, profiles/r06/pass_forms_by_size_*.txt:
     // Gnode-updates/s two-step / three-step, fp64: 256^3 212 / 216, 320^3 206 / 223, 384^3 258 / 288, 512^3 304 / 340, 768^3 326 / 396,
     // 1024^3 355 / 421 -- 256^3 with 8-byte lanes and the pass's launches fused: 211 / 234; fp32 (8-byte lanes: twice the instructions per byte): 384^3 364 / 375, 512^3 522 / 549, 768^3 577 / 532, 1024^3 660 / 693)

@@ -478,8 +478,8 @@ int Engine<Real>::build_xwall() {
     }
     WV_HIP(hipMalloc((void**)&xw_nbr_, nbr.size() * sizeof(uint32_t)));
     WV_HIP(hipMemcpy(xw_nbr_, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    WV_HIP(hipMalloc((void**)&xw_val_, (size_t)5 * n * sizeof(Real)));
-    WV_HIP(hipMemsetAsync(xw_val_, 0, (size_t)5 * n * sizeof(Real), stream_));
+    WV_HIP(hipMalloc((void**)&xw_val_, (size_t)7 * n * sizeof(Real)));
+    WV_HIP(hipMemsetAsync(xw_val_, 0, (size_t)7 * n * sizeof(Real), stream_));
     xw_built_ = true;
     xw_valid_ = false;
     return WV_OK;
@@ -495,6 +495,8 @@ void Engine<Real>::xwall_args(wv::BoundaryArgs<Real>& b) const {
     b.xw_f = xw_val_ + (size_t)2 * n_xw_;
     b.xw_f1 = xw_val_ + (size_t)3 * n_xw_;
     b.xw_g = xw_val_ + (size_t)4 * n_xw_;
+    b.xw_o2 = xw_val_ + (size_t)5 * n_xw_;
+    b.xw_f2 = xw_val_ + (size_t)6 * n_xw_;
 }
 
 template <typename Real>

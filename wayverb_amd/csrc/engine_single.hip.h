@@ -146,7 +146,7 @@ wv::BoundaryArgs<Real> Engine<Real>::boundary_args(Real* prev, const Real* cur, 
 // `out` (two-step passes): the new values go to another field instead of replacing `prev`.
 template <typename Real>
 int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0, int z1, const wv::PrePostArgs<Real>* next, Real* out, bool fix_inner,
-                                  bool levels, BoundaryLaunch* plan_only) {
+                                  bool levels, BoundaryLaunch* plan_only, int xw3) {
     const bool faces = z0 == z1 && (z0 == -1 || z0 == -2);
     if (!n_entries_ || (z0 >= z1 && !faces)) return WV_OK;
     wv::BoundaryArgs<Real> b = boundary_args(prev, cur, flag);
@@ -160,7 +160,8 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
     }
     // a two-step pass's launches over the bulk of the mesh: the x-facing walls by position, on their compact copies
     // (all of them lie in the planes of either such launch: xwall_eligible_kernel, engine_setup.hip.h)
-    const bool xw = out && xw_active_ && levels;
+    // (xw3: level 1, 2 or 3 of a three-step pass that does the same -- xwall3_node)
+    const bool xw = out && xw_active_ && (levels || xw3);
     uint32_t n = n_entries_ - (xw ? n_xw_ : 0u);
     if (faces) {
         const int rc = build_plane_order();
@@ -190,7 +191,22 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
         return WV_OK;
     }
     const dim3 grid((n + 255) / 256), block(256);
-    if (lds && fix_inner)
+    if (xw && xw3) {
+        if (lds && xw3 == 1)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false, 1>), grid, block, 0, st(), b, nx);
+        else if (lds && xw3 == 2 && fix_inner)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true, 2>), grid, block, 0, st(), b, nx);
+        else if (lds && xw3 == 3)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false, 3>), grid, block, 0, st(), b, nx);
+        else if (xw3 == 1)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false, 1>), grid, block, 0, st(), b, nx);
+        else if (xw3 == 2 && fix_inner)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false, true, 2>), grid, block, 0, st(), b, nx);
+        else if (xw3 == 3)
+            hipLaunchKernelGGL((wv::boundary_kernel<Real, false, false, 3>), grid, block, 0, st(), b, nx);
+        else
+            return fail(WV_E_STATE, "launch_boundary: a three-step pass's second level on compact copies without its entries finishing the nodes they face");
+    } else if (lds && fix_inner)
         hipLaunchKernelGGL((wv::boundary_kernel<Real, true, true>), grid, block, 0, st(), b, nx);
     else if (lds)
         hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false>), grid, block, 0, st(), b, nx);

@@ -73,7 +73,10 @@ int Engine<Real>::ensure_triple() {
         WV_HIP(hipMalloc((void**)&suspect_, kRing * sizeof(int)));
         WV_HIP(hipMemsetAsync(suspect_, 0, kRing * sizeof(int), stream_));
     }
-    if (triple_map_ && triple_source_ == src && triple_io_generation_ == io_generation_) {
+    // x-facing walls on their compact copies through all three levels where the two-step passes run on them (ensure_pair: the entries
+    // finish the nodes they face, the source is clear of them)
+    const bool xw = xw_active_ && pair_inner_ok_ > 0 && opt_.tuning.boundary_xwall != 2;
+    if (triple_map_ && triple_source_ == src && triple_io_generation_ == io_generation_ && triple_xw_ == xw) {
         triple_ready_ = true;
         return WV_OK;
     }
@@ -97,6 +100,21 @@ int Engine<Real>::ensure_triple() {
     m.cls_pitch = cls_pitch_;
     m.z_begin = z_begin_;
     m.z_end = z_end_;
+    ScopedDevice covered;  // the nodes those entries finish at the third level: not on its list
+    if (xw) {
+        const size_t words = (size_t)((stored_nodes_ + 31) / 32) + 1;
+        WV_HIP(hipMalloc(&covered.p, words * sizeof(uint32_t)));
+        WV_HIP(hipMemsetAsync(covered.p, 0, words * sizeof(uint32_t), stream_));
+        wv::XwCoverArgs c{};
+        c.bnode = bnode_;
+        c.btype = btype_;
+        c.covered = static_cast<uint32_t*>(covered.p);
+        c.xw_n = n_xw_;
+        hipLaunchKernelGGL(wv::xwall_cover_kernel, dim3((n_xw_ + 255) / 256), dim3(256), 0, stream_, c);
+        WV_HIP(hipGetLastError());
+        m.covered = c.covered;
+    }
+    triple_xw_ = xw;
     hipLaunchKernelGGL(wv::triple_map_kernel, dim3(blocks), dim3(256), 0, stream_, m);
     WV_HIP(hipGetLastError());
     std::vector<uint32_t> per_block(blocks);
@@ -123,9 +141,9 @@ int Engine<Real>::ensure_triple() {
         m.list = triple_list_;
         hipLaunchKernelGGL(wv::triple_map_kernel, dim3(blocks), dim3(256), 0, stream_, m);
         WV_HIP(hipGetLastError());
-        WV_HIP(hipStreamSynchronize(stream_));  // (per_block is on this function's stack)
         triple_list_n_ = (uint32_t)total;
     }
+    WV_HIP(hipStreamSynchronize(stream_));  // (per_block and the bitmap belong to this call)
     // receivers and the source node: their t+1 is read / written in the t+1 field whatever lies around them
     if (n_recv_ || src != ~0ull) {
         wv::TripleMarkArgs k{};
@@ -256,6 +274,13 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     // is a boundary node: their t+1 has been final since the march) and then the second level's list where it is short and none of its
     // nodes has a boundary node for a neighbour (the source's neighbours, typically)
     bool list2_done = false;
+    const bool xw = triple_xw_ && xw_active_;
+    if (xw && !xw_valid_) {  // the x-facing walls' compact copies, from fields t-1 and t
+        wv::BoundaryArgs<Real> g = boundary_args(A, B, flag1);
+        xwall_args(g);
+        hipLaunchKernelGGL(wv::xwall_gather_kernel<Real>, dim3(g.xw_pad / 256), dim3(256), 0, stream_, g);
+    }
+    xw_valid_ = xw;  // (passes that do not maintain the copies leave them behind)
     token = begin_part_timing(0);
     if (fuse && io) {
         wv::PrePostArgs<Real> nx = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
@@ -272,9 +297,9 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
             nx.pitch = pitch_;
             list2_done = true;
         }
-        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, &nx, O1, false, false))) return rc;
+        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, &nx, O1, false, false, nullptr, xw ? 1 : 0))) return rc;
     } else {
-        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false))) return rc;
+        if ((rc = launch_boundary(A, B, flag1, z_begin_, z_end_, nullptr, O1, false, false, nullptr, xw ? 1 : 0))) return rc;
         if (io) {
             wv::PrePostArgs<Real> pp = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
             pp.flag = nullptr;
@@ -289,9 +314,9 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     if (fuse && io && io_nodes_unfaced()) {
         wv::PrePostArgs<Real> nx = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
         nx.flag = nullptr;
-        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, &nx, O2, pair_inner_ok_ > 0, false))) return rc;
+        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, &nx, O2, pair_inner_ok_ > 0, false, nullptr, xw ? 2 : 0))) return rc;
     } else {
-        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2, pair_inner_ok_ > 0, false))) return rc;
+        if ((rc = launch_boundary(B, O1, flag2, z_begin_, z_end_, nullptr, O2, pair_inner_ok_ > 0, false, nullptr, xw ? 2 : 0))) return rc;
         if (io) {
             wv::PrePostArgs<Real> pp = pre_post_args(O2, slot + 2, true, signal_pos + 2, source_live);
             pp.flag = nullptr;
@@ -336,20 +361,20 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     }
     if ((rc = end_part_timing(3, token))) return rc;
     token = begin_part_timing(2);
-    if (fuse && fuse_next) {
-        // what follows reads its source / receiver nodes from the t+3 field: none of them is a boundary node
+    if (fuse && fuse_next && (!xw || io_nodes_unfaced())) {
+        // what follows reads its source / receiver nodes from the t+3 field: none of them is a boundary node (nor, with the x-facing walls
+        // on their copies, a node one of those entries finishes)
         wv::PrePostArgs<Real> nx = pre_post_args(O3, slot + 3, true, signal_pos + 3, source_live);
         if (fuse_next == 2) nx.flag2 = flags_ + slot + 4;
-        if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, &nx, O3, false, false))) return rc;
+        if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, &nx, O3, false, false, nullptr, xw ? 3 : 0))) return rc;
         pre_post_done_ = true;
-    } else if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false))) {
+    } else if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, nullptr, O3, false, false, nullptr, xw ? 3 : 0))) {
         return rc;
     }
     if ((rc = end_part_timing(2, token))) return rc;
     pass_timed_ = false;
     WV_HIP(hipGetLastError());
     ++triples_taken_;
-    xw_valid_ = false;  // (the x-facing walls' compact copies belong to the two-step passes)
     // roles: (previous, current) = (t+2, t+3); the fields that held t-1 and t are the spares now
     const int a_idx = prv_, b_idx = cur_;
     prv_ = spare_[0];

@@ -524,13 +524,14 @@ struct TripleMapArgs {
     uint32_t* list;          // fill pass: stored indices of the shell nodes; null: count pass
     int ny, nz, pitch, cls_pitch;
     int z_begin, z_end;      // planes this engine owns (nodes outside them are not listed)
+    const uint32_t* covered; // bit per stored node: finished at the third level by an x-facing wall's entry, not listed; null: none
 };
 
 __global__ void __launch_bounds__(256) triple_map_kernel(const TripleMapArgs a) {
     __shared__ uint32_t scan[256];
     const int64_t n_bytes = (int64_t)a.cls_pitch * a.ny * a.nz;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t out = 0, mine = 0;
+    uint32_t out = 0, mine = 0, listed_bits = 0;
     int xb = 0, y = 0, z = 0;
     if (i < n_bytes) {
         xb = (int)(i % a.cls_pitch);
@@ -549,7 +550,15 @@ __global__ void __launch_bounds__(256) triple_map_kernel(const TripleMapArgs a) 
                 const bool shell = pc == 3u || code_at(x - 1, y, z) == 3u || code_at(x + 1, y, z) == 3u || code_at(x, y - 1, z) == 3u ||
                                    code_at(x, y + 1, z) == 3u || code_at(x, y, z - 1) == 3u || code_at(x, y, z + 1) == 3u;
                 code = shell ? 3u : 1u;
-                if (shell && z >= a.z_begin && z < a.z_end) ++mine;
+                bool listed = shell && z >= a.z_begin && z < a.z_end;
+                if (listed && a.covered) {
+                    const uint32_t node = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + x);
+                    listed = !((a.covered[node >> 5] >> (node & 31u)) & 1u);
+                }
+                if (listed) {
+                    ++mine;
+                    listed_bits |= 1u << k;
+                }
             }
             out |= code << (2 * k);
         }
@@ -569,9 +578,9 @@ __global__ void __launch_bounds__(256) triple_map_kernel(const TripleMapArgs a) 
         return;
     }
     uint32_t at = a.block_count[blockIdx.x] + scan[threadIdx.x] - mine;
-    if (i < n_bytes && z >= a.z_begin && z < a.z_end)
+    if (i < n_bytes)
         for (int k = 0; k < 4; ++k)
-            if (((out >> (2 * k)) & 3u) == 3u) a.list[at++] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + xb * 4 + k);
+            if ((listed_bits >> k) & 1u) a.list[at++] = (uint32_t)(((int64_t)z * a.ny + y) * a.pitch + xb * 4 + k);
 }
 
 // receiver nodes and the source node that came out deep: shell all the same -- their t+1 has to be in the t+1 field (the source's
