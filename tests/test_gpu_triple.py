@@ -144,6 +144,47 @@ def test_triple_path_non_box_rooms(oracle, room, tag, dtype):
             eng.close()
 
 
+@pytest.mark.parametrize("lanes", [0, 8, 16])
+@pytest.mark.parametrize("room,dims", [("L", (300, 36, 30)), ("sphere", (200, 70, 64)), ("sphere", (520, 24, 40)), ("L", (140, 90, 100))])
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_triple_path_over_the_work_list_of_a_room_that_leaves_much_of_its_mesh_outside(oracle, room, dims, tag, dtype, lanes):
+    """A sparse room's three-step march visits the listed units only -- strips x chunks of planes with a node to update, the live
+    waves of each (build_triple_units) -- and everything else keeps its zeros: the same bits as the oracle's dense steps."""
+    if tag == "f32" and lanes == 16:
+        pytest.skip("floats march in 8-byte lanes")
+    set_tuning(pair=1, triple=1, triple_lanes=lanes)
+    mask = M.room_mask((dims[2], dims[1], dims[0]), room, seed=5)
+    nodes, counts = E.classify_nodes(mask)
+    rng = np.random.default_rng(23)
+    coeffs = np.concatenate([M.passive_peak_filter_coefficients(rng, 3), np.array([M.flat_coefficients(0.3)], dtype=M.coefficients_dtype)])
+    mesh = M.mesh_from_nodes(dims, nodes, counts, coeffs, surface_of_port=[0, 1, 2, 3, 0, 1])
+    inside = np.nonzero(mesh.nodes["boundary_type"] & M.ID_INSIDE)[0]
+    steps = 32
+    sig = rng.uniform(-0.1, 0.1, steps)
+    src = int(inside[len(inside) // 2])
+    recv = [src + 1, int(inside[3]), int(inside[-4]), int(inside[len(inside) // 3])]
+    live = mesh.nodes["boundary_type"] != 0
+    prev, cur = np.zeros(mesh.num_nodes), np.zeros(mesh.num_nodes)
+    prev[live] = rng.uniform(-0.25, 0.25, int(live.sum()))
+    cur[live] = rng.uniform(-0.25, 0.25, int(live.sum()))
+    case = dict(mesh=mesh, steps=steps, source_kind=E.SOURCE_SOFT, source_node=src, signal=sig, recv=recv, init=(prev, cur))
+    want = run_oracle(oracle, case, dtype, threads=4)
+    eng = E.Engine(mesh, precision=tag)
+    try:
+        eng.write_field(prev.astype(dtype), E.BUF_PREVIOUS)
+        eng.write_field(cur.astype(dtype), E.BUF_CURRENT)
+        got_steps, out = E.run_fast(eng, E.SOURCE_SOFT, src, sig, recv)
+        assert eng.query(E.Engine.QUERY_TRIPLE_PASSES) == (steps - 2) // 3 and eng.query(E.Engine.QUERY_MARCH_LIVE_PERMILLE) < 950
+        assert want["flag"] == 0 and got_steps == steps
+        assert np.array_equal(out.astype(dtype).view(np.uint8), want["trace"].view(np.uint8))
+        assert eng.read_field(E.BUF_CURRENT).tobytes() == want["current"].tobytes()
+        assert eng.read_field(E.BUF_PREVIOUS).tobytes() == want["previous"].tobytes()
+        for d, b in zip((1, 2, 3), want["bd"]):
+            assert eng.read_boundary_data(d).tobytes() == b.tobytes()
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("where", ["wall", "corner_inside", "next_to_wall", "two_from_wall", "middle"])
 def test_triple_path_source_on_and_near_walls(oracle, where):
     """The source node is not a plain node at any level of a pass: its sample goes into t+1 and t+2 between the launches, and what lies

@@ -30,28 +30,30 @@ def main():
               % (cutoff, fs, mesh.spacing, "x".join(map(str, mesh.dims)), mesh.num_nodes / 1e6, 100 * room,
                  len(mesh.bidx[0]), len(mesh.bidx[1]), len(mesh.bidx[2]), setup), flush=True)
         results = {}
-        for pair in (0, 1, -1):
-            eng = E.Engine(mesh, precision="f64", tuning=dict(pair=pair, **E.tuning_from_env()))
+        forms = [("single steps", dict(pair=0, triple=0)), ("two-step passes", dict(pair=1, triple=0)),
+                 ("three-step passes, 8-byte lanes", dict(pair=1, triple=1, triple_lanes=8)),
+                 ("three-step passes, 16-byte lanes", dict(pair=1, triple=1, triple_lanes=16)), ("engine's choice", dict())]
+        for label, form in forms:
+            eng = E.Engine(mesh, precision="f64", tuning=dict(form, **E.tuning_from_env()))
             eng.enable_kernel_timing(True)
             sig = np.zeros(4096)
             sig[0] = 1.0
             eng.set_source(E.SOURCE_HARD, src, sig)
             eng.set_receivers([src + 2])
-            steps = 200
+            steps = 210
             eng.run_steps(20)
             t0 = time.perf_counter()
             done, flag = eng.run_steps(steps)
             dt = (time.perf_counter() - t0) / steps
             assert (done, flag) == (steps, 0)
-            results[pair] = (dt, eng.read_field(E.BUF_CURRENT))
-            _, launches, timed = eng.kernel_time_detail()
+            results[label] = eng.read_field(E.BUF_CURRENT)
+            passes = (eng.query(E.Engine.QUERY_PASSES), eng.query(E.Engine.QUERY_TRIPLE_PASSES))
             visited = (eng.query(E.Engine.QUERY_MARCH_LIVE_PERMILLE), eng.query(E.Engine.QUERY_SWEEP_LIVE_PERMILLE))
             eng.close()
-            label = {0: "single steps", 1: "two-step passes", -1: "engine's choice (%s)" % ("two-step passes" if timed > launches else "single steps")}[pair]
-            print("   %-34s %.3f ms/step = %.1f Gnode-updates/s over the mesh, %.1f over the room's nodes"
-                  % (label, dt * 1e3, mesh.num_nodes / dt / 1e9, mesh.num_nodes * room / dt / 1e9), flush=True)
-        print("   fields after 220 steps identical: %s; the march visits %.1f %% of the mesh (in wave-sized pieces of rows), the sweep %.1f %% (in tiles)"
-              % (results[0][1].tobytes() == results[1][1].tobytes(), visited[0] / 10.0, visited[1] / 10.0))
+            print("   %-34s %.3f ms/step = %.1f Gnode-updates/s over the mesh, %.1f over the room's nodes  (%d two-step, %d three-step passes; its march visits %.1f %% of the mesh in wave-sized pieces of rows, the sweep %.1f %% in tiles)"
+                  % (label, dt * 1e3, mesh.num_nodes / dt / 1e9, mesh.num_nodes * room / dt / 1e9, passes[0], passes[1], visited[0] / 10.0, visited[1] / 10.0), flush=True)
+        first = results["single steps"].tobytes()
+        print("   fields after 230 steps identical in all forms: %s" % all(r.tobytes() == first for r in results.values()))
 
 
 if __name__ == "__main__":

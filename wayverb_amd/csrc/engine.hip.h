@@ -97,6 +97,7 @@ public:
     int triple_lane_bytes() const;
     bool triple_eligible();
     int ensure_triple();
+    int build_triple_units();
     int enqueue_triple(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
     // ---- engine_batch.hip.h
     bool time_this_launch();
@@ -273,6 +274,10 @@ private:
     int* suspect_ = nullptr;           // [kRing] per step slot: the march saw an inf / nan
     uint64_t triple_source_ = 0, triple_io_generation_ = ~0ull;
     bool triple_failed_ = false, triple_ready_ = false, triple_attr_set_ = false;
+    uint32_t* triple_units_ = nullptr; // sparse rooms: the three-step march's work list (build_triple_units), XCD k's run at triple_unit_start_[k]
+    uint32_t triple_unit_start_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t triple_units_longest_ = 0;
+    double triple_live_frac_ = 1.0;    // live waves of listed units / all waves of all units
     bool triple_xw_ = false;           // the passes' three levels take the x-facing walls on their compact copies (and the third-level list leaves the nodes they face out)
     // stored nodes from which the engine takes three-step passes by itself (tools/pass_forms_by_size.py, profiles/r06/pass_forms_by_size_*.txt:
     // Gnode-updates/s two-step / three-step, fp64: 256^3 212 / 216, 320^3 206 / 223, 384^3 258 / 288, 512^3 304 / 340, 768^3 326 / 396,

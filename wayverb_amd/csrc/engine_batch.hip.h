@@ -356,7 +356,10 @@ int Engine<Real>::query(int what, uint64_t* value) {
             *value = n;
             return WV_OK;
         }
-        case WV_QUERY_MARCH_LIVE_PERMILLE: *value = pair_units_ ? (uint64_t)(pair_live_frac_ * 1000.0 + 0.5) : 1000; return WV_OK;
+        // (the march that runs: a sparse room's three-step passes have a work list of their own, narrower waves and all)
+        case WV_QUERY_MARCH_LIVE_PERMILLE:
+            *value = (triple_units_ && triple_ready_) ? (uint64_t)(triple_live_frac_ * 1000.0 + 0.5) : pair_units_ ? (uint64_t)(pair_live_frac_ * 1000.0 + 0.5) : 1000;
+            return WV_OK;
         case WV_QUERY_MARCH_ROUNDS: {
             if (!pair_map_ || pair_nw_ < 1) {
                 *value = 0;

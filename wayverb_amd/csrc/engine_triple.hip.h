@@ -54,7 +54,7 @@ template <typename Real>
 int Engine<Real>::ensure_triple() {
     int rc = ensure_pair();
     if (rc) return rc;
-    if (pair_failed_ || pair_units_ || !pair_sparse_ok_) {  // (a sparse room keeps its two-step passes over live units)
+    if (pair_failed_ || (!pair_sparse_ok_ && opt_.tuning.triple < 0)) {  // (a room so sparse that the sweep's tiles beat the march's units keeps single steps)
         triple_ready_ = false;
         return WV_OK;
     }
@@ -194,6 +194,16 @@ int Engine<Real>::ensure_triple() {
     chunks = std::max(1, std::min(chunks, std::max(1, owned / 4)));
     triple_zc_ = (owned + chunks - 1) / chunks;
     triple_chunks_ = (owned + triple_zc_ - 1) / triple_zc_;
+    // a room that leaves much of its mesh outside (the two-step march runs over a work list): so does this one
+    if (triple_units_) {
+        (void)hipFree(triple_units_);
+        triple_units_ = nullptr;
+    }
+    if (pair_units_ && (rc = build_triple_units())) return rc;
+    if (pair_units_ && !triple_units_) {  // (no list to be had: two-step passes)
+        triple_ready_ = false;
+        return WV_OK;
+    }
     if (!triple_attr_set_) {
         WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -203,6 +213,151 @@ int Engine<Real>::ensure_triple() {
         triple_attr_set_ = true;
     }
     triple_ready_ = true;
+    return WV_OK;
+}
+
+// The three-step march's work list for a room that leaves much of its mesh outside, after build_pair_units (engine_pair.hip.h): a unit is a
+// strip of four rows through one chunk of planes, listed when it holds a node to update, with the waves of its row between the first and
+// the last that hold anything but `none` nodes in what it reads or hands on (its rows +- a strip, its planes +- 3).  Each XCD takes a
+// run of neighbouring strips with about the same number of units, chunk by chunk.  Sets triple_zc_ / triple_chunks_ to the units' height.
+template <typename Real>
+int Engine<Real>::build_triple_units() {
+    const int owned = z_end_ - z_begin_;
+    const int lb = triple_lb_;
+    const int WX = 64 * (lb / (int)sizeof(Real));
+    const int row_waves = pitch_ / WX;
+    if (triple_windows_ || triple_strips_ >= (1 << 14) || row_waves > 16) return WV_OK;
+    const int64_t n_cells = (int64_t)nz_ * triple_strips_;
+    ScopedDevice act_mem, raw_mem;
+    WV_HIP(hipMalloc(&act_mem.p, (size_t)n_cells));
+    WV_HIP(hipMalloc(&raw_mem.p, (size_t)n_cells * sizeof(uint16_t)));
+    wv::TileActivityArgs t{};
+    t.cls = cls_;
+    t.active = static_cast<uint8_t*>(act_mem.p);
+    t.ny = ny_;
+    t.nz = nz_;
+    t.pitch = pitch_;
+    t.cls_pitch = cls_pitch_;
+    t.tile_rows = wv::kTripleRows;
+    t.tile_cols = pitch_;
+    t.tiles_x = 1;
+    t.tiles_y = triple_strips_;
+    hipLaunchKernelGGL(wv::tile_activity_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream_, t);
+    WV_HIP(hipGetLastError());
+    static_assert(wv::kTripleRows == wv::kPairRows, "pair_wave_activity_kernel counts strips of kPairRows rows");
+    wv::WaveActivityArgs w{};
+    w.cls = cls_;
+    w.raw16 = static_cast<uint16_t*>(raw_mem.p);
+    w.ny = ny_;
+    w.nz = nz_;
+    w.pitch = pitch_;
+    w.cls_pitch = cls_pitch_;
+    w.strips = triple_strips_;
+    w.nw = row_waves;
+    w.wave_cols = WX;
+    hipLaunchKernelGGL(wv::pair_wave_activity_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream_, w);
+    WV_HIP(hipGetLastError());
+    std::vector<uint8_t> active((size_t)n_cells);
+    std::vector<uint16_t> raw((size_t)n_cells);
+    WV_HIP(hipMemcpyAsync(active.data(), act_mem.p, (size_t)n_cells, hipMemcpyDeviceToHost, stream_));
+    WV_HIP(hipMemcpyAsync(raw.data(), raw_mem.p, (size_t)n_cells * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
+    WV_HIP(hipStreamSynchronize(stream_));
+    // How many planes to a unit?  About wv_tuning::pair_unit_planes + 8 (a unit marches four warm-up planes before its first output where
+    // a two-step unit marches three), and among the heights near that the one whose units fill the chip's workgroup slots in the fewest,
+    // fullest rounds -- as build_pair_units chooses.  wv_tuning::triple_chunks > 0 sets the number of chunks instead.
+    const int per_cu = std::max(1, (lb == 16 ? 8 : 12) / std::max(1, triple_nw_));
+    const int64_t slots_per_xcd = 32ll * per_cu;
+    auto units_of = [&](int height, std::vector<uint32_t>* per_strip) -> uint64_t {
+        const int n_chunks = (owned + height - 1) / height;
+        uint64_t units = 0;
+        for (int sidx = 0; sidx < triple_strips_; ++sidx)
+            for (int c = 0; c < n_chunks; ++c) {
+                const int zb = z_begin_ + c * height, ze = std::min(zb + height, z_end_);
+                bool any = false;
+                for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
+                if (per_strip) (*per_strip)[(size_t)sidx] += any;
+                units += any;
+            }
+        return units;
+    };
+    auto rounds_cost = [&](int height) -> double {
+        std::vector<uint32_t> per_strip((size_t)triple_strips_, 0u);
+        const uint64_t units = units_of(height, &per_strip);
+        if (!units) return 0.0;
+        uint64_t longest = 0, so_far = 0, start = 0;  // the same partition into eight runs of strips as below
+        int sidx = 0;
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t want = units * (uint64_t)(k + 1) / 8;
+            while (sidx < triple_strips_ && (so_far < want || k == 7)) so_far += per_strip[(size_t)sidx++];
+            longest = std::max(longest, so_far - start);
+            start = so_far;
+        }
+        return (double)((longest + slots_per_xcd - 1) / slots_per_xcd) * (double)(height + 4);
+    };
+    int zc;
+    if (opt_.tuning.triple_chunks > 0) {
+        zc = std::max(4, (owned + opt_.tuning.triple_chunks - 1) / opt_.tuning.triple_chunks);
+    } else {
+        const int base = std::max(8, std::min(owned, opt_.tuning.pair_unit_planes + 8));
+        zc = base;
+        double best = rounds_cost(zc);
+        for (int height = base * 3 / 4; height <= base * 5 / 4; ++height) {
+            if (height < 8 || height > owned) continue;
+            const double cost = rounds_cost(height);
+            if (cost > 0 && cost < best * 0.97) {  // (only a clear win moves the height)
+                best = cost;
+                zc = height;
+            }
+        }
+    }
+    const int chunks = (owned + zc - 1) / zc;
+    if (chunks >= (1 << 9)) return WV_OK;  // (9 bits of a list entry)
+    std::vector<std::vector<uint32_t>> of_strip((size_t)triple_strips_);
+    uint64_t total = 0, live_waves = 0;
+    for (int sidx = 0; sidx < triple_strips_; ++sidx)
+        for (int c = 0; c < chunks; ++c) {
+            const int zb = z_begin_ + c * zc, ze = std::min(zb + zc, z_end_);
+            bool any = false;
+            for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
+            if (!any) continue;
+            uint32_t bits = 0;
+            for (int z = std::max(0, zb - 3); z < std::min(nz_, ze + 3); ++z)
+                for (int ss = std::max(0, sidx - 1); ss <= std::min(triple_strips_ - 1, sidx + 1); ++ss) bits |= raw[(size_t)z * triple_strips_ + ss];
+            const uint32_t lo = std::min((uint32_t)__builtin_ctz(bits | (1u << 31)), (uint32_t)row_waves - 1u);
+            const uint32_t hi = std::min(32u - (uint32_t)__builtin_clz(bits | 1u), (uint32_t)row_waves);
+            const uint32_t span = hi > lo ? hi - lo : 1u;
+            of_strip[(size_t)sidx].push_back(wv::triple_unit_entry((uint32_t)sidx, (uint32_t)c, lo, span));
+            live_waves += span;
+            ++total;
+        }
+    if (!total) return WV_OK;
+    triple_live_frac_ = (double)live_waves / ((double)triple_strips_ * chunks * row_waves);
+    std::vector<uint32_t> list;
+    list.reserve((size_t)total);
+    triple_units_longest_ = 0;
+    int sidx = 0;
+    for (int k = 0; k < 8; ++k) {
+        triple_unit_start_[k] = (uint32_t)list.size();
+        const uint64_t want = total * (uint64_t)(k + 1) / 8;  // cumulative share of XCDs 0 .. k
+        const size_t first = list.size();
+        while (sidx < triple_strips_ && (list.size() < want || k == 7)) {
+            list.insert(list.end(), of_strip[(size_t)sidx].begin(), of_strip[(size_t)sidx].end());
+            ++sidx;
+        }
+        // (chunk by chunk, the strips of a chunk side by side: what an XCD runs at one time are neighbouring strips at the same planes)
+        std::stable_sort(list.begin() + (std::ptrdiff_t)first, list.end(), [](uint32_t a, uint32_t b) { return ((a >> 14) & 0x1FFu) < ((b >> 14) & 0x1FFu); });
+        triple_units_longest_ = std::max<uint32_t>(triple_units_longest_, (uint32_t)list.size() - triple_unit_start_[k]);
+    }
+    triple_unit_start_[8] = (uint32_t)list.size();
+    uint32_t* staged = nullptr;
+    WV_HIP(hipMalloc((void**)&staged, list.size() * sizeof(uint32_t)));
+    if (hipMemcpy(staged, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(staged);
+        return fail(WV_E_HIP, "copying the three-step march's unit list to the device failed");
+    }
+    triple_units_ = staged;
+    triple_zc_ = zc;
+    triple_chunks_ = chunks;
     return WV_OK;
 }
 
@@ -258,7 +413,12 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         a.win_store_lo |= (uint64_t)triple_win_[2][k] << (8 * k);
         a.win_store_hi |= (uint64_t)triple_win_[3][k] << (8 * k);
     }
-    const unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
+    unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
+    if (triple_units_) {
+        a.unit_list = triple_units_;
+        for (int k = 0; k < 9; ++k) a.list_start[k] = triple_unit_start_[k];
+        grid = 8u * triple_units_longest_;
+    }
     // (kernel timing: the march in an account of its own -- WV_QUERY_TRIPLE_MARCH_NS -- and, every eighth timed pass, its parts)
     const bool timed = timing && time_this_launch();
     int token = timed ? begin_part_timing(4, true) : -1;

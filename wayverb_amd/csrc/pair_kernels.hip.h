@@ -558,6 +558,7 @@ struct WaveActivityArgs {
     const uint8_t* cls;
     uint8_t* raw;  // [nz][strips]: bit w = wave w's column block (128 doubles / 256 floats) of the strip's rows at plane z
     int ny, nz, pitch, cls_pitch, strips, nw, wave_cols;
+    uint16_t* raw16;  // the same with room for 16 waves (the three-step march's narrower waves); null: `raw` is written
 };
 
 __global__ void __launch_bounds__(256) pair_wave_activity_kernel(const WaveActivityArgs a) {
@@ -573,7 +574,10 @@ __global__ void __launch_bounds__(256) pair_wave_activity_kernel(const WaveActiv
                 any |= a.cls[cls_byte_index(x, y, z, a.ny, a.cls_pitch)];  // any class but CLS_NONE
             if (any) bits |= 1u << w;
         }
-    a.raw[t] = (uint8_t)bits;
+    if (a.raw16)
+        a.raw16[t] = (uint16_t)bits;
+    else
+        a.raw[t] = (uint8_t)bits;
 }
 
 }  // namespace wv

@@ -86,9 +86,21 @@ struct TripleArgs {
     // (byte k of each word belongs to window k)
     int windows;
     uint64_t win_first, win_count, win_store_lo, win_store_hi;
+    // optional work list (rooms that leave much of the mesh outside; no windows then): workgroup j of XCD k takes unit
+    // unit_list[list_start[k] + j] = strip | chunk << 14 | first wave << 23 | waves - 1 << 27 -- the waves of the row between the first
+    // and the last one that holds anything but `none` nodes in all the unit reads, produces or hands on (its rows +- a strip, its planes
+    // +- 3); what lies beyond is zeros in every field, which is what a missing neighbour counts as.  Units without a node to update are
+    // not listed: their outputs keep the zeros they hold.
+    const uint32_t* unit_list;
+    uint32_t list_start[9];
 };
 
 constexpr int kTripleMaxWindows = 8;
+
+// a work-list entry's fields
+__host__ __device__ inline uint32_t triple_unit_entry(uint32_t strip, uint32_t chunk, uint32_t wave_first, uint32_t waves) {
+    return strip | (chunk << 14) | (wave_first << 23) | ((waves - 1u) << 27);
+}
 
 // How a row of `row_waves` waves is shared out: windows of at most kTripleMaxWaves waves, one halo wave on every interior side.
 // win[0..3][k] = first wave run, waves run, first wave stored, end of the stored waves.  `full_first`: as many full workgroups (12 waves:
@@ -239,8 +251,19 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
         store_lo = (int)((a.win_store_lo >> (8 * win)) & 0xFFu);
         store_hi = (int)((a.win_store_hi >> (8 * win)) & 0xFFu);
     }
-    const int strip = xcd * a.strips_per_xcd + j % a.strips_per_xcd;
-    const int chunk = j / a.strips_per_xcd;
+    int strip, chunk;
+    if (a.unit_list) {
+        const uint32_t first = a.list_start[xcd], count = a.list_start[xcd + 1] - first;
+        if ((uint32_t)j >= count) return;  // whole workgroup
+        const uint32_t u = a.unit_list[first + (uint32_t)j];
+        strip = (int)(u & 0x3FFFu);
+        chunk = (int)((u >> 14) & 0x1FFu);
+        wave_first = (int)((u >> 23) & 0xFu);
+        row_waves = (int)(u >> 27) + 1;
+    } else {
+        strip = xcd * a.strips_per_xcd + j % a.strips_per_xcd;
+        chunk = j / a.strips_per_xcd;
+    }
     if (wave >= row_waves) return;  // (a finished wave does not hold up the barriers)
     if (strip >= a.strips || chunk >= a.chunks) return;  // whole workgroup
     const int wave_abs = wave_first + wave;
@@ -503,7 +526,12 @@ __global__ void __launch_bounds__(DENSE ? 1024 : 64 * triple_max_waves(LB)) trip
     // (which strip: as in the body)
     int j = (int)(blockIdx.x >> 3);
     if (a.windows) j %= (int)(gridDim.x >> 3) / a.windows;
-    const int strip = (int)(blockIdx.x & 7) * a.strips_per_xcd + j % a.strips_per_xcd;
+    int strip = (int)(blockIdx.x & 7) * a.strips_per_xcd + j % a.strips_per_xcd;
+    if (a.unit_list) {
+        const uint32_t first = a.list_start[blockIdx.x & 7], count = a.list_start[(blockIdx.x & 7) + 1] - first;
+        if ((uint32_t)j >= count) return;
+        strip = (int)(a.unit_list[first + (uint32_t)j] & 0x3FFFu);
+    }
     const int y0 = strip * kTripleRows;
     if (y0 < 4 || y0 + kTripleRows + 2 >= a.ny)
         triple_march_body<Real, X, true, PVDMA, LB, DENSE>(a);
