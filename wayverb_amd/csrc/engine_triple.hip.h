@@ -40,14 +40,18 @@ bool Engine<Real>::triple_eligible() {
     return true;
 }
 
-// Bytes of a row per lane of the march.  Doubles: 16 (half the instructions per byte, two waves per SIMD) where the rows are long enough
-// to give a CU its eight waves in one or two workgroups; 8 on short rows, where three workgroups of four waves hide more than three of
-// two.  Floats: 8 (the 16-byte form does not fit the register file without spills).  wv_tuning::triple_lanes forces one.
+// Bytes of a row per lane of the march.  Doubles: 16 (half the instructions per byte, two waves per SIMD) or 8 (three narrower waves per
+// SIMD, finer pieces of rows in a sparse room's work list), whichever ran faster on boxes of that row length (profiles/r06/
+// lane_width_by_size.txt; the concert hall at 1 600 Hz, 640-double rows, agrees: 390 against 374): 8 up to 256 doubles (a workgroup of
+// four waves, three of them per CU), 16 from 320, 8 again from 512 (eight to ten waves: one workgroup fills a CU), 16 from 768 (rows
+// that need windows of 8-byte lanes).  Floats: 8 (the 16-byte form does not fit the register file without spills).
+// wv_tuning::triple_lanes forces one.
 template <typename Real>
 int Engine<Real>::triple_lane_bytes() const {
     if (sizeof(Real) == 4) return 8;
     if (opt_.tuning.triple_lanes == 8 || opt_.tuning.triple_lanes == 16) return opt_.tuning.triple_lanes;
-    return pitch_ >= triple_wide_from_ ? 16 : 8;
+    if (pitch_ < triple_wide_from_) return 8;
+    return (pitch_ >= 512 && pitch_ < 768) ? 8 : 16;
 }
 
 template <typename Real>
