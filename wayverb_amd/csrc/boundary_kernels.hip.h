@@ -528,6 +528,18 @@ __device__ __forceinline__ void boundary_body(const BoundaryArgs<Real>& a, const
 
 template <typename Real, bool LDSC, bool FIX = false, int XW3 = 0>
 __global__ void __launch_bounds__(256) boundary_kernel(const BoundaryArgs<Real> a, const PrePostArgs<Real> next) {
+    if (next.fused) {
+        // the source / receiver work that rides here has a workgroup of its own, the grid's FIRST (launch_boundary adds it): a chain of
+        // some eight dependent memory round trips -- sample, node, fence, the short list's neighbours -- that starts with the launch and
+        // runs beside the boundary workgroups, instead of behind the last of them (10 us of a 25 us launch at 256^3)
+        if (blockIdx.x == 0) {
+            pre_post_body<Real>(next, threadIdx.x, 256);
+            return;
+        }
+        PrePostArgs<Real> none{};
+        boundary_body<Real, LDSC, FIX, XW3>(a, none, blockIdx.x - 1, gridDim.x - 1);
+        return;
+    }
     boundary_body<Real, LDSC, FIX, XW3>(a, next, blockIdx.x, gridDim.x);
 }
 

@@ -190,7 +190,7 @@ int Engine<Real>::launch_boundary(Real* prev, const Real* cur, int* flag, int z0
         plan_only->lds = lds;
         return WV_OK;
     }
-    const dim3 grid((n + 255) / 256), block(256);
+    const dim3 grid((n + 255) / 256 + (nx.fused ? 1u : 0u)), block(256);  // (+ 1: the riding source / receiver work's own workgroup)
     if (xw && xw3) {
         if (lds && xw3 == 1)
             hipLaunchKernelGGL((wv::boundary_kernel<Real, true, false, 1>), grid, block, 0, st(), b, nx);
