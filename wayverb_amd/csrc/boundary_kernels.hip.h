@@ -354,9 +354,14 @@ __device__ __forceinline__ void xwall_node(const BoundaryArgs<Real>& a, const do
 //                                        --L2-->  xw_f2 = t+2 (computed here, as in a two-step pass)   --L3-->  xw_f = t+3 (computed here)
 //   level 1 (t-1, t -> t+1)    reads one line of the t+1 field (the march's shell values), writes its own t+1 into it
 //   level 2 (t, t+1 -> t+2)    reads no field; writes its own and the faced node's t+2 (one line)
-//   level 3 (t+1, t+2 -> t+3)  reads the node behind the faced one at t+2 from its own line of the t+2 field; writes its own and the faced
-//                              node's t+3 (one line) -- the faced nodes of these entries are not on the third level's list
-// (the node behind the faced one gets its t+3 from that list: its lateral neighbours at t+2 are four more lines.)
+//   level 3 (t+1, t+2 -> t+3)  reads no field; writes its own, the faced node's AND the t+3 of the node behind that one (one line) -- none
+//                              of these nodes is on the third level's list, where each node two columns from an x-facing wall cost six lines
+//                              (1.56 GB per launch of that list at 1024^3 for 0.3 GB of values)
+// The node behind the faced one (xw_gok: a plain node whose six neighbours are plain, the one behind it neither a boundary node nor finished
+// by one -- its t+2 is the march's or the second level's list's, final before level 2 runs): level 2 captures its t+2 and that of the node
+// behind it from their line of the t+2 field (xw_g2 / xw_h2); level 3 gives it its update from the faced node's fresh t+2 (xw_f2), xw_h2,
+// the lateral neighbours' xw_g2 and its own t+1 (xw_g).  Where xw_gok is 0 level 3 reads that node from the t+2 field as before and the
+// list keeps it.
 // a.prev / a.cur / a.next are the fields at the levels boundary_node would read and write; rim entries fall back to them as in xwall_node.
 template <typename Real, int LEVEL>
 __device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const double* coeffs, uint32_t pos_e, int& bad) {
@@ -378,11 +383,19 @@ __device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const d
     const Real* const own_prev = LEVEL == 1 ? a.xw_a : (LEVEL == 2 ? a.xw_b : a.xw_o2);  // ... one level back: this node's own old value
     Real* const own_out = LEVEL == 1 ? a.xw_o2 : (LEVEL == 2 ? a.xw_a : a.xw_b);
     const Real* const f_nb = LEVEL == 1 ? a.xw_f : (LEVEL == 2 ? a.xw_f1 : a.xw_f2);     // the faced node at the neighbours' level
+    const int64_t gn = fn + (far_off ? 0 : step);  // the node behind the faced one (the faced one itself if that is off the grid)
+    const bool h_off = far_off || x + 3 * step < 0 || x + 3 * step >= a.nx;
+    const bool gok = LEVEL != 1 && a.xw_gok[pos_e] != 0;
 
     // ---- loads -----------------------------------------------------------------------------------
     uint32_t ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ref[k] = a.xw_nbr[(size_t)k * a.xw_n + pos_e];
+    Real g2c = 0, h2c = 0;  // level 2: t+2 of that node and of the one behind it (a.next: nobody writes them in this launch where gok)
+    if (LEVEL == 2) {
+        g2c = a.next[gn];
+        h2c = a.next[gn + (h_off ? 0 : step)];
+    }
     Real nb[3][2];
     bool off[3][2];
     off[0][0] = x - 1 < 0;
@@ -415,7 +428,8 @@ __device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const d
         far1 = far_off ? Real(0) : far1;
     } else {
         const Real own_at = own_nb[pos_e];  // this node's own value at the neighbours' level
-        Real far = LEVEL == 2 ? a.xw_g[pos_e] : a.cur[fn + (far_off ? 0 : step)];
+        // (level 3: from level 2's capture where there is one -- no field line --, else from the t+2 field)
+        Real far = LEVEL == 2 ? a.xw_g[pos_e] : *(gok ? a.xw_g2 + pos_e : a.cur + gn);
         far = (LEVEL == 3 && far_off) ? Real(0) : far;
         fnb[0][0] = step > 0 ? own_at : far;
         fnb[0][1] = step > 0 ? far : own_at;
@@ -428,6 +442,32 @@ __device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const d
             any_lateral_field = any_lateral_field || (!regular && !off[ax][s]);
         }
         fprev = LEVEL == 2 ? a.xw_f[pos_e] : a.xw_f1[pos_e];
+    }
+    // level 3: the node behind the faced one, from copies alone where its lateral neighbours are such nodes of neighbouring entries
+    Real gnb[3][2], gprev = 0;
+    uint32_t g_from_field = 0;
+    if (LEVEL == 3) {
+        const Real f2 = nb[0][0], h2 = a.xw_h2[pos_e];
+        gnb[0][0] = step > 0 ? f2 : h2;
+        gnb[0][1] = step > 0 ? h2 : f2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = 1 + (k >> 1), s = k & 1;
+            const bool regular = ref[k] != XW_FIELD && (ref[k] & XW_SAME_FACING);
+            const uint32_t other = regular ? (ref[k] & ~XW_SAME_FACING) : pos_e;
+            const bool copy = regular && a.xw_gok[other] != 0;
+            const Real v = a.xw_g2[other];
+            gnb[ax][s] = off[ax][s] ? Real(0) : v;
+            if (!copy && !off[ax][s]) g_from_field |= 1u << k;
+        }
+        gprev = a.xw_g[pos_e];
+        if (gok && g_from_field) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ax = 1 + (k >> 1), s = k & 1;
+                if ((g_from_field >> k) & 1u) gnb[ax][s] = a.cur[gn + (s ? stride[ax] : -stride[ax])];
+            }
+        }
     }
     // the wall's rim, walls that meet other things than walls: those neighbours come from the fields
     if (any_field) {
@@ -461,6 +501,16 @@ __device__ __forceinline__ void xwall3_node(const BoundaryArgs<Real>& a, const d
         bad |= bad_bits(sf);
         a.next[fn] = sf;
         (LEVEL == 2 ? a.xw_f2 : a.xw_f)[pos_e] = sf;
+        if (LEVEL == 2) {
+            a.xw_g2[pos_e] = g2c;
+            a.xw_h2[pos_e] = h_off ? Real(0) : h2c;
+        } else {
+            const Real sg = faced_value<Real>(gnb, gprev);
+            if (gok) {
+                bad |= bad_bits(sg);
+                a.next[gn] = sg;
+            }
+        }
     }
 }
 
@@ -550,12 +600,30 @@ struct XwCoverArgs {
     const uint8_t* btype;
     uint32_t* covered;  // bitmap over stored node indices
     uint32_t xw_n;
+    // the node behind the faced one: xwall3_node's xw_gok (see there) -- and covered too where that says yes
+    const uint8_t* pair_map;
+    uint8_t* gok;
+    int nx, ny, nz, pitch, cls_pitch;
 };
 __global__ void __launch_bounds__(256) xwall_cover_kernel(const XwCoverArgs a) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.xw_n) return;
-    const uint32_t fn = a.bnode[p] + ((a.btype[p] & 2u) ? 1u : 0xFFFFFFFFu);
+    const uint32_t idx = a.bnode[p];
+    const int step = (a.btype[p] & 2u) ? 1 : -1;
+    const uint32_t fn = idx + (uint32_t)step;
     atomicOr(a.covered + (fn >> 5), 1u << (fn & 31u));
+    const int x = (int)(idx % (uint32_t)a.pitch);
+    const uint32_t q = idx / (uint32_t)a.pitch;
+    const int y = (int)(q % (uint32_t)a.ny), z = (int)(q / (uint32_t)a.ny);
+    auto code_at = [&](int xx) -> uint32_t { return (a.pair_map[cls_byte_index(xx, y, z, a.ny, a.cls_pitch)] >> ((xx & 3) * 2)) & 3u; };
+    const int xg = x + 2 * step, xh = x + 3 * step;
+    bool ok = xg >= 0 && xg < a.nx && code_at(xg) == 1u;  // plain, and so are its six neighbours: its t+2 is the march's
+    if (ok && xh >= 0 && xh < a.nx) ok = code_at(xh) != 2u && code_at(xh) != 3u;  // (3: its t+2 may be a boundary entry's, in level 2's own launch)
+    a.gok[p] = ok ? 1 : 0;
+    if (ok) {
+        const uint32_t gn = idx + (uint32_t)(2 * step);
+        atomicOr(a.covered + (gn >> 5), 1u << (gn & 31u));
+    }
 }
 
 // Which 1-D entries may live on compact copies (xwall_node): facing along x, in the planes the march produces, the

@@ -152,6 +152,10 @@ struct BoundaryArgs {
     // ... and in three-step passes (xwall3_node): two more generations, the wall node's own value at a third time level and the faced
     // node at t+2
     Real *xw_o2, *xw_f2;
+    // ... and for the node BEHIND the faced one, which such an entry finishes at the third level too where xw_gok says it may (a plain
+    // node among plain nodes: xwall_cover_kernel): that node and the one behind it at t+2, captured by level 2
+    Real *xw_g2, *xw_h2;
+    const uint8_t* xw_gok;
 };
 
 template <typename Real>

@@ -119,6 +119,7 @@ public:
     bool io_nodes_plain();
     bool io_nodes(std::vector<uint64_t>* stored);
     bool io_nodes_unfaced();
+    bool io_nodes_clear_of_x_walls();
     int fetch_receivers(uint64_t first, uint64_t n, double* dst) override;
     Real* buffer(int which) { return which == WV_BUF_CURRENT ? field_[cur_] : field_[prv_]; }
     hipError_t class_of(uint64_t x, uint64_t row, uint32_t* cls);
@@ -215,6 +216,7 @@ private:
     bool batch_can_fuse_ = false, batch_source_live_ = false;  // plan_batch's decisions for the batch being enqueued
     bool io_plain_known_ = false, io_plain_ = false;
     bool io_unfaced_known_ = false, io_unfaced_ = false;
+    bool io_xclear_known_ = false, io_xclear_ = false;  // io_nodes_clear_of_x_walls
     bool duties_known_ = false, duties_ok_ = false;  // whole_step_ready
     wv::StepDuty* duties_ = nullptr;                  // [n_duties_] the source first, then the recorded receivers
     uint32_t n_duties_ = 0;
@@ -261,7 +263,8 @@ private:
     // x-facing walls on compact copies in two-step passes (boundary_kernels.hip.h, xwall_node; engine_pair.hip.h)
     uint32_t n_xw_ = 0;            // the first n_xw_ entries qualify (settled with the entry order in init)
     uint32_t* xw_nbr_ = nullptr;   // [4][n_xw_] in-wall neighbours by entry position
-    Real* xw_val_ = nullptr;       // [7][n_xw_]: own value at the odd / even level, faced node, level 1's captures; a three-step pass's third generations
+    Real* xw_val_ = nullptr;       // [9][n_xw_]: own value at the odd / even level, faced node, level 1's captures; a three-step pass's third generations and level 2's captures
+    uint8_t* xw_gok_ = nullptr;    // [n_xw_]: the entry finishes the node behind the one it faces at a three-step pass's third level (xwall_cover_kernel)
     bool xw_built_ = false;        // table and copies allocated (first ensure_pair that may use them)
     bool xw_active_ = false;       // this (mesh, source) runs its passes on them
     bool xw_valid_ = false;        // the copies hold what the fields hold

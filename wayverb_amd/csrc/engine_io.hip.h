@@ -33,7 +33,7 @@ int Engine<Real>::set_source(int kind, uint64_t node, const double* signal, uint
     signal_len_ = kind == WV_SOURCE_NONE ? 0 : n;
     signal_pos_ = 0;
     io_plain_known_ = false;
-    io_unfaced_known_ = false;
+    io_unfaced_known_ = io_xclear_known_ = false;
     duties_known_ = false;
     ++io_generation_;
     if (kind == WV_SOURCE_NONE) return WV_OK;
@@ -74,7 +74,7 @@ int Engine<Real>::set_receivers(const uint64_t* nodes, uint32_t n) {
     recv_first_step_ = steps_done;
     n_recv_ = n;
     io_plain_known_ = false;
-    io_unfaced_known_ = false;
+    io_unfaced_known_ = io_xclear_known_ = false;
     duties_known_ = false;
     ++io_generation_;
     return WV_OK;
@@ -135,6 +135,29 @@ bool Engine<Real>::io_nodes_unfaced() {
         }
     }
     io_unfaced_ = true;
+    return true;
+}
+
+// true when, besides, none of them lies within two nodes of a boundary node along x: in a three-step pass the entries of x-facing walls
+// finish the node they face and the one behind it at t+3 (xwall3_node), in the launch the next step's source / receiver work would ride in
+template <typename Real>
+bool Engine<Real>::io_nodes_clear_of_x_walls() {
+    if (!io_nodes_unfaced()) return false;
+    if (io_xclear_known_) return io_xclear_;
+    io_xclear_known_ = true;
+    io_xclear_ = false;
+    std::vector<uint64_t> stored;
+    if (!io_nodes(&stored)) return false;
+    for (uint64_t idx : stored) {
+        const int64_t x = (int64_t)(idx % (uint64_t)pitch_), row = (int64_t)(idx / (uint64_t)pitch_);
+        for (int64_t dx = -2; dx <= 2; ++dx) {
+            if (dx == 0 || x + dx < 0 || x + dx >= pitch_) continue;
+            uint32_t cls = 0;
+            if (class_of((uint64_t)(x + dx), (uint64_t)row, &cls) != hipSuccess) return false;
+            if (cls == wv::CLS_BOUNDARY) return false;
+        }
+    }
+    io_xclear_ = true;
     return true;
 }
 

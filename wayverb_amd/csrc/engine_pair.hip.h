@@ -478,8 +478,10 @@ int Engine<Real>::build_xwall() {
     }
     WV_HIP(hipMalloc((void**)&xw_nbr_, nbr.size() * sizeof(uint32_t)));
     WV_HIP(hipMemcpy(xw_nbr_, nbr.data(), nbr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    WV_HIP(hipMalloc((void**)&xw_val_, (size_t)7 * n * sizeof(Real)));
-    WV_HIP(hipMemsetAsync(xw_val_, 0, (size_t)7 * n * sizeof(Real), stream_));
+    WV_HIP(hipMalloc((void**)&xw_val_, (size_t)9 * n * sizeof(Real)));
+    WV_HIP(hipMemsetAsync(xw_val_, 0, (size_t)9 * n * sizeof(Real), stream_));
+    WV_HIP(hipMalloc((void**)&xw_gok_, (size_t)n));
+    WV_HIP(hipMemsetAsync(xw_gok_, 0, (size_t)n, stream_));
     xw_built_ = true;
     xw_valid_ = false;
     return WV_OK;
@@ -497,6 +499,9 @@ void Engine<Real>::xwall_args(wv::BoundaryArgs<Real>& b) const {
     b.xw_g = xw_val_ + (size_t)4 * n_xw_;
     b.xw_o2 = xw_val_ + (size_t)5 * n_xw_;
     b.xw_f2 = xw_val_ + (size_t)6 * n_xw_;
+    b.xw_g2 = xw_val_ + (size_t)7 * n_xw_;
+    b.xw_h2 = xw_val_ + (size_t)8 * n_xw_;
+    b.xw_gok = xw_gok_;
 }
 
 template <typename Real>

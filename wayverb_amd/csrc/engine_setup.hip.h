@@ -558,7 +558,7 @@ void Engine<Real>::release() {
     for (auto& f : ckpt_.field)
         if (f) (void)hipFree(f);
     if (ckpt_.fmem) (void)hipFree(ckpt_.fmem);
-    void* ptrs[] = {field1_, triple_map_, triple_list_, triple_units_, suspect_, pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, xw_nbr_, xw_val_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
+    void* ptrs[] = {field1_, triple_map_, triple_list_, triple_units_, suspect_, pair_units_, pair_map_, pair_list_, pair_counter_, signal_base_dev_, tile_list_, xw_nbr_, xw_val_, xw_gok_, ref_to_pos_, cls_,   bnode_,      btype_,    fmem_,  cidx_,
                     status_,          coeffs_,    flags_,      scratch_, signal_, recv_nodes_, recv_out_, zorder_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -114,6 +114,13 @@ int Engine<Real>::ensure_triple() {
         c.btype = btype_;
         c.covered = static_cast<uint32_t*>(covered.p);
         c.xw_n = n_xw_;
+        c.pair_map = pair_map_;
+        c.gok = xw_gok_;
+        c.nx = nx_;
+        c.ny = ny_;
+        c.nz = nz_;
+        c.pitch = pitch_;
+        c.cls_pitch = cls_pitch_;
         hipLaunchKernelGGL(wv::xwall_cover_kernel, dim3((n_xw_ + 255) / 256), dim3(256), 0, stream_, c);
         WV_HIP(hipGetLastError());
         m.covered = c.covered;
@@ -525,9 +532,9 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     }
     if ((rc = end_part_timing(3, token))) return rc;
     token = begin_part_timing(2);
-    if (fuse && fuse_next && (!xw || io_nodes_unfaced())) {
+    if (fuse && fuse_next && (!xw || io_nodes_clear_of_x_walls())) {
         // what follows reads its source / receiver nodes from the t+3 field: none of them is a boundary node (nor, with the x-facing walls
-        // on their copies, a node one of those entries finishes)
+        // on their copies, one of the two nodes such an entry finishes)
         wv::PrePostArgs<Real> nx = pre_post_args(O3, slot + 3, true, signal_pos + 3, source_live);
         if (fuse_next == 2) nx.flag2 = flags_ + slot + 4;
         if ((rc = launch_boundary(O1, O2, flag3, z_begin_, z_end_, &nx, O3, false, false, nullptr, xw ? 3 : 0))) return rc;
