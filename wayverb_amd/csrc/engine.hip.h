@@ -283,9 +283,10 @@ private:
     double triple_live_frac_ = 1.0;    // live waves of listed units / all waves of all units
     bool triple_xw_ = false;           // the passes' three levels take the x-facing walls on their compact copies (and the third-level list leaves the nodes they face out)
     // stored nodes from which the engine takes three-step passes by itself (tools/pass_forms_by_size.py, profiles/r06/pass_forms_by_size_*.txt:
-    // Gnode-updates/s two-step / three-step, fp64: 256^3 212 / 216, 320^3 206 / 223, 384^3 258 / 288, 512^3 304 / 340, 768^3 326 / 396,
-    // 1024^3 355 / 421 -- 256^3 with 8-byte lanes and the pass's launches fused: 211 / 234; fp32 (8-byte lanes: twice the instructions per byte): 384^3 364 / 375, 512^3 522 / 549, 768^3 577 / 532, 1024^3 660 / 693)
-    uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (12ull << 20) : (900ull << 20);
+    // Gnode-updates/s two-step / three-step at the end of round 6, fp64: 224^3 187 / 200, 256^3 213 / 243, 320^3 214 / 255, 384^3 267 / 321,
+    // 512^3 286 / 362, 768^3 326 / 416, 1024^3 338 / 443; fp32: 384^3 352 / 421, 512^3 487 / 587, 640^3 460 / 484, 768^3 557 / 590,
+    // 896^3 536 / 649, 1024^3 626 / 765 -- wherever two-step passes run at all in fp64; in fp32 from the first size measured)
+    uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (12ull << 20) : (24ull << 20);
     int triple_nw_ = 1, triple_strips_ = 0, triple_zc_ = 0, triple_chunks_ = 1, triple_windows_ = 0;
     uint8_t triple_win_[4][wv::kTripleMaxWindows] = {};
     int triple_lb_ = 8;                // bytes of a row per lane of the march as set up (triple_lane_bytes)
