@@ -137,6 +137,7 @@ def main():
             bd[d].append(e.read_boundary_data(d + 1))
     detail = [e.kernel_time_detail() for e in engines]
     early_passes = [int(e.query(E.Engine.QUERY_EARLY_PASSES)) for e in engines]
+    three_step = [int(e.query(E.Engine.QUERY_TRIPLE_PASSES)) for e in engines]
     for e in engines:
         e.close()
     if trace.tobytes() != want["trace"].tobytes():
@@ -157,7 +158,7 @@ def main():
         print("FAILED", problems)
         sys.exit(4)
     two_step = all(steps_ > launches for _, launches, steps_ in detail if launches)
-    print("OK steps %d flag %d two_step_passes %s early_passes %s" % (want_done, want_flag, two_step, early_passes))
+    print("OK steps %d flag %d two_step_passes %s early_passes %s three_step_passes %s" % (want_done, want_flag, two_step, early_passes, three_step))
 
 
 if __name__ == "__main__":

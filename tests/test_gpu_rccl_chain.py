@@ -34,8 +34,10 @@ def shm_mock(tmp_path_factory, built_library):
     return str(d / "libwvmockrccl.so")
 
 
-def run_worker(mock_dir, *args, pair=None, timeout=300, extra=()):
+def run_worker(mock_dir, *args, pair=None, timeout=300, extra=(), hw_queues=None):
     env = dict(os.environ)
+    if hw_queues:
+        env["GPU_MAX_HW_QUEUES"] = str(hw_queues)
     if mock_dir:
         env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env["WV_NO_TORCH_PRELOAD"] = "1"   # torch would bring the real librccl (same soname) into the process
@@ -55,6 +57,30 @@ def test_chain_of_ranks_over_the_rccl_path_equals_the_single_domain(mock_dir, wo
     planes = dims[2] // world
     if pair and planes >= 4:
         assert "two_step_passes True" in last, last
+
+
+THREE = "--tuning=triple=1,tile_lists=0,slab_early=1"
+
+
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+@pytest.mark.parametrize("world,room,dims,precision,source_plane", [(2, "box", (20, 18, 24), "f64", 15), (3, "L", (28, 24, 30), "f64", 14),
+                                                                    (4, "blob", (30, 26, 33), "f32", 3), (5, "box", (140, 12, 40), "f64", 20),
+                                                                    (2, "box", (300, 10, 17), "f32", 4)])
+def test_three_step_passes_of_a_chain_of_ranks(mock_dir, world, room, dims, precision, source_plane, transport):
+    """Three-step passes on the chain's own code path (comm.cpp: grouped send / receive, or copies into IPC-mapped fields with mailbox
+    flags): three exchanges per pass, the t+1 faces by way of the t+3 field's face planes.  The source inside a slab; every rank must
+    take the passes (a box: 27 steps = 2 single sweeps for the written fields + 8 passes + 1 step), and equal the single domain."""
+    # (ipc, ranks as threads of one process: a rank's wait must not sit in front of the neighbour's copy in one hardware queue)
+    last = run_worker(mock_dir, world, room, *dims, precision, 27, 500 + world, pair=1, hw_queues=2 * world + 2 if transport == "ipc" else None,
+                      extra=[THREE, "--source-plane=%d" % source_plane, "--transport=" + transport])
+    if room == "box":
+        assert "three_step_passes %s" % ([8] * world) in last, last
+
+
+def test_a_non_finite_value_inside_a_three_step_pass_stops_every_rank_at_that_step(mock_dir):
+    for bad in (16, 17, 18):
+        last = run_worker(mock_dir, 3, "box", 18, 16, 27, "f64", 40, 7, bad, pair=1, extra=[THREE, "--source-plane=12"])
+        assert last.startswith("OK steps %d " % bad) and " flag 0 " not in last, last
 
 
 @pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])

@@ -14,7 +14,7 @@ from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes", "two-step-passes-round-3-order"])
+@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes", "two-step-passes-round-3-order", "three-step-passes"])
 def _step_mode(request):
     """Every test of this file runs three times: with the engine's default choice (single steps on meshes this
     small); with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
@@ -22,11 +22,15 @@ def _step_mode(request):
     faces' second step on the halo stream (round 4); and with passes in the order of round 3 (wv_tuning::slab_early = 0:
     the second exchange after the march, and the planes around the exchanges in two launches, sweep then boundary nodes:
     wv_tuning::fuse_planes = 0), which is also what a slab with a source within two planes of a cut falls back to.  Slabs with
-    fewer than four planes cannot take two-step passes, and then the whole chain falls back together."""
+    fewer than four planes cannot take two-step passes, and then the whole chain falls back together.
+    A fourth time with three-step passes forced on (wv_tuning::triple = 1: engine_triple.hip.h, enqueue_triple_slab -- three exchanges per
+    pass, the face planes and the planes next to them by plain steps); slabs of fewer than six planes, a source on a slab face or a room
+    that marches a work list keep the chain on two-step passes."""
     old = dict(E.default_tuning)
-    E.default_tuning.pop("pair", None)
-    E.default_tuning.pop("slab_early", None)
-    E.default_tuning.pop("fuse_planes", None)
+    for key in ("pair", "slab_early", "fuse_planes", "triple", "tile_lists"):
+        E.default_tuning.pop(key, None)
+    if request.param == "three-step-passes":
+        E.default_tuning.update(pair=1, triple=1, slab_early=1, tile_lists=0)
     if request.param.startswith("two-step-passes"):
         E.default_tuning["pair"] = 1
         E.default_tuning["slab_early"] = 1      # (forced: by default slabs that share a device keep round 3's order)
@@ -108,7 +112,8 @@ def slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, recei
         prev.append(e.read_field(E.BUF_PREVIOUS)[lo:hi])
         for d in range(3):
             bd[d].append(e.read_boundary_data(d + 1))
-    queries = ([e.query(E.Engine.QUERY_PASSES) for e in engines], [e.query(E.Engine.QUERY_EARLY_PASSES) for e in engines])
+    queries = ([e.query(E.Engine.QUERY_PASSES) for e in engines], [e.query(E.Engine.QUERY_EARLY_PASSES) for e in engines],
+               [e.query(E.Engine.QUERY_TRIPLE_PASSES) for e in engines])
     group.close()
     return dict(done=done, flag=flag, trace=trace, ghost_trace=ghost_trace, cur=np.concatenate(cur), detail=detail,
                 prev=np.concatenate(prev), bd=[np.concatenate(b) for b in bd], queries=queries)
@@ -225,6 +230,41 @@ def test_exhausted_source_ends_a_chain(built_library):
     group.close()
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("world,room,dims,steps", [(2, "box", (24, 20, 20), 23), (3, "box", (40, 36, 33), 24), (4, "box", (130, 12, 40), 25),
+                                                   (2, "L", (20, 18, 24), 23), (3, "blob", (24, 22, 30), 24), (2, "box", (1200, 9, 16), 22),
+                                                   (5, "box", (300, 13, 61), 20)])
+def test_three_step_passes_on_slab_chains(built_library, world, room, dims, steps, precision, _step_mode):
+    """Slabs thick enough for three-step passes, the source inside a slab (not on a face), receivers on faces, next to them, in ghost
+    planes and in mid-slab: with three-step passes forced on every slab takes them -- two single sweeps for the written fields, then
+    passes of three, then what the step count leaves -- and the chain equals the single domain bit for bit in every mode."""
+    rng = np.random.default_rng(3000 + world + dims[0])
+    gmesh = global_mesh(dims, room, rng)
+    dtype = np.float32 if precision == "f32" else np.float64
+    live = gmesh.nodes["boundary_type"] != 0
+    gprev = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    gcur = np.where(live, rng.uniform(-0.25, 0.25, gmesh.num_nodes), 0.0).astype(dtype)
+    signal = rng.uniform(-0.1, 0.1, steps)
+    inside = (gmesh.nodes["boundary_type"] & M.ID_INSIDE) != 0
+    L0, L1 = SlabLayout(dims, 0, world), SlabLayout(dims, 1, world)
+
+    def an_inside_node(z, k=2):
+        idx = np.nonzero(inside[z * L0.plane:(z + 1) * L0.plane])[0]
+        return int(z * L0.plane + idx[len(idx) // k])
+    source = an_inside_node(L1.z0 + 3)                       # three planes into slab 1
+    centre = an_inside_node(L1.z0)                            # a directional receiver's seven nodes around slab 1's bottom face
+    receivers = [centre] + [n for n in gmesh.compute_neighbors(centre)]
+    assert all(n != 0xFFFFFFFF for n in receivers)
+    receivers += [an_inside_node(L0.z1 - 2, 3), an_inside_node(L0.z1 - 3, 3), an_inside_node(L1.z0 + 1, 3), an_inside_node(L1.z0 + 2, 3)]
+    for kind in (E.SOURCE_SOFT, E.SOURCE_HARD):
+        want = single_domain(gmesh, precision, gprev, gcur, kind, source, signal, receivers, steps)
+        got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps, ghost_readers=range(7))
+        assert want["done"] == steps and want["flag"] == 0
+        assert_same(got, want, gmesh)
+        if _step_mode == "three-step-passes" and room == "box":
+            assert all(t == (steps - 2) // 3 for t in got["queries"][2]), got["queries"]
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_slab_chains_equal_the_single_domain(built_library, seed, _step_mode):
     """Seeded random chains: 2-7 slabs of unequal thickness (down to one plane, where the whole chain falls back to
@@ -300,7 +340,8 @@ def test_a_slab_with_a_neighbour_elsewhere_marches_in_two_rounds(_step_mode):
     engines = []
     for r in range(2):
         L = SlabLayout((n, n, nz), r, 2)
-        engines.append(E.Engine(box_slab_mesh(n, n, nz, L, coefficients=coeffs), precision="f64", ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi))
+        engines.append(E.Engine(box_slab_mesh(n, n, nz, L, coefficients=coeffs), precision="f64", ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi,
+                                tuning=dict(triple=0)))                   # (the two-step march's rounds: slabs this big take three-step passes by themselves)
     group = E.LocalSlabGroup(engines)
     try:
         assert all(e.query(E.Engine.QUERY_MARCH_ROUNDS) == 0 for e in engines)      # nothing planned yet
@@ -314,7 +355,7 @@ def test_a_slab_with_a_neighbour_elsewhere_marches_in_two_rounds(_step_mode):
         zl0, zl1, z0, z1 = 0, nz // 2, 0, nz // 2
         local_dims = (n, n, nz // 2)
         plane = n * n
-    single = E.Engine(box_slab_mesh(n, n, nz // 2, Whole, coefficients=coeffs), precision="f64")
+    single = E.Engine(box_slab_mesh(n, n, nz // 2, Whole, coefficients=coeffs), precision="f64", tuning=dict(triple=0))
     try:
         assert single.run_steps(4) == (4, 0)
         assert single.query(E.Engine.QUERY_MARCH_ROUNDS) == 1
@@ -323,7 +364,7 @@ def test_a_slab_with_a_neighbour_elsewhere_marches_in_two_rounds(_step_mode):
     # a middle rank over RCCL (its own neighbour on both sides): two rounds
     nodes, counts = E.make_box_nodes(n, n, 8 * 64, z_begin=3 * 64 - 1, z_count=66, number_from=3 * 64, number_to=4 * 64)
     bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1) for d in range(3)]
-    rank = E.Engine(M.Mesh((n, n, 66), nodes, coeffs, *bidx), precision="f64", ghost_lo=True, ghost_hi=True)
+    rank = E.Engine(M.Mesh((n, n, 66), nodes, coeffs, *bidx), precision="f64", ghost_lo=True, ghost_hi=True, tuning=dict(triple=0))
     try:
         rank.comm_init(E.Engine.comm_unique_id(), 0, 1)
         assert rank.run_steps(4) == (4, 0)
@@ -389,7 +430,7 @@ def test_sources_around_a_cut_and_which_slabs_keep_the_older_order(built_library
         got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps)
         assert want["done"] == steps and want["flag"] == 0
         assert_same(got, want, gmesh)
-        passes, early = got["queries"]
+        passes, early, _ = got["queries"]
         if _step_mode == "two-step-passes":
             assert all(p == (steps - 2) // 2 for p in passes), passes
             if E.default_tuning.get("slab_early", -1) == 0:

@@ -89,6 +89,8 @@ public:
     int batch_pair_eligible(int* eligible) override;
     int batch_pair_prepare(int* ready, int* singles_first) override;
     int batch_pair_vetoed() override;
+    int batch_triple_prepare(int* ready) override;
+    int enqueue_batch_triple(uint64_t i, int part) override;
     uint64_t role_signature() const override {
         return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
     }
@@ -99,6 +101,9 @@ public:
     int ensure_triple();
     int build_triple_units();
     int enqueue_triple(int slot, uint64_t signal_pos, bool source_live, int fuse_next);
+    int enqueue_triple_slab(int slot, int part, uint64_t signal_pos, bool source_live);
+    int launch_triple_march(int slot, const Real* A, const Real* B, Real* O1, Real* O2, Real* O3);
+    int launch_triple_list(int slot, const Real* A, const Real* B, const Real* O1, const Real* O2, Real* O3, bool source_live);
     // ---- engine_batch.hip.h
     bool time_this_launch();
     int drain_timing();
@@ -287,6 +292,7 @@ private:
     // 512^3 286 / 362, 768^3 326 / 416, 1024^3 338 / 443; fp32: 384^3 352 / 421, 512^3 487 / 587, 640^3 460 / 484, 768^3 557 / 590,
     // 896^3 536 / 649, 1024^3 626 / 765 -- wherever two-step passes run at all in fp64; in fp32 from the first size measured)
     uint64_t triple_min_nodes_ = sizeof(Real) == 8 ? (12ull << 20) : (24ull << 20);
+    int triple_z0_ = 0, triple_z1_ = 0;  // the planes the march produces: the owned ones, less the face plane and the plane next to it where a neighbour follows
     int triple_nw_ = 1, triple_strips_ = 0, triple_zc_ = 0, triple_chunks_ = 1, triple_windows_ = 0;
     uint8_t triple_win_[4][wv::kTripleMaxWindows] = {};
     int triple_lb_ = 8;                // bytes of a row per lane of the march as set up (triple_lane_bytes)

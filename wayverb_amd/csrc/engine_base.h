@@ -112,6 +112,10 @@ struct wv_engine {
     virtual int batch_pair_eligible(int* eligible) = 0;
     virtual int batch_pair_prepare(int* ready, int* singles_first) = 0;
     virtual int batch_pair_vetoed() = 0;  // the chain stays with single steps: the spare fields go back
+    // three-step passes (engine_triple.hip.h): *ready = this engine can take them in the batch being planned (everything allocated and built);
+    // a pass of a slab is enqueued in three parts, each part of every slab of an in-process chain before the next part of any
+    virtual int batch_triple_prepare(int* ready) = 0;
+    virtual int enqueue_batch_triple(uint64_t i, int part) = 0;
     virtual uint64_t role_signature() const = 0;  // which field buffer plays which role, and after how many steps
     virtual int collect_batch(uint64_t batch) = 0;
     virtual const int* batch_flags() const = 0;

@@ -285,12 +285,21 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             // ... and three steps per pass wherever it has three left (one domain, a room that fills its mesh: engine_triple.hip.h).
             // The passes do not reset flag words one by one: the whole batch's are set here.
             bool triples = false;
-            if (pairs && !chain && batch >= (uint64_t)singles_first + 3 && triple_eligible()) {
-                if ((rc = ensure_triple())) return rc;
-                triples = triple_ready_;
-                if (triples) {
+            if (pairs && batch >= (uint64_t)singles_first + 3) {
+                int mine = 0;
+                const int prepared = batch_triple_prepare(&mine);
+                if (prepared && !chain) return prepared;
+                if (chain) {  // (every rank's consent, and a rank that failed goes into the all-reduce with the others: as above)
+                    uint64_t words[2] = {(uint64_t)(prepared ? 0 : mine), prepared ? 0ull : 1ull};
+                    if (!comm_->agree_min(stream_, words, 2, &cerr)) return fail(WV_E_COMM, cerr);
+                    if (prepared) return prepared;
+                    if (words[1] == 0)
+                        return fail(WV_E_COMM, "another rank of the chain failed while preparing three-step passes (its wv_last_error says why)");
+                    mine = (int)words[0];
+                }
+                triples = mine != 0;
+                if (triples && !batch_flags_reset_) {
                     WV_HIP(hipMemsetD32Async((hipDeviceptr_t)flags_, static_flag_, (size_t)batch, stream_));
-                    WV_HIP(hipMemsetAsync(suspect_, 0, (size_t)batch * sizeof(int), stream_));
                     batch_flags_reset_ = true;
                 }
             }
@@ -300,7 +309,12 @@ int Engine<Real>::run(uint64_t n_steps, uint64_t* done, int32_t* flag_out) {
             auto kind_at = [&](uint64_t i) { return i >= batch ? 0 : (pair_at(i) ? 2 : 1); };
             for (uint64_t i = 0; i < batch;) {
                 if (triple_at(i)) {
-                    if ((rc = enqueue_triple((int)i, signal_pos_ + i, batch_source_live_, kind_at(i + 3)))) return rc;
+                    if (comm_) {
+                        for (int part = 0; part < 3; ++part)
+                            if ((rc = enqueue_batch_triple(i, part))) return rc;
+                    } else if ((rc = enqueue_triple((int)i, signal_pos_ + i, batch_source_live_, kind_at(i + 3)))) {
+                        return rc;
+                    }
                     i += 3;
                 } else if (pair_at(i)) {
                     if ((rc = enqueue_batch_pair(i, 0, 0))) return rc;

@@ -142,11 +142,27 @@ inline int group_run(wv_engine* const* engines, int32_t n, uint64_t n_steps, uin
                 if (rc) return rc;
             }
         const bool pairs = singles_first >= 0;
-        // lockstep: step i of every slab is enqueued before step i + 1 of any, and the two parts of a
-        // two-step pass likewise (comm.h, local transport)
-        auto pair_at = [&](uint64_t i) { return pairs && i >= (uint64_t)singles_first && i + 2 <= batch; };
+        // ... and three-step passes wherever the batch has three steps left, if every slab can take those
+        bool triples = pairs && batch >= (uint64_t)singles_first + 3;
+        for (int k = 0; k < n && triples; ++k) {
+            int ready = 0;
+            const int rc = engines[k]->batch_triple_prepare(&ready);
+            if (rc) return rc;
+            triples = ready != 0;
+        }
+        // lockstep: step i of every slab is enqueued before step i + 1 of any, and the parts of a
+        // pass likewise (comm.h, local transport)
+        auto triple_at = [&](uint64_t i) { return triples && i >= (uint64_t)singles_first && i + 3 <= batch; };
+        auto pair_at = [&](uint64_t i) { return pairs && !triple_at(i) && i >= (uint64_t)singles_first && i + 2 <= batch; };
         for (uint64_t i = 0; i < batch;) {
-            if (pair_at(i)) {
+            if (triple_at(i)) {
+                for (int part = 0; part < 3; ++part)
+                    for (int k = 0; k < n; ++k) {
+                        const int rc = engines[k]->enqueue_batch_triple(i, part);
+                        if (rc) return rc;
+                    }
+                i += 3;
+            } else if (pair_at(i)) {
                 for (int part = 0; part < 2; ++part)
                     for (int k = 0; k < n; ++k) {
                         const int rc = engines[k]->enqueue_batch_pair(i, part, 0);

@@ -29,7 +29,17 @@ namespace wv {
 template <typename Real>
 bool Engine<Real>::triple_eligible() {
     if (opt_.tuning.triple == 0 || triple_failed_) return false;
-    if (comm_ || opt_.ghost_lo || opt_.ghost_hi) return false;
+    const bool slab = opt_.ghost_lo || opt_.ghost_hi;
+    if (slab != (comm_ != nullptr)) return false;  // (ghost planes nobody fills; a communicator with nobody behind it)
+    if (slab) {
+        // A z-slab (enqueue_triple_slab): the march leaves out the face plane and the plane next to it where a neighbour follows.
+        // Its source's sample must be in the face plane before that plane travels, and the faces travel ahead of the samples:
+        if (z_end_ - z_begin_ < (opt_.ghost_lo ? 2 : 0) + (opt_.ghost_hi ? 2 : 0) + 2) return false;
+        if (source_kind_ != WV_SOURCE_NONE) {
+            const int sz = (int)(source_node_ / ((uint64_t)pitch_ * (uint64_t)ny_));
+            if ((opt_.ghost_lo && sz <= z_begin_) || (opt_.ghost_hi && sz >= z_end_ - 1)) return false;
+        }
+    }
     if (!pair_eligible()) return false;
     const int lb = triple_lane_bytes();
     const int WX = 64 * (lb / (int)sizeof(Real));
@@ -58,6 +68,12 @@ template <typename Real>
 int Engine<Real>::ensure_triple() {
     int rc = ensure_pair();
     if (rc) return rc;
+    triple_z0_ = z_begin_ + (opt_.ghost_lo ? 2 : 0);
+    triple_z1_ = z_end_ - (opt_.ghost_hi ? 2 : 0);
+    if (comm_ && pair_units_) {  // (a sparse room cut into slabs keeps its two-step passes)
+        triple_ready_ = false;
+        return WV_OK;
+    }
     if (pair_failed_ || (!pair_sparse_ok_ && opt_.tuning.triple < 0)) {  // (a room so sparse that the sweep's tiles beat the march's units keeps single steps)
         triple_ready_ = false;
         return WV_OK;
@@ -79,7 +95,9 @@ int Engine<Real>::ensure_triple() {
     }
     // x-facing walls on their compact copies through all three levels where the two-step passes run on them (ensure_pair: the entries
     // finish the nodes they face, the source is clear of them)
-    const bool xw = xw_active_ && pair_inner_ok_ > 0 && opt_.tuning.boundary_xwall != 2;
+    // (a slab: only where those entries keep clear of the planes next to the faces as well as of the faces -- xwall_eligible_kernel
+    // under wv_tuning::slab_early -- which a pass here steps by gathering from the fields)
+    const bool xw = xw_active_ && pair_inner_ok_ > 0 && opt_.tuning.boundary_xwall != 2 && !(comm_ && opt_.tuning.slab_early == 0);
     if (triple_map_ && triple_source_ == src && triple_io_generation_ == io_generation_ && triple_xw_ == xw) {
         triple_ready_ = true;
         return WV_OK;
@@ -102,8 +120,8 @@ int Engine<Real>::ensure_triple() {
     m.nz = nz_;
     m.pitch = pitch_;
     m.cls_pitch = cls_pitch_;
-    m.z_begin = z_begin_;
-    m.z_end = z_end_;
+    m.z_begin = triple_z0_;  // (the third level's list: the march's planes)
+    m.z_end = triple_z1_;
     ScopedDevice covered;  // the nodes those entries finish at the third level: not on its list
     if (xw) {
         const size_t words = (size_t)((stored_nodes_ + 31) / 32) + 1;
@@ -186,21 +204,27 @@ int Engine<Real>::ensure_triple() {
     const int by_lds = std::max<int>(1, (int)((160u * 1024u) / lds));
     const int by_waves = std::max(1, (lb == 16 ? 8 : 12) / triple_nw_);
     const int64_t slots = 256ll * std::min(by_lds, by_waves);
-    const int owned = z_end_ - z_begin_;
+    const int owned = triple_z1_ - triple_z0_;
     int chunks = opt_.tuning.triple_chunks;
     if (chunks <= 0) {
-        double best = 0;
-        chunks = 1;
+        // (a slab with a neighbour on another GPU: at least two rounds where that costs little, so that the exchange of the t+1 faces --
+        // enqueued ahead of the march, but in need of a CU where it is carried by kernels -- gets in at the first round's end instead
+        // of after the march: as ensure_pair chooses for the two-step march)
+        const int64_t want_rounds = ((opt_.ghost_lo || opt_.ghost_hi) && comm_ && comm_->peers_elsewhere()) ? 2 : 1;
+        double best[2] = {0, 0};
+        int at[2] = {0, 0};  // [0] any number of rounds, [1] at least `want_rounds`
         for (int c = 1; c <= std::max(1, owned / 12) && c <= 256; ++c) {
             const int64_t wgs = (int64_t)triple_strips_ * c * std::max(1, triple_windows_);
             const int64_t rounds = (wgs + slots - 1) / slots;
             const double zc = (double)((owned + c - 1) / c);
             const double cost = (double)(rounds * slots) / (double)wgs * (zc + 4.0) / zc;
-            if (c == 1 || cost < best - 1e-9) {
-                best = cost;
-                chunks = c;
-            }
+            for (int k = 0; k < 2; ++k)
+                if ((k == 0 || rounds >= want_rounds) && (at[k] == 0 || cost < best[k] - 1e-9)) {
+                    best[k] = cost;
+                    at[k] = c;
+                }
         }
+        chunks = (at[1] && best[1] <= 1.06 * best[0]) ? at[1] : std::max(1, at[0]);
     }
     chunks = std::max(1, std::min(chunks, std::max(1, owned / 4)));
     triple_zc_ = (owned + chunks - 1) / chunks;
@@ -372,6 +396,95 @@ int Engine<Real>::build_triple_units() {
     return WV_OK;
 }
 
+// The march of a pass over the planes [triple_z0_, triple_z1_) (a slab: t+2 also on the plane next to a face, which only the march can
+// supply), timed in an account of its own (WV_QUERY_TRIPLE_MARCH_NS); every eighth timed pass times its other launches too.
+template <typename Real>
+int Engine<Real>::launch_triple_march(int slot, const Real* A, const Real* B, Real* O1, Real* O2, Real* O3) {
+    int rc;
+    wv::TripleArgs<Real> a{};
+    a.prev = A;
+    a.cur = B;
+    a.out1 = O1;
+    a.out2 = O2;
+    a.out3 = O3;
+    a.map = triple_map_;
+    a.suspect = suspect_ + slot;
+    a.ny = ny_;
+    a.nz = nz_;
+    a.pitch = pitch_;
+    a.cls_pitch = cls_pitch_;
+    a.z_begin = triple_z0_;
+    a.z_end = triple_z1_;
+    a.z2_lo = triple_z0_ > z_begin_ ? 1 : 0;
+    a.z2_hi = triple_z1_ < z_end_ ? 1 : 0;
+    a.nw = triple_nw_;
+    a.zc = triple_zc_;
+    a.chunks = triple_chunks_;
+    a.strips = triple_strips_;
+    a.strips_per_xcd = (triple_strips_ + 7) / 8;
+    a.windows = triple_windows_;
+    for (int k = 0; k < triple_windows_; ++k) {
+        a.win_first |= (uint64_t)triple_win_[0][k] << (8 * k);
+        a.win_count |= (uint64_t)triple_win_[1][k] << (8 * k);
+        a.win_store_lo |= (uint64_t)triple_win_[2][k] << (8 * k);
+        a.win_store_hi |= (uint64_t)triple_win_[3][k] << (8 * k);
+    }
+    unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
+    if (triple_units_) {
+        a.unit_list = triple_units_;
+        for (int k = 0; k < 9; ++k) a.list_start[k] = triple_unit_start_[k];
+        grid = 8u * triple_units_longest_;
+    }
+    const bool timed = timing && time_this_launch();
+    const int token = timed ? begin_part_timing(4, true) : -1;
+    if (triple_lb_ == 8)
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, 8>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
+                           wv::triple_lds_bytes(triple_nw_, false, 8), stream_, a);
+    else
+        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
+                           wv::triple_lds_bytes(triple_nw_, false, kWideLaneBytes), stream_, a);
+    if ((rc = end_part_timing(4, token))) return rc;
+    pass_timed_ = timed && (part_timing_calls_++ & 7u) == 0;
+    return WV_OK;
+}
+
+// The third level's list -- every shell node of the march's planes from the finished t+2 field -- and the exact error bits of what the
+// march was the last to write, should it have seen an inf or a nan (fields t-1 and t are still what the march read).
+template <typename Real>
+int Engine<Real>::launch_triple_list(int slot, const Real* A, const Real* B, const Real* O1, const Real* O2, Real* O3, bool source_live) {
+    wv::PairFixupArgs<Real> f{};
+    f.nodes = triple_list_;
+    f.n = triple_list_n_;
+    f.t1 = O2;
+    f.cur = O1;
+    f.out2 = O3;
+    f.flag2 = flags_ + slot + 2;
+    f.nx = nx_;
+    f.ny = ny_;
+    f.nz = nz_;
+    f.pitch = pitch_;
+    wv::TripleFlagsArgs<Real> g{};
+    g.prev = A;
+    g.cur = B;
+    g.out2 = O2;
+    g.out3 = O3;
+    g.pair_map = pair_map_;
+    g.suspect = suspect_ + slot;
+    g.flag1 = flags_ + slot;
+    g.flag2 = flags_ + slot + 1;
+    g.flag3 = flags_ + slot + 2;
+    g.source_node = source_live ? source_node_ : ~0ull;
+    g.nx = nx_;
+    g.ny = ny_;
+    g.nz = nz_;
+    g.pitch = pitch_;
+    g.cls_pitch = cls_pitch_;
+    g.z_begin = triple_z0_;
+    g.z_end = triple_z1_;
+    hipLaunchKernelGGL(wv::triple_list_kernel<Real>, dim3(std::max(1u, (triple_list_n_ + 255) / 256)), dim3(256), 0, stream_, f, g);
+    return WV_OK;
+}
+
 // Steps `slot` .. `slot + 2` of a batch in one pass.  The flag words of the batch hold the mesh-static bits already (run()).
 // `fuse_next` (0: nothing follows in this batch, 1: a single step or another three-step pass, 2: a two-step pass): the next step's source /
 // receiver work rides in the last boundary launch -- like the source / receiver work of steps t+1 and t+2 in the first two, and the
@@ -398,49 +511,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
     }
     pre_post_done_ = false;
-    wv::TripleArgs<Real> a{};
-    a.prev = A;
-    a.cur = B;
-    a.out1 = O1;
-    a.out2 = O2;
-    a.out3 = O3;
-    a.map = triple_map_;
-    a.suspect = suspect_ + slot;
-    a.ny = ny_;
-    a.nz = nz_;
-    a.pitch = pitch_;
-    a.cls_pitch = cls_pitch_;
-    a.z_begin = z_begin_;
-    a.z_end = z_end_;
-    a.nw = triple_nw_;
-    a.zc = triple_zc_;
-    a.chunks = triple_chunks_;
-    a.strips = triple_strips_;
-    a.strips_per_xcd = (triple_strips_ + 7) / 8;
-    a.windows = triple_windows_;
-    for (int k = 0; k < triple_windows_; ++k) {
-        a.win_first |= (uint64_t)triple_win_[0][k] << (8 * k);
-        a.win_count |= (uint64_t)triple_win_[1][k] << (8 * k);
-        a.win_store_lo |= (uint64_t)triple_win_[2][k] << (8 * k);
-        a.win_store_hi |= (uint64_t)triple_win_[3][k] << (8 * k);
-    }
-    unsigned grid = 8u * (unsigned)a.strips_per_xcd * (unsigned)triple_chunks_ * (unsigned)std::max(1, triple_windows_);
-    if (triple_units_) {
-        a.unit_list = triple_units_;
-        for (int k = 0; k < 9; ++k) a.list_start[k] = triple_unit_start_[k];
-        grid = 8u * triple_units_longest_;
-    }
-    // (kernel timing: the march in an account of its own -- WV_QUERY_TRIPLE_MARCH_NS -- and, every eighth timed pass, its parts)
-    const bool timed = timing && time_this_launch();
-    int token = timed ? begin_part_timing(4, true) : -1;
-    if (triple_lb_ == 8)
-        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, 8>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
-                           wv::triple_lds_bytes(triple_nw_, false, 8), stream_, a);
-    else
-        hipLaunchKernelGGL((wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>), dim3(grid), dim3(64u * (unsigned)triple_nw_),
-                           wv::triple_lds_bytes(triple_nw_, false, kWideLaneBytes), stream_, a);
-    if ((rc = end_part_timing(4, token))) return rc;
-    pass_timed_ = timed && (part_timing_calls_++ & 7u) == 0;
+    if ((rc = launch_triple_march(slot, A, B, O1, O2, O3))) return rc;
     // level 1: boundary nodes to t+1 -- and, by the launch's last workgroup, step t+1's source sample / receivers (none of those nodes
     // is a boundary node: their t+1 has been final since the march) and then the second level's list where it is short and none of its
     // nodes has a boundary node for a neighbour (the source's neighbours, typically)
@@ -452,7 +523,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
         hipLaunchKernelGGL(wv::xwall_gather_kernel<Real>, dim3(g.xw_pad / 256), dim3(256), 0, stream_, g);
     }
     xw_valid_ = xw;  // (passes that do not maintain the copies leave them behind)
-    token = begin_part_timing(0);
+    int token = begin_part_timing(0);
     if (fuse && io) {
         wv::PrePostArgs<Real> nx = pre_post_args(O1, slot + 1, true, signal_pos + 1, source_live);
         nx.flag = nullptr;
@@ -498,38 +569,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     // level 3: every shell node from the finished t+2 field -- and the exact error bits of what the march was the last to write, should it
     // have seen an inf or a nan (fields t-1 and t are still what the march read) --, then the boundary nodes
     token = begin_part_timing(3);
-    {
-        wv::PairFixupArgs<Real> f{};
-        f.nodes = triple_list_;
-        f.n = triple_list_n_;
-        f.t1 = O2;
-        f.cur = O1;
-        f.out2 = O3;
-        f.flag2 = flag3;
-        f.nx = nx_;
-        f.ny = ny_;
-        f.nz = nz_;
-        f.pitch = pitch_;
-        wv::TripleFlagsArgs<Real> g{};
-        g.prev = A;
-        g.cur = B;
-        g.out2 = O2;
-        g.out3 = O3;
-        g.pair_map = pair_map_;
-        g.suspect = suspect_ + slot;
-        g.flag1 = flag1;
-        g.flag2 = flag2;
-        g.flag3 = flag3;
-        g.source_node = source_live ? source_node_ : ~0ull;
-        g.nx = nx_;
-        g.ny = ny_;
-        g.nz = nz_;
-        g.pitch = pitch_;
-        g.cls_pitch = cls_pitch_;
-        g.z_begin = z_begin_;
-        g.z_end = z_end_;
-        hipLaunchKernelGGL(wv::triple_list_kernel<Real>, dim3(std::max(1u, (triple_list_n_ + 255) / 256)), dim3(256), 0, stream_, f, g);
-    }
+    if ((rc = launch_triple_list(slot, A, B, O1, O2, O3, source_live))) return rc;
     if ((rc = end_part_timing(3, token))) return rc;
     token = begin_part_timing(2);
     if (fuse && fuse_next && (!xw || io_nodes_clear_of_x_walls())) {
@@ -553,6 +593,142 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
     spare_[0] = a_idx;
     spare_[1] = b_idx;
     return WV_OK;
+}
+
+// ---- three-step passes of a z-slab -----------------------------------------------------------------------------------------------
+// With f = a face plane (a neighbour mirrors it as its ghost plane), n = the owned plane next to it, g = the ghost plane beyond it: from
+// the ghost's t alone the march can produce t+1 from f on, t+2 from n on, t+3 from the plane after n on -- so it marches
+// [triple_z0_, triple_z1_), stores t+2 on n as well (TripleArgs::z2_lo / z2_hi), and f and n take plain steps (launch_faces: sweep + their
+// boundary nodes, as in a two-step pass), each level as soon as the neighbour's face of the level before is here.  Three exchanges per
+// pass, each enqueued ahead of some other work of about its length:
+//   part 0  [ghosts of t]  source / receivers on t -> f, n to t+1 -> EXCHANGE 1 (t+1 faces) -> march -> boundary nodes of its planes to t+1
+//   part 1  [ghosts of t+1]  source / receivers on t+1 -> f to t+2 -> EXCHANGE 2 (t+2 faces) -> second level's list, boundary nodes from
+//           n on to t+2 (they finish the nodes they face)
+//   part 2  [ghosts of t+2]  source / receivers on t+2 -> f, n to t+3 -> EXCHANGE 3 (t+3 faces) -> third level's list, boundary nodes of the
+//           march's planes to t+3
+// (an in-process chain enqueues part k of every slab before part k + 1 of any: each part opens with a wait for pushes that must have been
+// enqueued by then -- comm.h, local transport.)
+// The t+1 field is the engine's fifth (field1_), which the communicator does not know: its faces travel in the face / ghost planes of the
+// t+3 field, which nobody reads or writes before part 2 (the march's stores start two planes further in) -- one plane-sized copy either
+// side of the exchange.
+// Not here: a source on a face plane (its samples of t+1 and t+2 would have to be in the plane before it travels: triple_eligible),
+// sparse rooms' work lists, anything riding in anything (batch_can_fuse_ is off for slabs).
+template <typename Real>
+int Engine<Real>::enqueue_triple_slab(int slot, int part, uint64_t signal_pos, bool source_live) {
+    DeviceGuard guard(device_);
+    Real* A = field_[prv_];
+    Real* B = field_[cur_];
+    Real* O1 = field1_;
+    Real* O2 = field_[spare_[0]];
+    Real* O3 = field_[spare_[1]];
+    int* flag1 = flags_ + slot;
+    int* flag2 = flags_ + slot + 1;
+    int* flag3 = flags_ + slot + 2;
+    int rc;
+    std::string cerr;
+    const bool io = n_recv_ || source_live;
+    const bool xw = triple_xw_ && xw_active_;
+    const size_t plane = (size_t)pitch_ * ny_;
+    const int z0 = triple_z0_, z1 = triple_z1_;
+    const int n0 = z0 - (opt_.ghost_lo ? 1 : 0), n1 = z1 + (opt_.ghost_hi ? 1 : 0);  // ... and the planes next to the faces
+    auto pre_post = [&](Real* field, int step) {
+        if (!io) return;
+        wv::PrePostArgs<Real> pp = pre_post_args(field, slot + step, true, signal_pos + (uint64_t)step, source_live);
+        pp.flag = nullptr;  // (the batch's flag words were reset in one go: plan_batch)
+        hipLaunchKernelGGL(wv::pre_post_kernel<Real>, dim3(1), dim3(64), 0, stream_, pp);
+    };
+    auto wait_for = [&](int field) -> int {
+        const int token = begin_halo_wait_timing();
+        if (!comm_->wait_ghosts(stream_, field, &cerr)) return fail(WV_E_COMM, cerr);
+        return end_halo_wait_timing(token);
+    };
+    // plane z of `src` into plane z of `dst`, on the compute stream
+    auto copy_plane = [&](Real* dst, const Real* src, int z) -> int {
+        WV_HIP(hipMemcpyAsync(dst + (size_t)z * plane, src + (size_t)z * plane, plane * sizeof(Real), hipMemcpyDeviceToDevice, stream_));
+        return WV_OK;
+    };
+    if (!batch_flags_reset_) return fail(WV_E_STATE, "a slab's three-step pass without the batch's flag words reset");
+    if (part == 0) {
+        if ((rc = wait_for(cur_))) return rc;
+        pre_post(B, 0);
+        pre_post_done_ = false;
+        if ((rc = launch_faces(A, B, flag1, O1, 2))) return rc;
+        WV_HIP(hipGetLastError());
+        if (opt_.ghost_lo && (rc = copy_plane(O3, O1, z_begin_))) return rc;
+        if (opt_.ghost_hi && (rc = copy_plane(O3, O1, z_end_ - 1))) return rc;
+        if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
+        if (!comm_->bulk_begin(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // (slabs of one device take turns at the march)
+        if ((rc = launch_triple_march(slot, A, B, O1, O2, O3))) return rc;
+        if (!comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+        if (xw && !xw_valid_) {  // the x-facing walls' compact copies, from fields t-1 and t
+            wv::BoundaryArgs<Real> g = boundary_args(A, B, flag1);
+            xwall_args(g);
+            hipLaunchKernelGGL(wv::xwall_gather_kernel<Real>, dim3(g.xw_pad / 256), dim3(256), 0, stream_, g);
+        }
+        xw_valid_ = xw;
+        const int token = begin_part_timing(0);
+        if ((rc = launch_boundary(A, B, flag1, z0, z1, nullptr, O1, false, false, nullptr, xw ? 1 : 0))) return rc;
+        if ((rc = end_part_timing(0, token))) return rc;
+    } else if (part == 1) {
+        if ((rc = wait_for(spare_[1]))) return rc;
+        if (opt_.ghost_lo && (rc = copy_plane(O1, O3, 0))) return rc;
+        if (opt_.ghost_hi && (rc = copy_plane(O1, O3, nz_ - 1))) return rc;
+        pre_post(O1, 1);
+        if ((rc = launch_faces(B, O1, flag2, O2, 1))) return rc;
+        WV_HIP(hipGetLastError());
+        if (!comm_->exchange_faces(stream_, spare_[0], &cerr)) return fail(WV_E_COMM, cerr);
+        if ((rc = launch_fixup(0, pair_list_n_, O1, B, O2, flag2))) return rc;
+        const int token = begin_part_timing(1);
+        if ((rc = launch_boundary(B, O1, flag2, n0, n1, nullptr, O2, pair_inner_ok_ > 0, false, nullptr, xw ? 2 : 0))) return rc;
+        if ((rc = end_part_timing(1, token))) return rc;
+    } else {
+        if ((rc = wait_for(spare_[0]))) return rc;
+        pre_post(O2, 2);
+        if ((rc = launch_faces(O1, O2, flag3, O3, 2))) return rc;
+        WV_HIP(hipGetLastError());
+        if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
+        int token = begin_part_timing(3);
+        if ((rc = launch_triple_list(slot, A, B, O1, O2, O3, source_live))) return rc;
+        if ((rc = end_part_timing(3, token))) return rc;
+        token = begin_part_timing(2);
+        if ((rc = launch_boundary(O1, O2, flag3, z0, z1, nullptr, O3, false, false, nullptr, xw ? 3 : 0))) return rc;
+        if ((rc = end_part_timing(2, token))) return rc;
+        pass_timed_ = false;
+        WV_HIP(hipGetLastError());
+        if (!comm_->step_done(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+        ++triples_taken_;
+        const int a_idx = prv_, b_idx = cur_;
+        prv_ = spare_[0];
+        cur_ = spare_[1];
+        spare_[0] = a_idx;
+        spare_[1] = b_idx;
+    }
+    return WV_OK;
+}
+
+// Can this engine take three-step passes in the batch being planned (after batch_pair_prepare said yes to passes)?  Builds what they need.
+template <typename Real>
+int Engine<Real>::batch_triple_prepare(int* ready) {
+    DeviceGuard guard(device_);
+    *ready = 0;
+    if (!triple_eligible()) return WV_OK;
+    const int rc = ensure_triple();
+    if (rc == WV_E_HIP && wv::last_hip_error() == hipErrorOutOfMemory) {  // (no room: two-step passes)
+        (void)hipGetLastError();
+        triple_failed_ = true;
+        return WV_OK;
+    }
+    if (rc) return rc;
+    *ready = triple_ready_ ? 1 : 0;
+    if (*ready && suspect_) WV_HIP(hipMemsetAsync(suspect_, 0, kRing * sizeof(int), stream_));
+    return WV_OK;
+}
+
+// One part (0, 1, 2) of the three-step pass that starts at step i of the batch -- a slab's; a single domain's pass is one part
+template <typename Real>
+int Engine<Real>::enqueue_batch_triple(uint64_t i, int part) {
+    if (comm_) return enqueue_triple_slab((int)i, part, signal_pos_ + i, batch_source_live_);
+    return part == 0 ? enqueue_triple((int)i, signal_pos_ + i, batch_source_live_, 0) : WV_OK;
 }
 
 }  // namespace wv

@@ -76,6 +76,10 @@ struct TripleArgs {
     int* suspect;        // set when anything the march kept is inf or nan: triple_flags_kernel then works out the exact error bits
     int ny, nz, pitch, cls_pitch;
     int z_begin, z_end;  // planes to produce
+    // z-slabs: t+2 is wanted one plane beyond either end of that range too (z2_lo / z2_hi: 1 or 0) -- the plane next to a face plane, whose
+    // t+3 is a plain step's business (the face's t+2 waits for the neighbour's) but whose t+2 only this march can supply: its neighbours'
+    // t+1 is stored at shell nodes alone.  The first chunk stores it from its last warm-up trip, the last chunk runs one trip more.
+    int z2_lo, z2_hi;
     int nw;              // waves per workgroup
     int zc, chunks;      // planes per workgroup, workgroups along z
     int strips, strips_per_xcd;
@@ -271,6 +275,7 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     const int y0 = strip * RY;
     const int zb = a.z_begin + chunk * a.zc, ze = min(zb + a.zc, a.z_end);
     if (zb >= ze) return;
+    const int zb2 = zb - (zb == a.z_begin ? a.z2_lo : 0), ze2 = ze + (ze == a.z_end ? a.z2_hi : 0);  // t+2 is stored on [zb2, ze2)
     const int pitch = a.pitch;
     const int64_t plane = (int64_t)pitch * a.ny;
 
@@ -376,10 +381,11 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     auto trip = [&](int f, int set, V(&b_mid)[R0], V(&b_new)[R0], V(&u_mid)[R1], V(&u_new)[R1], V(&w_mid)[R2], V(&w_new)[R2], V(&pv)[R1],
                     V(&pv_next)[R1]) {
         const int z = f - 3;
-        const bool storing = z >= zb && stores;  // (warm-up trips and halo waves produce nothing)
+        const bool storing = z >= zb && z < ze && stores;  // (warm-up trips and halo waves produce nothing)
+        const bool storing2 = z >= zb2 && stores;          // (t+2: a slab's extra plane at either end)
         const Rsrc r_cur = plane_of(a.cur, f, true), r_prev = plane_of(a.prev, f - 1, true);
         const Rsrc r_cur_n = plane_of(a.cur, f + 1, true), r_prev_n = plane_of(a.prev, f, true);
-        const Rsrc r_o1 = plane_of(a.out1, z, storing), r_o2 = plane_of(a.out2, z, storing), r_o3 = plane_of(a.out3, z, storing);
+        const Rsrc r_o1 = plane_of(a.out1, z, storing), r_o2 = plane_of(a.out2, z, storing2), r_o3 = plane_of(a.out3, z, storing);
         const uint32_t code_word = codes_of(min(max(z, 0), a.nz - 1));
         const bool z1 = in_z(f - 1), z2 = in_z(f - 2);
         // the edge columns of this trip's centre planes, published by every wave at the end of the last trip
@@ -513,9 +519,9 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
             wait_vmcnt<0>();  // (the waits inside the trips count on a whole trip's instructions between a DMA and its use)
         }
     }
-    for (int f = zb - 1; f <= ze + 2; f += 2) {
+    for (int f = zb - 1; f <= ze2 + 2; f += 2) {
         trip(f, 0, bA, bB, uA, uB, wA, wB, pA, pB);
-        if (f + 1 <= ze + 2) trip(f + 1, 1, bB, bA, uB, uA, wB, wA, pB, pA);
+        if (f + 1 <= ze2 + 2) trip(f + 1, 1, bB, bA, uB, uA, wB, wA, pB, pA);
     }
     // inf / nan among the values this workgroup kept: say so, triple_flags_kernel (launched behind every march) works out the exact bits
     if (__any(top_exp >= (sizeof(Real) == 8 ? 0x7FF00000u : 0x7F800000u)) && lane == 0) atomicOr(a.suspect, 1);
