@@ -70,8 +70,9 @@ class BandedChain:
                 prev[z - a], cur[z - a] = self.noise_plane(z, dtype, sym)
         return prev, cur
 
-    def run_and_check(self, oracle, precision, coeffs, tuning, check_symmetry, signal, expect_two_step, after_run=None):
-        """Builds the chain, runs S steps, compares with the oracle's windows.  Returns per-engine (passes, early passes)."""
+    def run_and_check(self, oracle, precision, coeffs, tuning, check_symmetry, signal, expect_two_step, after_run=None, expect_three_step=False):
+        """Builds the chain, runs S steps, compares with the oracle's windows.  Returns per-engine (two-step passes, early passes,
+        three-step passes)."""
         from wayverb_amd import engine as E
         from wayverb_amd.slab import SlabLayout, box_slab_mesh
         N, WORLD, PLANES, NZG, S = self.N, self.WORLD, self.PLANES, self.NZG, self.S
@@ -103,9 +104,13 @@ class BandedChain:
             group = E.LocalSlabGroup(engines)
             done, flag = group.run_steps(S)
             assert (done, flag) == (S, 0)
-            queries = [(e.query(E.Engine.QUERY_PASSES), e.query(E.Engine.QUERY_EARLY_PASSES)) for e in engines]
-            # (the fields were written to: two single full sweeps come first, then passes of two steps)
-            assert all(p == ((S - 2) // 2 if expect_two_step else 0) for p, _ in queries), "stepping mode: %r" % (queries,)
+            queries = [(e.query(E.Engine.QUERY_PASSES), e.query(E.Engine.QUERY_EARLY_PASSES), e.query(E.Engine.QUERY_TRIPLE_PASSES)) for e in engines]
+            # (the fields were written to: two single full sweeps come first, then passes of two steps -- or of three, and a pass of two
+            # where two steps are left over)
+            if expect_three_step:
+                assert all(t == (S - 2) // 3 and p == ((S - 2) % 3) // 2 for p, _, t in queries), "stepping mode: %r" % (queries,)
+            else:
+                assert all(p == ((S - 2) // 2 if expect_two_step else 0) and t == 0 for p, _, t in queries), "stepping mode: %r" % (queries,)
 
             def planes_of(z0, z1, buf):
                 """Global planes [z0, z1) from whichever slabs own them."""

@@ -26,11 +26,14 @@ S, W = 8, 3
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-_TUNINGS = {"both-exchanges-under-the-march": dict(slab_early=1), "round-3-order": dict(slab_early=0, fuse_planes=0),
-            "early-two-rounds": dict(slab_early=1, pair_chunks=2), "defaults": dict()}
+# (slabs this wide take three-step passes by themselves -- "defaults" --: the forms of the two-step pass are asked for with triple = 0)
+_TUNINGS = {"both-exchanges-under-the-march": dict(slab_early=1, triple=0), "round-3-order": dict(slab_early=0, fuse_planes=0, triple=0),
+            "early-two-rounds": dict(slab_early=1, pair_chunks=2, triple=0), "two-step-defaults": dict(triple=0), "defaults": dict(),
+            "three-step-passes-in-two-chunks": dict(triple=1, triple_chunks=2)}
 _FORMS = [(2, 160, t, s) for t in _TUNINGS for s in ("next-to-the-cut", "mid-slab")] + \
          [(8, 32, "both-exchanges-under-the-march", "next-to-the-cut"), (8, 32, "both-exchanges-under-the-march", "mid-slab"),
-          (8, 32, "defaults", "next-to-the-cut")]     # (the oracle's windows around seven cuts take 17 s per case)
+          (8, 32, "two-step-defaults", "next-to-the-cut"), (8, 32, "defaults", "next-to-the-cut"),
+          (8, 32, "defaults", "mid-slab")]     # (the oracle's windows around seven cuts take 17 s per case)
 
 
 @pytest.mark.parametrize("world,planes,tuning,source_at", _FORMS, ids=["%dx%d-planes-%s-%s" % f for f in _FORMS])
@@ -59,9 +62,15 @@ def test_bench_width_fp64_passes_across_a_cut_against_the_oracle(oracle, built_l
 
     def after_run(trace):
         assert np.any(trace[:, 6] != 0) and np.any(trace[:, 7] != 0)
-    queries = chain.run_and_check(oracle, "f64", coeffs, tuning, False, signal, True, after_run)
-    passes = [p for p, _ in queries]
-    early = [e for _, e in queries]
+    three = tuning.get("triple", -1) != 0
+    queries = chain.run_and_check(oracle, "f64", coeffs, tuning, False, signal, True, after_run, expect_three_step=three)
+    passes = [p for p, _, _ in queries]
+    early = [e for _, e, _ in queries]
+    if three:
+        # written fields: two single sweeps first, then two passes of three steps (three exchanges each: engine_triple.hip.h,
+        # enqueue_triple_slab) -- a source on plane n or beyond keeps nobody from them
+        assert [t for _, _, t in queries] == [2] * WORLD and passes == [0] * WORLD and early == [0] * WORLD, queries
+        return
     assert passes == [3] * WORLD, queries                      # written fields: two single sweeps first, then three passes
     want_early = tuning.get("slab_early", -1) == 1             # (-1: slabs that share a device keep round 3's order)
     below, above = WORLD // 2 - 1, WORLD // 2                  # the slabs either side of the cut
@@ -95,7 +104,18 @@ def test_bench_width_fp64_passes_over_the_rccl_branch_equal_the_single_domain(mo
     env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env["WV_NO_TORCH_PRELOAD"] = "1"
     out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py"), "2", "box", str(N), str(N), "320", "f64", "27", "77",
-                          "--pair=1", "--tuning=slab_early=%d" % early, "--source-plane=240"], capture_output=True, text=True, env=env, timeout=900)
+                          "--pair=1", "--tuning=slab_early=%d,triple=0" % early, "--source-plane=240"], capture_output=True, text=True, env=env, timeout=900)
     last = (out.stdout.strip().splitlines() or [""])[-1]
     assert out.returncode == 0 and last.startswith("OK steps 27 flag 0 two_step_passes True"), (out.stdout[-1500:], out.stderr[-1500:])
     assert ("early_passes [12, 12]" if early else "early_passes [0, 0]") in last, last
+
+
+def test_bench_width_fp64_three_step_passes_over_the_rccl_branch_equal_the_single_domain(mock_dir):
+    """... and in the form slabs this wide take by themselves: 27 steps = two single sweeps, eight three-step passes, one step."""
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = mock_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["WV_NO_TORCH_PRELOAD"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_chain_worker.py"), "2", "box", str(N), str(N), "320", "f64", "27", "77",
+                          "--source-plane=240"], capture_output=True, text=True, env=env, timeout=900)
+    last = (out.stdout.strip().splitlines() or [""])[-1]
+    assert out.returncode == 0 and last.startswith("OK steps 27 flag 0 ") and "three_step_passes [8, 8]" in last, (out.stdout[-1500:], out.stderr[-1500:])
