@@ -183,6 +183,9 @@ def test_slab_chain_equals_single_domain(built_library, world, room, dims, preci
         if _step_mode == "two-step-passes" and planes >= 4:
             # written fields -> two single full sweeps first, then passes of two steps
             assert all(steps_ > launches for _, launches, steps_ in got["detail"] if launches), got["detail"]
+        if _step_mode == "three-step-passes" and planes >= 6 and room == "box":
+            # ... or of three: a source on a slab face keeps nobody from them (the neighbour adds the samples to its ghost copy itself)
+            assert all(t == (steps - 2) // 3 for t in got["queries"][2]), got["queries"]
 
 
 def test_a_flag_on_one_slab_stops_the_whole_chain(built_library):
@@ -430,7 +433,9 @@ def test_sources_around_a_cut_and_which_slabs_keep_the_older_order(built_library
         got = slab_chain(gmesh, world, precision, gprev, gcur, kind, source, signal, receivers, steps)
         assert want["done"] == steps and want["flag"] == 0
         assert_same(got, want, gmesh)
-        passes, early, _ = got["queries"]
+        passes, early, triples = got["queries"]
+        if _step_mode == "three-step-passes":
+            assert all(t == (steps - 2) // 3 for t in triples), triples     # wherever the source lies: on a face, in a ghost plane, next to them
         if _step_mode == "two-step-passes":
             assert all(p == (steps - 2) // 2 for p in passes), passes
             if E.default_tuning.get("slab_early", -1) == 0:

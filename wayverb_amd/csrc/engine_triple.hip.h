@@ -32,13 +32,8 @@ bool Engine<Real>::triple_eligible() {
     const bool slab = opt_.ghost_lo || opt_.ghost_hi;
     if (slab != (comm_ != nullptr)) return false;  // (ghost planes nobody fills; a communicator with nobody behind it)
     if (slab) {
-        // A z-slab (enqueue_triple_slab): the march leaves out the face plane and the plane next to it where a neighbour follows.
-        // Its source's sample must be in the face plane before that plane travels, and the faces travel ahead of the samples:
+        // A z-slab (enqueue_triple_slab): the march leaves out the face plane and the plane next to it where a neighbour follows
         if (z_end_ - z_begin_ < (opt_.ghost_lo ? 2 : 0) + (opt_.ghost_hi ? 2 : 0) + 2) return false;
-        if (source_kind_ != WV_SOURCE_NONE) {
-            const int sz = (int)(source_node_ / ((uint64_t)pitch_ * (uint64_t)ny_));
-            if ((opt_.ghost_lo && sz <= z_begin_) || (opt_.ghost_hi && sz >= z_end_ - 1)) return false;
-        }
     }
     if (!pair_eligible()) return false;
     const int lb = triple_lane_bytes();
@@ -611,8 +606,10 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
 // The t+1 field is the engine's fifth (field1_), which the communicator does not know: its faces travel in the face / ghost planes of the
 // t+3 field, which nobody reads or writes before part 2 (the march's stores start two planes further in) -- one plane-sized copy either
 // side of the exchange.
-// Not here: a source on a face plane (its samples of t+1 and t+2 would have to be in the plane before it travels: triple_eligible),
-// sparse rooms' work lists, anything riding in anything (batch_can_fuse_ is off for slabs).
+// A source on a face plane: the face travels as computed, before the level's sample goes in -- the neighbour that holds the plane as its ghost
+// adds the sample to its copy itself (as in every other form of step), and every level's source / receiver work comes after the wait for
+// that level's ghosts, which also covers this slab's own push of the plane the sample goes into.
+// Not here: sparse rooms' work lists, anything riding in anything (batch_can_fuse_ is off for slabs).
 template <typename Real>
 int Engine<Real>::enqueue_triple_slab(int slot, int part, uint64_t signal_pos, bool source_live) {
     DeviceGuard guard(device_);
