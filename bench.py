@@ -156,7 +156,8 @@ def cpu_baseline(args, elem):
 def chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch):
     """N > 1: before anything is timed, the chain proves itself on THIS machine's links.  A small room (192 x 160 x 24 N nodes, four
     wall materials, noise in the room, a soft source on a slab face, receivers on both sides of a cut) is stepped 26 times as N
-    slabs over the same transport the timed run will use, two-step passes forced, and by rank 0 alone as one domain: the owned
+    slabs over the same transport the timed run will use, in the form the timed run takes (three-step passes forced: two single sweeps for
+    the written fields, eight passes of three exchanges each; wv_tuning triple=0 on the command line: two-step passes), and by rank 0 alone as one domain: the owned
     planes of both fields, the filter memories and the receiver rows must be the same bytes.  Returns what goes into the bench line
     as config.halo_parity (never raises: a failure here is reported, not fatal to the measurement)."""
     import hashlib
@@ -178,7 +179,9 @@ def chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch):
         L0 = SlabLayout((nx, ny, nz), 0, world)
         source = (L0.z1 - 1) * plane + (ny // 2) * nx + nx // 2            # top owned plane of slab 0: its ghost copy injects too
         receivers = [source + 3, source + plane, source - plane, (nz - 3) * plane + 5 * nx + 7]
-        tuning = dict(pair=1)
+        tuning = dict(pair=1, triple=1, tile_lists=0)
+        if E.default_tuning.get("triple") == 0:   # (--tuning triple=0: the chain's two-step passes are what is checked and timed)
+            tuning["triple"] = 0
         L = SlabLayout((nx, ny, nz), rank, world)
         eng = E.Engine(slab_mesh(gmesh, L), precision="f64", device=local_rank, ghost_lo=L.ghost_lo, ghost_hi=L.ghost_hi, tuning=tuning,
                        comm_timeout_s=args.comm_timeout, transport=args.transport)
@@ -202,7 +205,7 @@ def chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch):
             h.update(np.ascontiguousarray(eng.read_boundary_data(d)["filter_memory"]).tobytes())
         got = eng.fetch_receivers(0, done)
         mine_rows = {pos: got[:, col].tobytes() for col, (pos, _) in enumerate(mine)}
-        passes = int(eng.query(E.Engine.QUERY_PASSES))
+        passes = (int(eng.query(E.Engine.QUERY_PASSES)), int(eng.query(E.Engine.QUERY_TRIPLE_PASSES)))
         eng.close()
         everyone = [None] * world
         dist.all_gather_object(everyone, (done, flag, h.hexdigest(), mine_rows, passes))
@@ -239,7 +242,8 @@ def chain_parity_check(args, rank, world, local_rank, coll_device, dist, torch):
             if not ok:
                 wrong.append(r)
         return {"bitwise_equal": not wrong, "ranks_that_differ": wrong, "mesh": "%dx%dx%d fp64" % (nx, ny, nz), "steps": steps,
-                "two_step_passes_per_rank": [e[4] for e in everyone], "transport": args.transport,
+                "two_step_passes_per_rank": [e[4][0] for e in everyone], "three_step_passes_per_rank": [e[4][1] for e in everyone],
+                "transport": args.transport,
                 "seconds": round(time.perf_counter() - t0, 2),
                 "what": "fields, filter memories and receiver rows of the chain against the single domain on rank 0, before the timed run"}
     except BaseException as e:  # noqa: BLE001
@@ -481,7 +485,8 @@ def run_bench(args, guard):
     # the engine took two-step passes (N=1 on a mesh this size), else 1
     steps_per_launch = (timed_steps / launches) if launches else 1.0
     two_step = steps_per_launch > 1.5   # (more than one: the fields cross the HBM interface once per PASS, 4 x elem bytes per node)
-    timed_planes = (layout.z1 - layout.z0) - (int(layout.ghost_lo) + int(layout.ghost_hi))
+    # (a slab's three-step march also leaves out the plane next to each face: engine_triple.hip.h, enqueue_triple_slab)
+    timed_planes = (layout.z1 - layout.z0) - (2 if three_step else 1) * (int(layout.ghost_lo) + int(layout.ghost_hi))
     # Algorithmic bytes of one launch = what the kernel has to move if every value crosses the HBM
     # interface once: the single-step sweep reads 2 fields and writes 1 per node
     # (3 x elem = 24 B per node-update in fp64); the two-step pass reads 2 and writes 2 for TWO updates
@@ -550,9 +555,11 @@ def run_bench(args, guard):
                                % (nx, ny, nz_global, "fp64" if elem == 8 else "fp32"),
                    "per_gpu": "%dx%dx%d z-slab" % (nx, ny, layout.z1 - layout.z0), "decomposition": "z-slabs x%d" % world,
                    "halo": ("none" if world == 1 else
-                            "RCCL send/recv of the face planes on a second stream (two exchanges per two-step pass, both under the march: the faces' second step runs on that stream between them)"
-                            if args.transport == "rccl" else
-                            "face planes copied into the neighbours' IPC-mapped fields on a second stream, ordered by mailbox counters (two exchanges per two-step pass, both under the march); RCCL for the ranks' agreements and the flag OR only"),
+                            ("RCCL send/recv of the face planes on a second stream" if args.transport == "rccl" else
+                             "face planes copied into the neighbours' IPC-mapped fields on a second stream, ordered by mailbox counters; RCCL for the ranks' agreements and the flag OR only")
+                            + ("; three exchanges per three-step pass (t+1, t+2, t+3 faces), each enqueued ahead of a boundary launch of about its length; the face planes and "
+                               "the planes next to them take plain steps, the march covers the planes in between" if three_step else
+                               "; two exchanges per two-step pass, both under the march: the faces' second step runs on that stream between them")),
                    "halo_measured": halo,
                    "halo_parity": halo_parity,
                    "setup_s": round(t_setup, 2)},

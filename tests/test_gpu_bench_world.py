@@ -48,7 +48,8 @@ def run_bench(world, shm_mock, *extra, timeout=600):
 
 
 @pytest.mark.parametrize("world,scaling,tuning,two_step", [(2, "weak", "pair=1", True), (3, "strong", "pair=0", False),
-                                                          (4, "weak", "", None), (8, "strong", "pair=1", True)])
+                                                          (4, "weak", "", None), (8, "strong", "pair=1", True),
+                                                          (3, "weak", "pair=1,triple=1,tile_lists=0", "three")])
 def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_step):
     nx, ny, nz, steps, warmup = 256, 96, (48 if scaling == "weak" else (96 if world < 8 else 128)), 8, 4
     extra = ["--steps", steps, "--warmup", warmup, "--nx", nx, "--ny", ny, "--nz", nz, "--scaling", scaling]
@@ -61,7 +62,9 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
     assert r["config"]["workload"].startswith("%dx%dx%d box mesh" % (nx, ny, nz_global))
     assert r["config"]["decomposition"] == "z-slabs x%d" % world and "RCCL" in r["config"]["halo"]
     # the chain checked itself against the single domain before the timed run, over the transport of the run
-    assert r["config"]["halo_parity"]["bitwise_equal"] is True and r["config"]["halo_parity"]["two_step_passes_per_rank"] == [12] * world, r["config"]["halo_parity"]
+    # (in three-step passes, the form a timed run of full-size slabs takes: 26 steps = 2 single sweeps for the written fields + 8 passes)
+    assert r["config"]["halo_parity"]["bitwise_equal"] is True and r["config"]["halo_parity"]["three_step_passes_per_rank"] == [8] * world, r["config"]["halo_parity"]
+    assert r["config"]["halo_parity"]["two_step_passes_per_rank"] == [0] * world
     if world == 4:   # the same chain with the planes on the IPC transport (processes sharing the GPU map each other's fields)
         r2 = run_bench(world, shm_mock, *(extra + ["--transport", "ipc"]))
         assert "IPC-mapped" in r2["config"]["halo"] and r2["roofline"]["launches"] > 0 and r2["value"] > 0
@@ -76,11 +79,18 @@ def test_bench_line_of_a_chain_of_ranks(shm_mock, world, scaling, tuning, two_st
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["launches"] > 0 and roof["kernel_ms"] > 0
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3)
+    owned0 = nz_global // world + (1 if 0 < nz_global % world else 0)
+    if two_step == "three":
+        # three-step passes, the form full-size slabs take by themselves: the march covers rank 0's owned planes but the face plane and
+        # the plane next to it; three exchanges per pass
+        assert roof["kernel"] == "triple_march_kernel" and roof["time_steps_per_launch"] == 3.0 and "three exchanges per three-step pass" in r["config"]["halo"]
+        assert roof["alg_bytes_per_launch"] == 4 * 8 * nx * ny * (owned0 - 2)
+        assert r["cpu_baseline"] is None
+        return
     if two_step is not None:
         assert roof["kernel"] == ("pair_march_kernel" if two_step else "stream_sweep_kernel")
         assert roof["time_steps_per_launch"] == (2.0 if two_step else 1.0)
     # rank 0's slab: the timed launch covers its owned planes but the face plane(s) next to a neighbour
-    owned0 = nz_global // world + (1 if 0 < nz_global % world else 0)
     fields = 4 if roof["time_steps_per_launch"] > 1.5 else 3
     assert roof["alg_bytes_per_launch"] == fields * 8 * nx * ny * (owned0 - 1)
     assert r["cpu_baseline"] is None

@@ -24,7 +24,7 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy", "memcpy %s" % r.get("Direction", "")))
     rows.sort()
-    short = [(s, e) for s, e, q, name in rows if name.startswith("pair_march") and e - s < 2_000_000]
+    short = [(s, e) for s, e, q, name in rows if name.startswith(("pair_march", "triple_march")) and e - s < 2_000_000]
     if len(short) >= 2 * which_slabs(rows):
         # a chain of slabs on one device: from the first slab's march of one pass to its march of the next
         n = which_slabs(rows)
@@ -34,7 +34,7 @@ def main():
     else:
         marches = {}
         for s, e, q, name in rows:
-            if name.startswith("pair_march"):
+            if name.startswith(("pair_march", "triple_march")):
                 marches.setdefault(q, []).append(s)
         if not marches:
             print("no march in the trace")

@@ -596,7 +596,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
 // [triple_z0_, triple_z1_), stores t+2 on n as well (TripleArgs::z2_lo / z2_hi), and f and n take plain steps (launch_faces: sweep + their
 // boundary nodes, as in a two-step pass), each level as soon as the neighbour's face of the level before is here.  Three exchanges per
 // pass, each enqueued ahead of some other work of about its length:
-//   part 0  [ghosts of t]  source / receivers on t -> f, n to t+1 -> EXCHANGE 1 (t+1 faces) -> march -> boundary nodes of its planes to t+1
+//   part 0  [ghosts of t]  source / receivers on t -> f, n to t+1 -> march -> EXCHANGE 1 (t+1 faces) -> boundary nodes of its planes to t+1
 //   part 1  [ghosts of t+1]  source / receivers on t+1 -> f to t+2 -> EXCHANGE 2 (t+2 faces) -> second level's list, boundary nodes from
 //           n on to t+2 (they finish the nodes they face)
 //   part 2  [ghosts of t+2]  source / receivers on t+2 -> f, n to t+3 -> EXCHANGE 3 (t+3 faces) -> third level's list, boundary nodes of the
@@ -653,10 +653,14 @@ int Engine<Real>::enqueue_triple_slab(int slot, int part, uint64_t signal_pos, b
         WV_HIP(hipGetLastError());
         if (opt_.ghost_lo && (rc = copy_plane(O3, O1, z_begin_))) return rc;
         if (opt_.ghost_hi && (rc = copy_plane(O3, O1, z_end_ - 1))) return rc;
-        if (!comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
+        // (the exchange behind the march, under the boundary launch that follows: enqueued ahead of the march its copy kernels sat on the
+        // device for the whole of it -- 3.2 ms for 8 MB -- and the march of 508 planes took 3.3 ms where half the single domain's is 2.9)
+        const bool ahead = opt_.tuning.slab_early == 2;  // (measurement: the first form)
+        if (ahead && !comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
         if (!comm_->bulk_begin(stream_, &cerr)) return fail(WV_E_COMM, cerr);  // (slabs of one device take turns at the march)
         if ((rc = launch_triple_march(slot, A, B, O1, O2, O3))) return rc;
         if (!comm_->bulk_end(stream_, &cerr)) return fail(WV_E_COMM, cerr);
+        if (!ahead && !comm_->exchange_faces(stream_, spare_[1], &cerr)) return fail(WV_E_COMM, cerr);
         if (xw && !xw_valid_) {  // the x-facing walls' compact copies, from fields t-1 and t
             wv::BoundaryArgs<Real> g = boundary_args(A, B, flag1);
             xwall_args(g);
