@@ -36,8 +36,9 @@ def _bands():
     return out
 
 
-@pytest.mark.parametrize("precision,pair", [("f64", 0), ("f32", 1)], ids=["f64-single-steps", "f32-two-step-passes"])
-def test_config3_1024x1024x8192_as_eight_slabs_on_one_gpu(oracle, built_library, precision, pair):
+@pytest.mark.parametrize("precision,pair,triple", [("f64", 0, 0), ("f32", 1, 0), ("f32", 1, -1)],
+                         ids=["f64-single-steps", "f32-two-step-passes", "f32-the-engines-choice-three-step-passes"])
+def test_config3_1024x1024x8192_as_eight_slabs_on_one_gpu(oracle, built_library, precision, pair, triple):
     rng = np.random.default_rng(8192)
     # fp64: ONE order-6 material on every wall, so that x-mirror-symmetric bands must stay mirror symmetric bit for bit;
     # fp32: the bench's four materials dealt over the wall filters (no symmetry to speak of: the oracle is the check)
@@ -53,4 +54,6 @@ def test_config3_1024x1024x8192_as_eight_slabs_on_one_gpu(oracle, built_library,
 
     def after_run(trace):
         assert np.any(trace[:, 6] != 0) and np.any(trace[:, 8] != 0)
-    chain.run_and_check(oracle, precision, coeffs, dict(pair=pair), coeffs.shape[0] == 1, signal, bool(pair), after_run)
+    # (slabs this size take three-step passes by themselves -- the source on a slab face and all: triple = -1, the default)
+    chain.run_and_check(oracle, precision, coeffs, dict(pair=pair, triple=triple), coeffs.shape[0] == 1, signal, bool(pair), after_run,
+                        expect_three_step=triple != 0)
