@@ -2,7 +2,7 @@
 """The step of a MIDDLE rank of the 8-GPU weak-scaling run (BASELINE configs[3]: 1024 x 1024 x 1024 owned planes +
 two ghost planes, both neighbours present), timed on ONE GPU: the slab is its own neighbour on both sides through a
 one-rank RCCL communicator (grouped ncclSend/ncclRecv to self), so everything a rank does per step is there --
-face planes first, two exchanges per two-step pass on the halo stream, march overlapped, flag all-reduce -- except
+face planes first, two exchanges per two-step pass (three per three-step pass) on the halo stream, march overlapped, flag all-reduce -- except
 the xGMI links themselves.  Prints ms per step next to the single-domain engine on the same box.
 
     python tools/middle_rank_bench.py [--steps 60] [--chunks 1,2,4]
@@ -38,9 +38,9 @@ def main():
     sig[0] = 1.0
     src = (nz // 2) * n * n + (n // 2) * n + n // 2
     out = {}
-    modes = ["single steps", "two-step passes"] + ["two-step passes, %d chunk(s)" % int(c) for c in args.chunks.split(",") if c]
+    modes = ["single steps", "two-step passes", "three-step passes"] + ["two-step passes, %d chunk(s)" % int(c) for c in args.chunks.split(",") if c]
     for mode in modes:
-        tuning = dict(pair=0 if mode == "single steps" else 1)
+        tuning = dict(pair=0 if mode == "single steps" else 1, triple=1 if mode == "three-step passes" else 0)
         if "chunk" in mode:
             tuning["pair_chunks"] = int(mode.split(",")[1].split()[0])
         eng = E.Engine(mesh, precision="f64", ghost_lo=True, ghost_hi=True, tuning=tuning)
@@ -58,8 +58,9 @@ def main():
             print("  %s: %.3f ms/step, march in %d round(s) of workgroups" % (mode, out[mode], rounds))
     owned = n * n * n
     print("middle rank of configs[3] on one GPU (RCCL to self): single steps %.3f ms/step (%.1f Gnode-updates/s per rank), "
-          "two-step passes %.3f ms/step (%.1f)" % (out["single steps"], owned / out["single steps"] / 1e6,
-                                                  out["two-step passes"], owned / out["two-step passes"] / 1e6))
+          "two-step passes %.3f ms/step (%.1f), three-step passes (three exchanges per pass) %.3f ms/step (%.1f)"
+          % (out["single steps"], owned / out["single steps"] / 1e6, out["two-step passes"], owned / out["two-step passes"] / 1e6,
+             out["three-step passes"], owned / out["three-step passes"] / 1e6))
 
 
 if __name__ == "__main__":

@@ -70,10 +70,11 @@ def main():
     bidx = [(np.arange(counts[d] * (d + 1), dtype=np.uint32) % np.uint32(coeffs.shape[0])).reshape(counts[d], d + 1) for d in range(3)]
     mesh = M.Mesh((n, ny, nz), nodes, coeffs, *bidx)
     src = (nz // 2) * n * ny + (ny // 2) * n + n // 2
-    forms = (("both exchanges under the march", dict(pair=1, slab_early=1)),
-             ("... march in one round", dict(pair=1, slab_early=1, pair_chunks=1)),
-             ("second exchange after the march (round 3)", dict(pair=1, slab_early=0)),
-             ("... march in one round", dict(pair=1, slab_early=0, pair_chunks=1)),
+    forms = (("three-step passes, three exchanges per pass", dict(pair=1, triple=1)),
+             ("... march in one round", dict(pair=1, triple=1, triple_chunks=1)),
+             ("two-step passes, both exchanges under the march", dict(pair=1, slab_early=1, triple=0)),
+             ("... march in one round", dict(pair=1, slab_early=1, pair_chunks=1, triple=0)),
+             ("two-step passes, second exchange after the march", dict(pair=1, slab_early=0, triple=0)),
              ("single steps", dict(pair=0)))
     for transport, (name, tuning) in [(t, f) for t in args.transport.split(",") for f in forms]:
         name = "[%s] %s" % (transport, name)
@@ -84,9 +85,16 @@ def main():
         t = timed(eng, steps)
         waits = eng.query(E.Engine.QUERY_HALO_WAITS)
         wait_us = eng.query(E.Engine.QUERY_HALO_WAIT_NS) / 1e3 / waits if waits else float("nan")
+        t_n = eng.query(E.Engine.QUERY_TRIPLE_MARCH_TIMED)
+        triple_ms = eng.query(E.Engine.QUERY_TRIPLE_MARCH_NS) / 1e6 / t_n if t_n else None
         march_ms, launches, tsteps = eng.kernel_time_detail()
         early, passes, rounds = eng.query(E.Engine.QUERY_EARLY_PASSES), eng.query(E.Engine.QUERY_PASSES), eng.query(E.Engine.QUERY_MARCH_ROUNDS)
+        triples = eng.query(E.Engine.QUERY_TRIPLE_PASSES)
         eng.close()
+        if triples:
+            print("  %-51s %.1f us/step -> at most %.2f x at %d ranks before the links; march %.1f us per pass of three steps, compute stream waits %.1f us "
+                  "for ghosts per timed wait; %d three-step passes" % (name, t * 1e3, t_single / t, ranks, triple_ms * 1e3, wait_us, triples))
+            continue
         print("  %-51s %.1f us/step -> at most %.2f x at %d ranks before the links; march %.1f us (%d round(s)), compute stream waits %.1f us "
               "for ghosts per timed wait; %d of %d passes with the faces' second step on the halo stream"
               % (name, t * 1e3, t_single / t, ranks, march_ms * 1e3, rounds, wait_us, early, passes))
