@@ -212,6 +212,50 @@ class Chain:
         self.op(S, "fix-up list + boundary nodes to t+2", reads=self.planes(k, o1, self.OWNED) | self.planes(k, b, marched), writes=self.planes(k, o2, marched))
         self.step_done(k)
 
+    # --- engine_triple.hip.h: enqueue_triple_slab (round 6) -------------------------------------------------------------
+    # Three steps per pass, three exchanges.  o1 is the engine's FIFTH field (the t+1 field; the communicator does not know it): its
+    # faces travel in the face / ghost planes of the t+3 field o3, one plane-sized copy either side of exchange 1.  The march covers
+    # "inner" (t+1 at its shell nodes, t+3) and stores t+2 on the planes next to the faces as well; faces and next planes take
+    # plain steps.  Every level's source sample comes behind the wait for that level's ghosts.
+    def enqueue_triple_part(self, k, part, a, b, o1, o2, o3):
+        S = ("S", k)
+        src = self.source_planes(k)
+        faces = ["face_" + side for side in self.sides(k)]
+        ghosts = ["ghost_" + side for side in self.sides(k)]
+        nexts = ["next_" + side for side in self.sides(k)]
+        first = faces + nexts
+        inner = [p for p in self.OWNED if p not in first]
+        if part == 0:
+            self.wait_ghosts(k, b)
+            if src:
+                self.op(S, "source sample into t", reads=self.planes(k, b, src), writes=self.planes(k, b, src))
+            self.op(S, "faces and the planes next to them to t+1", reads=self.planes(k, b, self.ALL) | self.planes(k, a, first), writes=self.planes(k, o1, first))
+            if faces:
+                self.op(S, "t+1 faces into the t+3 field's face planes", reads=self.planes(k, o1, faces), writes=self.planes(k, o3, faces))
+            self.bulk(k, "three-step march", reads=self.planes(k, b, self.ALL) | self.planes(k, a, self.OWNED),
+                      writes=self.planes(k, o1, inner) | self.planes(k, o2, inner + nexts) | self.planes(k, o3, inner))
+            yield o3, False                                  # exchange 1, behind the march
+            self.op(S, "boundary nodes of the march's planes to t+1", reads=self.planes(k, b, self.OWNED) | self.planes(k, a, inner), writes=self.planes(k, o1, inner))
+        elif part == 1:
+            self.wait_ghosts(k, o3)
+            if ghosts:
+                self.op(S, "the neighbours' t+1 faces out of the t+3 field's ghost planes", reads=self.planes(k, o3, ghosts), writes=self.planes(k, o1, ghosts))
+            if src:
+                self.op(S, "source sample into t+1", reads=self.planes(k, o1, src), writes=self.planes(k, o1, src))
+            self.op(S, "faces to t+2", reads=self.planes(k, o1, ghosts + faces + nexts) | self.planes(k, b, faces), writes=self.planes(k, o2, faces))
+            yield o2, False                                  # exchange 2
+            self.op(S, "second level's list + boundary nodes from the next planes on to t+2", reads=self.planes(k, o1, self.OWNED) | self.planes(k, b, inner + nexts),
+                    writes=self.planes(k, o2, inner + nexts))
+        else:
+            self.wait_ghosts(k, o2)
+            if src:
+                self.op(S, "source sample into t+2", reads=self.planes(k, o2, src), writes=self.planes(k, o2, src))
+            self.op(S, "faces and the planes next to them to t+3", reads=self.planes(k, o2, self.ALL) | self.planes(k, o1, first), writes=self.planes(k, o3, first))
+            yield o3, False                                  # exchange 3
+            self.op(S, "third level's list + boundary nodes of the march's planes to t+3", reads=self.planes(k, o2, self.OWNED) | self.planes(k, o1, inner),
+                    writes=self.planes(k, o3, inner))
+            self.step_done(k)
+
     # --- engine_slab.hip.h: group_run ----------------------------------------------------------------------------------
     def enqueue_all(self, make):
         """One step (or half a pass) of every slab, lockstep as wv_run_group enqueues them: slab after slab."""
@@ -220,10 +264,14 @@ class Chain:
                 self.exchange_faces(k, buf, on_halo)
 
     def run(self, kinds):
-        """kinds: a sequence of "step" / "pass"; every slab takes the same ones."""
+        """kinds: a sequence of "step" / "pass" / "triple" (a three-step pass); every slab takes the same ones."""
         prv, cur, spare = 0, 1, [2, 3]
         for kind in kinds:
-            if kind == "step":
+            if kind == "triple":
+                for part in range(3):
+                    self.enqueue_all(lambda k: self.enqueue_triple_part(k, part, prv, cur, 4, spare[0], spare[1]))
+                prv, cur, spare = spare[0], spare[1], [prv, cur]
+            elif kind == "step":
                 self.enqueue_all(lambda k: self.enqueue_step(k, cur, prv))          # in place: the next field goes where `previous` was
                 prv, cur = cur, prv
             else:
@@ -398,6 +446,37 @@ def test_the_transport_orders_every_conflicting_access(n, kinds, source, early):
     if early and "pass" in kinds:                          # (the order under test is the one that ran)
         near_cut = source is not None and source[1] != "inner"
         assert any("halo stream" in o.name for o in chain.ops) or (near_cut and n == 2)
+
+
+TRIPLES = [["triple"] * 5, ["step", "step", "triple", "triple", "pass", "step", "triple", "pass", "triple", "triple", "step"],
+           ["triple", "pass", "triple", "step", "step", "triple", "triple", "pass", "pass", "triple"]]
+
+
+@pytest.mark.parametrize("transport", ["in-process", "rccl", "ipc"])
+@pytest.mark.parametrize("n,source", CHAINS, ids=str)
+@pytest.mark.parametrize("kinds", TRIPLES, ids=lambda s: "".join(k[0] for k in s))
+def test_three_step_passes_of_slabs_order_every_conflicting_access(n, kinds, source, transport):
+    """Round 6 (engine_triple.hip.h, enqueue_triple_slab): three exchanges per pass -- the t+1 faces by way of the t+3 field's face and
+    ghost planes, which the SAME pass's third exchange overwrites -- mixed with two-step passes and single steps, the source anywhere
+    (on a face, in the neighbour's ghost copy, next to them), over all three transports, whose code is unchanged."""
+    for early in (True, False):
+        chain = {"in-process": lambda: Chain(n, Rules(early=early), source), "rccl": lambda: RcclChain(n, source, early=early),
+                 "ipc": lambda: IpcChain(n, source, early=early)}[transport]().run(kinds)
+        bad = unordered_conflicts(chain)
+        assert not bad, bad[:3]
+        assert any("three-step march" in o.name for o in chain.ops)
+
+
+def test_what_orders_the_t1_faces_detour_through_the_t3_field():
+    """The ghost plane of the t+3 field holds the neighbour's t+1 face from exchange 1 until this slab has copied it out (part 1), and
+    the neighbour's t+3 face from exchange 3 on: nothing but causality orders the two -- the neighbour's exchange 3 follows its wait for
+    THIS slab's exchange 2, which follows the copy in stream order.  Without waits for ghosts at all the detour races (and so does
+    everything else); without the wait for its own pushes a source on a face still races with the push of the plane it goes into."""
+    assert not unordered_conflicts(Chain(3, Rules(), None).run(["triple"] * 4))
+    assert unordered_conflicts(RcclChain(3, None, wait_for_ghosts=False).run(["triple"] * 4))
+    late = unordered_conflicts(IpcChain(3, None, counters=False).run(["triple"] * 4))
+    assert late and any("t+3 field's ghost planes" in a or "t+3 field's ghost planes" in b for _, a, _, b, _ in late), late[:3]
+    assert unordered_conflicts(Chain(3, Rules(own_pushes=False), (1, "face_lo")).run(["triple"] * 4))
 
 
 @pytest.mark.parametrize("kinds", [k for k in SEQUENCES if "pass" in k], ids=lambda s: "".join(k[0] for k in s))
