@@ -92,7 +92,7 @@ def main():
              prev=e.read_field(E.BUF_PREVIOUS)[lo:hi], trace=got, cols=np.array([pos for pos, _ in mine], dtype=np.int64),
              bd1=e.read_boundary_data(1), bd2=e.read_boundary_data(2), bd3=e.read_boundary_data(3),
              passes=e.query(E.Engine.QUERY_PASSES), early=e.query(E.Engine.QUERY_EARLY_PASSES),
-             exchanges=e.query(E.Engine.QUERY_HALO_EXCHANGES))
+             exchanges=e.query(E.Engine.QUERY_HALO_EXCHANGES), triples=e.query(E.Engine.QUERY_TRIPLE_PASSES))
     e.close()
     print("OK rank %d steps %d flag %d" % (rank, done, flag))
 

@@ -40,7 +40,9 @@ def mock_dir(tmp_path_factory, built_library):
 
 @pytest.mark.parametrize("world,room,dims,precision,pair,tuning", [
     (2, "box", (20, 18, 24), "f64", 0, ""), (2, "box", (20, 18, 24), "f64", 1, ""), (3, "L", (28, 24, 30), "f64", 1, "slab_early=0"),
-    (4, "blob", (30, 26, 33), "f32", 1, ""), (3, "box", (140, 12, 40), "f64", 1, "slab_early=1")])
+    (4, "blob", (30, 26, 33), "f32", 1, ""), (3, "box", (140, 12, 40), "f64", 1, "slab_early=1"),
+    # three-step passes (three exchanges per pass, the t+1 faces by way of the t+3 field's planes) between PROCESSES, real IPC handles
+    (3, "box", (140, 12, 40), "f64", 1, "triple=1,tile_lists=0,slab_early=1"), (2, "L", (28, 24, 30), "f32", 1, "triple=1,tile_lists=0")])
 def test_processes_with_ipc_mapped_fields_equal_the_single_domain(shm_mock, tmp_path, world, room, dims, precision, pair, tuning):
     from _ipc_chain_rank import case
     from wayverb_amd import engine as E
@@ -88,7 +90,11 @@ def test_processes_with_ipc_mapped_fields_equal_the_single_domain(shm_mock, tmp_
         mem = np.concatenate([g["bd%d" % (d + 1)]["filter_memory"] for g in got])
         assert mem.tobytes() == np.ascontiguousarray(want["bd"][d][rows]["filter_memory"]).tobytes(), "filter memories differ (D=%d)" % (d + 1)
     planes = min(SlabLayout(dims, r, world).z1 - SlabLayout(dims, r, world).z0 for r in range(world))
-    if pair and planes >= 4:
+    if "triple=1" in tuning:
+        # 27 steps: two single sweeps for the written fields, eight three-step passes of three exchanges each, one step
+        assert all(int(g["triples"]) == (steps - 2) // 3 and int(g["passes"]) == 0 for g in got), [(int(g["triples"]), int(g["passes"])) for g in got]
+        assert all(int(g["exchanges"]) == 3 * int(g["triples"]) + (steps - 3 * int(g["triples"])) for g in got)
+    elif pair and planes >= 4:
         assert all(int(g["passes"]) == (steps - 2) // 2 for g in got), [int(g["passes"]) for g in got]
         assert all(int(g["exchanges"]) == 2 * int(g["passes"]) + (steps - 2 * int(g["passes"])) for g in got)
 
