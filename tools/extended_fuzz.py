@@ -46,17 +46,20 @@ def main():
         def chains(seed, _fn=S.test_random_slab_chains_equal_the_single_domain):
             # the engine's choice of stepping, two-step passes forced with both exchanges under the march (round 4), and in round 3's
             # order (the test's _step_mode fixture)
-            for pair, early in ((None, 1), (1, 1), (1, 0)):
+            # ... and three-step passes forced (round 6: three exchanges per pass; slabs of fewer than six planes send the chain to two-step passes)
+            for pair, early, triple in ((None, 1, None), (1, 1, None), (1, 0, None), (1, 1, 1)):
                 old = dict(E.default_tuning)
                 if pair is not None:
                     E.default_tuning["pair"] = pair
                     E.default_tuning["slab_early"] = early
+                if triple is not None:
+                    E.default_tuning.update(triple=1, tile_lists=0)
                 try:
-                    _fn(None, seed, "two-step-passes" if pair else "single-steps")
+                    _fn(None, seed, "three-step-passes" if triple else ("two-step-passes" if pair else "single-steps"))
                 finally:
                     E.default_tuning.clear()
                     E.default_tuning.update(old)
-        families.append(("random slab chains against the single domain, single steps and passes in both orders", chains))
+        families.append(("random slab chains against the single domain, single steps, two-step passes in both orders, three-step passes", chains))
     except Exception:  # noqa: BLE001
         traceback.print_exc()
     failed = False
