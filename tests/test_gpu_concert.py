@@ -87,13 +87,15 @@ def test_concert_hall_impulse_response(hall, oracle, precision, dtype):
     assert spec[freqs > 260].max() < 5e-2 * spec.max()                             # band-limited at the 200 Hz cutoff
 
 
-@pytest.mark.parametrize("pair", [0, 1], ids=["single-steps", "two-step-passes"])
+@pytest.mark.parametrize("pair", [0, 1, 3], ids=["single-steps", "two-step-passes", "three-step-passes"])
 @pytest.mark.parametrize("world", [2, 8])
 def test_concert_hall_in_z_slabs(hall, world, pair, monkeypatch):
     """The hall cut into z-slabs and stepped as a chain == the single-domain run (fields, wall filter
-    memories, receiver traces), source and receiver wherever they fall."""
+    memories, receiver traces), source and receiver wherever they fall.  (Three-step passes: every slab marches a work list of the
+    hall's live pieces between its faces' neighbours -- build_triple_units on [triple_z0_, triple_z1_).)"""
     from test_gpu_slabs import assert_same, single_domain, slab_chain
-    monkeypatch.setitem(E.default_tuning, "pair", pair)
+    monkeypatch.setitem(E.default_tuning, "pair", min(pair, 1))
+    monkeypatch.setitem(E.default_tuning, "triple", 1 if pair == 3 else 0)
     vm = hall["vm"]
     mesh = vm.mesh
     steps = 90
@@ -107,6 +109,8 @@ def test_concert_hall_in_z_slabs(hall, world, pair, monkeypatch):
     got = slab_chain(mesh, world, "f64", zeros, zeros, E.SOURCE_HARD, src, sig, receivers, steps)
     assert want["done"] == steps and want["flag"] == 0 and np.abs(want["cur"]).max() > 0
     assert_same(got, want, mesh)
+    if pair == 3:
+        assert all(t == (steps - 2) // 3 for t in got["queries"][2]), got["queries"]   # (two single sweeps first: the fields were written to)
 
 
 @pytest.mark.parametrize("slabs", [2, 5])

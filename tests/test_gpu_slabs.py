@@ -14,7 +14,8 @@ from wayverb_amd.slab import SlabLayout, place_source_and_receivers, slab_mesh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes", "two-step-passes-round-3-order", "three-step-passes"])
+@pytest.fixture(autouse=True, params=["single-steps", "two-step-passes", "two-step-passes-round-3-order", "three-step-passes",
+                                      "three-step-passes-over-work-lists"])
 def _step_mode(request):
     """Every test of this file runs three times: with the engine's default choice (single steps on meshes this
     small); with two-step passes forced on (wv_tuning::pair = 1), where a slab exchanges its face planes
@@ -24,20 +25,22 @@ def _step_mode(request):
     wv_tuning::fuse_planes = 0), which is also what a slab with a source within two planes of a cut falls back to.  Slabs with
     fewer than four planes cannot take two-step passes, and then the whole chain falls back together.
     A fourth time with three-step passes forced on (wv_tuning::triple = 1: engine_triple.hip.h, enqueue_triple_slab -- three exchanges per
-    pass, the face planes and the planes next to them by plain steps); slabs of fewer than six planes, a source on a slab face or a room
-    that marches a work list keep the chain on two-step passes."""
+    pass, the face planes and the planes next to them by plain steps; slabs of fewer than six planes keep the chain on two-step passes),
+    and a fifth with the rooms' work lists left on (these small rooms all count as sparse: every slab then marches a list of live units)."""
     old = dict(E.default_tuning)
     for key in ("pair", "slab_early", "fuse_planes", "triple", "tile_lists"):
         E.default_tuning.pop(key, None)
     if request.param == "three-step-passes":
         E.default_tuning.update(pair=1, triple=1, slab_early=1, tile_lists=0)
+    if request.param == "three-step-passes-over-work-lists":
+        E.default_tuning.update(pair=1, triple=1, slab_early=1)
     if request.param.startswith("two-step-passes"):
         E.default_tuning["pair"] = 1
         E.default_tuning["slab_early"] = 1      # (forced: by default slabs that share a device keep round 3's order)
         if request.param.endswith("round-3-order"):
             E.default_tuning["slab_early"] = 0
             E.default_tuning["fuse_planes"] = 0
-    yield "two-step-passes" if request.param.startswith("two-step-passes") else request.param
+    yield "two-step-passes" if request.param.startswith("two-step-passes") else ("three-step-passes" if request.param.startswith("three-step") else request.param)
     E.default_tuning.clear()
     E.default_tuning.update(old)
 

@@ -65,10 +65,6 @@ int Engine<Real>::ensure_triple() {
     if (rc) return rc;
     triple_z0_ = z_begin_ + (opt_.ghost_lo ? 2 : 0);
     triple_z1_ = z_end_ - (opt_.ghost_hi ? 2 : 0);
-    if (comm_ && pair_units_) {  // (a sparse room cut into slabs keeps its two-step passes)
-        triple_ready_ = false;
-        return WV_OK;
-    }
     if (pair_failed_ || (!pair_sparse_ok_ && opt_.tuning.triple < 0)) {  // (a room so sparse that the sweep's tiles beat the march's units keeps single steps)
         triple_ready_ = false;
         return WV_OK;
@@ -252,7 +248,10 @@ int Engine<Real>::ensure_triple() {
 // run of neighbouring strips with about the same number of units, chunk by chunk.  Sets triple_zc_ / triple_chunks_ to the units' height.
 template <typename Real>
 int Engine<Real>::build_triple_units() {
-    const int owned = z_end_ - z_begin_;
+    // (a slab: the march's planes; a unit that ends at either end of them also stores t+2 on the plane beyond it -- TripleArgs::z2_lo /
+    // z2_hi --, so a node to update there makes the unit live as well)
+    const int owned = triple_z1_ - triple_z0_;
+    const int z_lo = triple_z0_, z_hi = triple_z1_, extra_lo = triple_z0_ > z_begin_ ? 1 : 0, extra_hi = triple_z1_ < z_end_ ? 1 : 0;
     const int lb = triple_lb_;
     const int WX = 64 * (lb / (int)sizeof(Real));
     const int row_waves = pitch_ / WX;
@@ -302,9 +301,9 @@ int Engine<Real>::build_triple_units() {
         uint64_t units = 0;
         for (int sidx = 0; sidx < triple_strips_; ++sidx)
             for (int c = 0; c < n_chunks; ++c) {
-                const int zb = z_begin_ + c * height, ze = std::min(zb + height, z_end_);
+                const int zb = z_lo + c * height, ze = std::min(zb + height, z_hi);
                 bool any = false;
-                for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
+                for (int z = zb - (zb == z_lo ? extra_lo : 0); z < ze + (ze == z_hi ? extra_hi : 0) && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
                 if (per_strip) (*per_strip)[(size_t)sidx] += any;
                 units += any;
             }
@@ -346,9 +345,9 @@ int Engine<Real>::build_triple_units() {
     uint64_t total = 0, live_waves = 0;
     for (int sidx = 0; sidx < triple_strips_; ++sidx)
         for (int c = 0; c < chunks; ++c) {
-            const int zb = z_begin_ + c * zc, ze = std::min(zb + zc, z_end_);
+            const int zb = z_lo + c * zc, ze = std::min(zb + zc, z_hi);
             bool any = false;
-            for (int z = zb; z < ze && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
+            for (int z = zb - (zb == z_lo ? extra_lo : 0); z < ze + (ze == z_hi ? extra_hi : 0) && !any; ++z) any = active[(size_t)z * triple_strips_ + sidx] != 0;
             if (!any) continue;
             uint32_t bits = 0;
             for (int z = std::max(0, zb - 3); z < std::min(nz_, ze + 3); ++z)
@@ -609,7 +608,7 @@ int Engine<Real>::enqueue_triple(int slot, uint64_t signal_pos, bool source_live
 // A source on a face plane: the face travels as computed, before the level's sample goes in -- the neighbour that holds the plane as its ghost
 // adds the sample to its copy itself (as in every other form of step), and every level's source / receiver work comes after the wait for
 // that level's ghosts, which also covers this slab's own push of the plane the sample goes into.
-// Not here: sparse rooms' work lists, anything riding in anything (batch_can_fuse_ is off for slabs).
+// Not here: anything riding in anything (batch_can_fuse_ is off for slabs).
 template <typename Real>
 int Engine<Real>::enqueue_triple_slab(int slot, int part, uint64_t signal_pos, bool source_live) {
     DeviceGuard guard(device_);
