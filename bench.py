@@ -424,6 +424,7 @@ def run_bench(args, guard):
                 "exposed_wait_us_per_wait": round(eng.query(Q.QUERY_HALO_WAIT_NS) / 1e3 / waits, 2) if waits else None,
                 "timed_waits": int(waits),
                 "passes_with_both_exchanges_under_the_march": int(eng.query(Q.QUERY_EARLY_PASSES)), "passes": int(eng.query(Q.QUERY_PASSES)),
+                "three_step_passes": int(eng.query(Q.QUERY_TRIPLE_PASSES)),   # (three exchanges each; `passes`: two-step ones, two each)
                 "neighbours": int(layout.ghost_lo) + int(layout.ghost_hi), "ms_per_step": round(elapsed_mine / args.steps * 1e3, 4),
                 "rank": rank}
         # ... of EVERY rank: rank 0 is an end slab with one neighbour, the least loaded of the chain -- the line carries them all and
