@@ -127,8 +127,8 @@ typedef struct wv_tuning {
                                * leaves much of its mesh outside marches a work list of live pieces, as in two-step passes.  A batch takes them
                                * wherever it has three steps left, then a two-step pass or a single step */
     int32_t triple_chunks;    /* workgroups along z of the three-step march; 0 = fill whole rounds of workgroup slots */
-    int32_t triple_lanes;     /* bytes of a row per lane of the three-step march: 0 the engine decides (doubles: by row length, whichever ran faster
-                               * on boxes of that size; floats: 8), 8 / 16 force (doubles only) */
+    int32_t triple_lanes;     /* bytes of a row per lane of the three-step march: 0 the engine decides (by row length, whichever ran faster on
+                               * boxes of that size), 8 / 16 force */
 } wv_tuning;
 
 typedef struct wv_options {

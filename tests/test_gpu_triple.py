@@ -98,14 +98,15 @@ def test_triple_path_x_facing_walls_on_their_compact_copies_or_not(oracle, dims,
 
 
 @pytest.mark.parametrize("lanes", [8, 16])
-@pytest.mark.parametrize("dims", [(256, 40, 33), (300, 23, 41), (1024, 24, 19), (1100, 13, 12), (2100, 9, 8)], ids=lambda d: "x".join(map(str, d)))
-def test_triple_path_both_lane_widths_of_the_double_march(oracle, dims, lanes):
-    """Doubles march on 16-byte lanes (two per lane, eight waves per workgroup) or on 8-byte lanes (one per lane, up to twelve waves: what
-    short rows get by default): each forced on rows of every length -- one workgroup, two windows, several."""
+@pytest.mark.parametrize("dims", [(256, 40, 33), (300, 23, 41), (1024, 24, 19), (1100, 13, 12), (2100, 9, 8), (4200, 9, 6)], ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_triple_path_both_lane_widths_of_the_march(oracle, dims, lanes, tag, dtype):
+    """The march on 16-byte lanes (two doubles / four floats per lane, eight waves per workgroup) or on 8-byte lanes (one double / two
+    floats per lane, up to twelve waves): each forced on rows of every length -- one workgroup, two windows, several."""
     set_tuning(**ON, triple_lanes=lanes)
     case = _random_case(dims, seed=sum(dims) + lanes, steps=14)
-    want = run_oracle(oracle, case, np.float64, threads=4)
-    got = run_engine(case, "f64")
+    want = run_oracle(oracle, case, dtype, threads=4)
+    got = run_engine(case, tag)
     assert want["flag"] == 0 and got["steps"] == want["steps"] and got["triple_passes"] == 4
     assert np.array_equal(got["trace"].view(np.uint8), want["trace"].view(np.uint8))
     assert got["current"].tobytes() == want["current"].tobytes()
@@ -155,8 +156,6 @@ def test_triple_path_non_box_rooms(oracle, room, tag, dtype):
 def test_triple_path_over_the_work_list_of_a_room_that_leaves_much_of_its_mesh_outside(oracle, room, dims, tag, dtype, lanes):
     """A sparse room's three-step march visits the listed units only -- strips x chunks of planes with a node to update, the live
     waves of each (build_triple_units) -- and everything else keeps its zeros: the same bits as the oracle's dense steps."""
-    if tag == "f32" and lanes == 16:
-        pytest.skip("floats march in 8-byte lanes")
     set_tuning(pair=1, triple=1, triple_lanes=lanes)
     mask = M.room_mask((dims[2], dims[1], dims[0]), room, seed=5)
     nodes, counts = E.classify_nodes(mask)
@@ -179,7 +178,7 @@ def test_triple_path_over_the_work_list_of_a_room_that_leaves_much_of_its_mesh_o
         eng.write_field(prev.astype(dtype), E.BUF_PREVIOUS)
         eng.write_field(cur.astype(dtype), E.BUF_CURRENT)
         got_steps, out = E.run_fast(eng, E.SOURCE_SOFT, src, sig, recv)
-        assert eng.query(E.Engine.QUERY_TRIPLE_PASSES) == (steps - 2) // 3 and eng.query(E.Engine.QUERY_MARCH_LIVE_PERMILLE) < 950
+        assert eng.query(E.Engine.QUERY_TRIPLE_PASSES) == (steps - 2) // 3 and eng.query(E.Engine.QUERY_MARCH_LIVE_PERMILLE) < 980
         assert want["flag"] == 0 and got_steps == steps
         assert np.array_equal(out.astype(dtype).view(np.uint8), want["trace"].view(np.uint8))
         assert eng.read_field(E.BUF_CURRENT).tobytes() == want["current"].tobytes()

@@ -95,7 +95,7 @@ public:
         return (uint64_t)cur_ | (uint64_t)prv_ << 2 | (uint64_t)spare_[0] << 4 | (uint64_t)spare_[1] << 6 | steps_done << 8;
     }
     // ---- engine_triple.hip.h
-    static constexpr int kWideLaneBytes = sizeof(Real) == 8 ? 16 : 8;  // the wider form of the three-step march's lanes this precision has (triple_kernels.hip.h)
+    static constexpr int kWideLaneBytes = 16;  // the wider form of the three-step march's lanes (triple_kernels.hip.h)
     int triple_lane_bytes() const;
     bool triple_eligible();
     int ensure_triple();

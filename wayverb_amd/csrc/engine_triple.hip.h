@@ -49,12 +49,14 @@ bool Engine<Real>::triple_eligible() {
 // SIMD, finer pieces of rows in a sparse room's work list), whichever ran faster on boxes of that row length (profiles/r06/
 // lane_width_by_size.txt; the concert hall at 1 600 Hz, 640-double rows, agrees: 390 against 374): 8 up to 256 doubles (a workgroup of
 // four waves, three of them per CU), 16 from 320, 8 again from 512 (eight to ten waves: one workgroup fills a CU), 16 from 768 (rows
-// that need windows of 8-byte lanes).  Floats: 8 (the 16-byte form does not fit the register file without spills).
+// that need windows of 8-byte lanes).  Floats: 8, but 16 (four floats per lane, with a row less of lookahead: 249 registers) on rows of
+// 513-768 floats, three waves per workgroup and two workgroups per CU: 640^3 473 -> 545, 704^3 501 -> 608, 768^3 580 -> 675
+// Gnode-updates/s end to end; on rows of 1024 it loses (832^3 569 -> 505, 1024^3 734 -> 636), up to 512 it ties.
 // wv_tuning::triple_lanes forces one.
 template <typename Real>
 int Engine<Real>::triple_lane_bytes() const {
-    if (sizeof(Real) == 4) return 8;
     if (opt_.tuning.triple_lanes == 8 || opt_.tuning.triple_lanes == 16) return opt_.tuning.triple_lanes;
+    if (sizeof(Real) == 4) return (pitch_ > 512 && pitch_ <= 768) ? 16 : 8;
     if (pitch_ < triple_wide_from_) return 8;
     return (pitch_ >= 512 && pitch_ < 768) ? 8 : 16;
 }
@@ -233,9 +235,8 @@ int Engine<Real>::ensure_triple() {
     if (!triple_attr_set_) {
         WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (sizeof(Real) == 8)
-            WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        WV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wv::triple_march_kernel<Real, 0, false, kWideLaneBytes>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         triple_attr_set_ = true;
     }
     triple_ready_ = true;

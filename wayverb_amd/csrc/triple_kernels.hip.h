@@ -377,7 +377,9 @@ __device__ __forceinline__ void triple_march_body(const TripleArgs<Real>& a) {
     // the trips' boundaries too: the first four rows of the NEXT trip are asked for in the last four row steps of this one, into the
     // registers of "mid" rows that have retired (all of a trip's loads at its top would be registers waiting for their turn, and a trip
     // that opens with its first loads opens with a memory latency, every wave of the workgroup at the same time).
-    constexpr int LA = (EDGE ? 3 : 4) - (DENSE ? 1 : 0);  // rows of lookahead (the edge strips' offsets live in vector registers: they have fewer to spare)
+    // rows of lookahead (the edge strips' offsets live in vector registers: they have fewer to spare; so have floats on 16-byte lanes, four
+    // values per register row to shift and mask: 256 registers + 20 B of scratch with four rows, 249 and none with three)
+    constexpr int LA = (EDGE ? 3 : 4) - (DENSE ? 1 : 0) - ((sizeof(Real) == 4 && LB == 16) ? 1 : 0);
     auto trip = [&](int f, int set, V(&b_mid)[R0], V(&b_new)[R0], V(&u_mid)[R1], V(&u_new)[R1], V(&w_mid)[R2], V(&w_new)[R2], V(&pv)[R1],
                     V(&pv_next)[R1]) {
         const int z = f - 3;
