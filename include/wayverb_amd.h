@@ -123,9 +123,10 @@ typedef struct wv_tuning {
                                * bound by launches, not bytes), 1 / 0 force on / off.  Only where it is legal (one domain, the source and the
                                * receivers -- at most 63 -- on inside nodes); otherwise two launches per step as ever */
     int32_t triple;           /* three-step passes (triple_kernels.hip.h: 10.7 B per node-update where a two-step pass moves 16): -1 the engine
-                               * decides by mesh size, 1 / 0 force on / off.  One domain only (z-slabs keep two-step passes); a room that
-                               * leaves much of its mesh outside marches a work list of live pieces, as in two-step passes.  A batch takes them
-                               * wherever it has three steps left, then a two-step pass or a single step */
+                               * decides by mesh size, 1 / 0 force on / off.  Wherever two-step passes run: one domain, a z-slab of a chain
+                               * (three halo exchanges per pass; every rank's consent, like two-step passes), a room that leaves much of its
+                               * mesh outside (a work list of live pieces).  A batch takes them wherever it has three steps left, then a
+                               * two-step pass or a single step */
     int32_t triple_chunks;    /* workgroups along z of the three-step march; 0 = fill whole rounds of workgroup slots */
     int32_t triple_lanes;     /* bytes of a row per lane of the three-step march: 0 the engine decides (by row length, whichever ran faster on
                                * boxes of that size), 8 / 16 force */

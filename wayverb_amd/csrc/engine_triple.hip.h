@@ -16,7 +16,11 @@
 //   boundary nodes -> t+3      own old value from t+1, neighbours from t+2
 // Five fields: the engine's four rotate as in a two-step pass (the two that held t-1 and t receive t+2 and t+3 of the next pass), the
 // fifth holds t+1 at the shell nodes and the boundary nodes of whatever pass is in flight and zeros at outside nodes.
-// Results are bit-identical to three single steps (tests/test_gpu_triple.py).
+// (the exact-flags check shares the launch of fix-up list 3; the source / receiver work rides in the boundary launches where it may:
+// five launches.)  The x-facing walls' entries work on compact copies at all three levels and finish the two nodes in front of them
+// (boundary_kernels.hip.h, xwall3_node); a room that leaves much of its mesh outside marches a work list (build_triple_units); a
+// z-slab of a chain takes the same pass in three parts around three halo exchanges (enqueue_triple_slab).
+// Results are bit-identical to three single steps (tests/test_gpu_triple.py, test_gpu_slabs.py).
 #pragma once
 #include "engine.hip.h"
 #include "triple_kernels.hip.h"
@@ -24,8 +28,8 @@
 namespace wv {
 
 // May this engine take three-step passes right now?  Everything a two-step pass needs (it shares the pair map, the second level's
-// fix-up list and the spare fields), one domain (a slab's faces would need three exchanges per pass), a room that fills its mesh
-// (the march has no unit lists), and -- unless forced -- a mesh big enough that bytes, not launches and warm-up planes, decide.
+// fix-up list and the spare fields), a slab thick enough to leave the march something between its faces' neighbours, and -- unless
+// forced -- a mesh big enough that bytes, not launches and warm-up planes, decide.
 template <typename Real>
 bool Engine<Real>::triple_eligible() {
     if (opt_.tuning.triple == 0 || triple_failed_) return false;
