@@ -96,7 +96,7 @@ int Engine<Real>::ensure_triple() {
     // under wv_tuning::slab_early -- which a pass here steps by gathering from the fields)
     const bool xw = xw_active_ && pair_inner_ok_ > 0 && opt_.tuning.boundary_xwall != 2 && !(comm_ && opt_.tuning.slab_early == 0);
     if (triple_map_ && triple_source_ == src && triple_io_generation_ == io_generation_ && triple_xw_ == xw) {
-        triple_ready_ = true;
+        triple_ready_ = !(pair_units_ && !triple_units_);  // (a sparse room whose work list could not be had stays with two-step passes)
         return WV_OK;
     }
     const uint64_t cls_bytes = (uint64_t)cls_pitch_ * 4u * (uint64_t)((ny_ + 3) / 4) * nz_;
